@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Golden-vector generator  --  TEST INFRASTRUCTURE, build-container only.
+
+Imports the reference's own ``model.model`` / ``model.layers`` (read-only mount at
+/root/reference, CPU) and writes small ``.npz`` fixtures under ``tests/golden/``.
+The reference never travels: only the numeric inputs/outputs land in the repo.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_goldens.py
+
+Weights for the net-level goldens are drawn by ``oracle.msau_oracle.init_params(cfg, seed)``
+(seeded torch.Generator, reproducible) and loaded into the reference module with
+``load_state_dict`` -- fixtures then only need the seeds, a checksum of what the seeds
+produced, and the reference's outputs.  Op-level goldens store full tensors.
+"""
+import io
+import os
+import sys
+import contextlib
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("MSAU_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+
+from oracle import msau_oracle as O
+
+with contextlib.redirect_stdout(io.StringIO()):
+    from model.model import MSAUWrapper, MultiConvResidualBlock            # reference
+    from model.layers import layers as RL                                  # reference
+    from model.layers import attention as RA                               # reference
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def summarize(t: torch.Tensor, n: int = 64):
+    """norm, sum, strided sample (up to n elements) of a tensor."""
+    f = t.detach().reshape(-1).double()
+    stride = max(1, f.numel() // n)
+    return np.array([float(f.norm()), float(f.sum())]), f[::stride][:n].float().numpy()
+
+
+def checksum(sd):
+    return float(sum(float(v.double().abs().sum()) for v in sd.values()))
+
+
+def build_ref(cfg):
+    kw = dict(scale_space_num=cfg["scale_space_num"], res_depth=cfg["res_depth"],
+              featRoot=cfg["featRoot"], filter_size=cfg["filter_size"],
+              pool_size=cfg["pool_size"], final_act="softmax")
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = MSAUWrapper(cfg["channels"], cfg["n_class"], kw)
+    net.msau_net.num_blocks = cfg["num_blocks"]          # blocks are independent modules
+    return net
+
+
+def net_golden(name, cfg, B, H, W, seed, dense=False, with_step=True):
+    sd = O.init_params(dict(cfg, num_blocks=3), seed)    # the reference always owns 3 blocks
+    net = build_ref(cfg)
+    net.load_state_dict(sd)
+    x, label = O.synthetic_batch(B, cfg["channels"], H, W, cfg["n_class"], seed + 1, dense=dense)
+    pred, logits, aux = net(x)
+    out = dict(cfg=np.array(repr(cfg)), B=B, H=H, W=W, seed=seed, dense=dense,
+               weights_checksum=checksum(sd), input_checksum=float(x.double().abs().sum()),
+               label_checksum=float(label.sum()))
+    big = H * W > 20000                      # keep fixtures small: strided sample + norms
+    def put(nm, t):
+        if big:
+            out[nm + "_sub"] = t.detach()[:, :, ::7, ::5].numpy()
+            out[nm + "_summary"] = summarize(t)[0]
+        else:
+            out[nm] = t.detach().numpy()
+    put("pred", pred); put("logits", logits)
+    if aux is not None:
+        put("aux", aux)
+    if with_step:
+        # reference loss is batch-1 only (model.py:452-453): evaluate per sample, average
+        losses = []
+        for i in range(B):
+            l_i = net.loss(logits[i:i + 1], aux[i:i + 1], label[i:i + 1])
+            losses.append(l_i)
+        loss = sum(losses) / B
+        net.zero_grad()
+        loss.backward()
+        out["loss"] = float(loss)
+        names, gsum, gsamp, dead = [], [], [], []
+        for k, p in net.named_parameters():
+            if int(k.split(".")[2]) >= cfg["num_blocks"]:
+                continue
+            names.append(k)
+            if p.grad is None:
+                dead.append(k)
+                gsum.append(np.zeros(2)); gsamp.append(np.zeros(1, np.float32))
+            else:
+                s, smp = summarize(p.grad)
+                gsum.append(s); gsamp.append(smp)
+        out["param_names"] = np.array(names)
+        out["dead_params"] = np.array(dead)
+        out["grad_summary"] = np.stack(gsum)
+        out["grad_samples"] = np.array(gsamp, dtype=object)
+        # one optimiser step exactly as train_chargrid_funsd_msau.py:24-26,57-59
+        opt = torch.optim.Adam(filter(lambda p: p.requires_grad, net.parameters()), lr=1e-4)
+        before = {k: p.detach().clone() for k, p in net.named_parameters()}
+        gn = torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+        opt.step()
+        out["grad_norm"] = float(gn)
+        dsum, dsamp = [], []
+        for k, p in net.named_parameters():
+            if k in names:
+                s, smp = summarize(p.detach() - before[k])
+                dsum.append(s); dsamp.append(smp)
+        out["delta_summary"] = np.stack(dsum)
+        out["delta_samples"] = np.array(dsamp, dtype=object)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, "loss" in out and out["loss"])
+
+
+def op_goldens():
+    torch.manual_seed(1234)
+    out = {}
+
+    def fwd_bwd(tag, module, x, **kw):
+        x = x.clone().requires_grad_(True)
+        y = module(x, **kw)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        out[f"{tag}.x"] = x.detach().numpy(); out[f"{tag}.y"] = y.detach().numpy()
+        out[f"{tag}.gy"] = gy.numpy(); out[f"{tag}.gx"] = x.grad.numpy()
+        for k, p in module.named_parameters():
+            out[f"{tag}.p.{k}"] = p.detach().numpy()
+            out[f"{tag}.g.{k}"] = p.grad.numpy()
+
+    # A2: 3x3 / 1x1 / 4x4 SAME convs, odd sizes, with and without ReLU
+    fwd_bwd("conv3", RL.Conv2dBnLrnDrop([3, 3, 8, 16], activation=torch.nn.ReLU), torch.randn(2, 8, 11, 9))
+    fwd_bwd("conv3lin", RL.Conv2dBnLrnDrop([3, 3, 16, 8], activation=None), torch.randn(1, 16, 7, 13))
+    fwd_bwd("conv1", RL.Conv2dBnLrnDrop([1, 1, 32, 16], activation=torch.nn.ReLU), torch.randn(2, 32, 5, 6))
+    fwd_bwd("conv4", RL.Conv2dBnLrnDrop([4, 4, 8, 5], activation=None), torch.randn(2, 8, 9, 10))
+    fwd_bwd("conv3c13", RL.Conv2dBnLrnDrop([3, 3, 13, 8], activation=None), torch.randn(1, 13, 6, 7))
+    # A3: dilated conv + LRN, all dilations used by S=4
+    for d, (ci, co) in zip((1, 2, 4, 8), ((5, 8), (8, 16), (16, 32), (32, 64))):
+        fwd_bwd(f"dil{d}", RL.DilConv2dBnLrnDrop([3, 3, ci, co], rate=d, activation=None),
+                3.0 * torch.randn(1, ci, 19, 17))
+    # LRN alone with large activations so the normaliser matters
+    for C in (8, 16, 64):
+        lrn_mod = torch.nn.LocalResponseNorm(C)
+        fwd_bwd(f"lrn{C}", lrn_mod, 20.0 * torch.randn(2, C, 5, 7))
+    # A4: transposed conv, output_size odd and even
+    fwd_bwd("deconv_even", RL.Deconv2DBnLrnDrop([3, 3, 8, 16], activation=None), torch.randn(2, 16, 5, 4),
+            output_size=[10, 8])
+    fwd_bwd("deconv_odd", RL.Deconv2DBnLrnDrop([3, 3, 8, 16], activation=None), torch.randn(1, 16, 5, 4),
+            output_size=[9, 7])
+    # A5: residual block
+    fwd_bwd("res", MultiConvResidualBlock(2, 3, 8, False, torch.nn.ReLU), torch.randn(2, 8, 9, 7))
+    # A6: self attention (C=64 -> d=8) and (C=32 -> d=4)
+    fwd_bwd("attn64", RA.SAWrapperBlock(64), torch.randn(2, 64, 5, 6))
+    fwd_bwd("attn32", RA.SAWrapperBlock(32), 2.0 * torch.randn(1, 32, 7, 3))
+    # A7: zero SAME pad + 2x2 max pool on odd sizes (post-ReLU input, with ties at 0)
+    x = torch.relu(torch.randn(2, 8, 7, 9)).requires_grad_(True)
+    y = torch.nn.functional.max_pool2d(RL.pad_2d(x, 'SAME', 'pool2d', 2, 2, 2, 2), 2, 2)
+    gy = torch.randn_like(y); y.backward(gy)
+    out["pool.x"], out["pool.y"], out["pool.gy"], out["pool.gx"] = x.detach().numpy(), y.detach().numpy(), gy.numpy(), x.grad.numpy()
+    # A11: masked CE loss, batch 1
+    with contextlib.redirect_stdout(io.StringIO()):
+        w = MSAUWrapper(4, 5, dict(scale_space_num=2, res_depth=1, featRoot=4, final_act="softmax"))
+    lg = torch.randn(1, 5, 6, 7, requires_grad=True); ax = torch.randn(1, 5, 6, 7, requires_grad=True)
+    lab = torch.randint(0, 5, (1, 6, 7))
+    loss = w.loss(lg, ax, lab); loss.backward()
+    out["ce.logits"], out["ce.aux"], out["ce.label"] = lg.detach().numpy(), ax.detach().numpy(), lab.numpy()
+    out["ce.loss"], out["ce.glogits"], out["ce.gaux"] = float(loss), lg.grad.numpy(), ax.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "ops.npz"), **out)
+    print("wrote ops", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    op_goldens()
+    base = dict(n_class=5, scale_space_num=4, res_depth=2, featRoot=8, filter_size=3, pool_size=2, num_blocks=3)
+    # G2: the hyper-parameters the reference instantiates (train_chargrid_funsd_msau.py:211-214), odd size
+    net_golden("net_f8_c13_33x26", dict(base, channels=13), 1, 33, 26, seed=11)
+    # batch 2, even size, small width (exercises 8-channel padding: featRoot 4, d = 32//8 = 4)
+    net_golden("net_f4_c13_b2_64x48", dict(base, channels=13, featRoot=4), 2, 64, 48, seed=12)
+    # cfg 1 miniature: 1 stage (aux is None -> no loss golden)
+    net_golden("net_1stage_c32_b2_40x40", dict(base, channels=32, num_blocks=1), 2, 40, 40, seed=13, with_step=False)
+    # cfg 4 miniature: 2 stages, dense (BERT-like) input
+    net_golden("net_2stage_c24_dense_24x40", dict(base, channels=24, num_blocks=2), 1, 24, 40, seed=14, dense=True)
+    # res_depth 3 / scale_space_num 3 (wrapper defaults differ from the train script)
+    net_golden("net_r3_s3_c8_21x35", dict(base, channels=8, res_depth=3, scale_space_num=3), 1, 21, 35, seed=15)
+    # cfg 2 geometry checksum: 336x256x64, 3 stages, forward + loss + grads summaries
+    net_golden("net_cfg2_336x256x64", dict(base, channels=64), 1, 336, 256, seed=16)
