@@ -1,0 +1,252 @@
+/*
+ * msau_hip.h -- C ABI of libmsau_hip.so: the MI355X (gfx950) kernels behind the MSAU train path.
+ *
+ * The reference (datvo06/MSAU) has no FFI layer: its hot path reaches the backend through
+ * torch.nn modules.  Each entry point below replaces the backend op(s) one reference call site
+ * reaches; the call site is cited as <file>:<line> relative to the reference root.  The Python
+ * host side (msau_amd/) binds these with ctypes and passes raw device pointers; INTEGRATION.md
+ * shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless the name ends in _host.
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises.
+ *  - activations are NHWC ("pixel-major, channel-minor"): [B][H][W][Cs] with Cs = stored channels,
+ *    a multiple of 8 (real channels first, zero padding after).  dtype selects the STORAGE type of
+ *    activations and packed weights (MSAU_F32 or MSAU_BF16); accumulation is always fp32.
+ *  - every function returns 0 on success, a negative msau_status otherwise; msau_last_error()
+ *    returns a thread-local message.  Nothing throws across the ABI.
+ *  - functions are re-entrant per stream; handles/buffers are not thread-safe.
+ */
+#ifndef MSAU_HIP_H
+#define MSAU_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { MSAU_F32 = 0, MSAU_BF16 = 1 } msau_dtype;
+
+typedef enum {
+    MSAU_OK = 0,
+    MSAU_ERR_ARG = -1,      /* bad shape / flag / alignment               */
+    MSAU_ERR_LDS = -2,      /* tile does not fit the 160 KiB LDS          */
+    MSAU_ERR_HIP = -3       /* a HIP runtime call failed                  */
+} msau_status;
+
+const char* msau_last_error(void);
+int msau_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution, used for: SAME conv 3x3 / dilated 3x3 / 1x1 / 4x4 forward
+ * (model/layers/layers.py:82-102,152-164 -> torch.nn.Conv2d + utils.pad_2d), its data gradient,
+ * the transposed-conv forward (layers.py:249-250 -> ConvTranspose2d, `ups`=2) and the
+ * transposed-conv data gradient (`stride`=2).  The concat of model/model.py:147,242,251 is folded
+ * in as a second source pointer.
+ *
+ *   v   = sum_{tap,c} in(b, oy*stride + ky*dil - pad_t, ox*stride + kx*dil - pad_l, c) * W[co][tap][c]
+ *         (+ bias[co])
+ *   in  = concat(x1, x2) along channels, optionally ReLU'd on load (MSAU_CONV_RELU_IN); with ups=2 the
+ *         input is the zero-stuffed image (value at even virtual coords only)
+ *   v  *= (mask_a > 0)            if MSAU_CONV_MASK_A        (backward through a ReLU on the conv input)
+ *   v  += add                     if MSAU_CONV_ADD           (forward: residual; backward: other grad path)
+ *   v  += y_old                   if MSAU_CONV_ACCUM
+ *   v   = max(v, 0)               if MSAU_CONV_RELU_OUT
+ *   v  *= (mask_b > 0)            if MSAU_CONV_MASK_B        (backward through the ReLU that produced y's tensor)
+ *   y   = v                       (mask_a, add, mask_b, y share y's shape [B][Hout][Wout][Cout])
+ * ------------------------------------------------------------------------------------------ */
+enum {
+    MSAU_CONV_RELU_IN  = 1,
+    MSAU_CONV_RELU_OUT = 2,
+    MSAU_CONV_ADD      = 4,
+    MSAU_CONV_ACCUM    = 8,
+    MSAU_CONV_MASK_A   = 16,
+    MSAU_CONV_MASK_B   = 32
+};
+
+typedef struct {
+    int32_t B, Hin, Win, Hout, Wout;
+    int32_t C1, C2;             /* stored channels of x1 / x2 (C2 = 0: single source)               */
+    int32_t Cout;               /* stored output channels                                           */
+    int32_t KH, KW, dil;
+    int32_t pad_t, pad_l;
+    int32_t stride;             /* 1 | 2                                                            */
+    int32_t ups;                /* 1 | 2                                                            */
+    int32_t flags;
+    const void* x1;
+    const void* x2;
+    const void* wpack;          /* geometry.bytes bytes, written by msau_pack_params           */
+    const float* bias;          /* [Cout] fp32 or NULL                                              */
+    const void* add;
+    const void* mask_a;
+    const void* mask_b;
+    void* y;
+} msau_conv_desc;
+
+/* Geometry of the packed weight image the conv kernel expects for a given layer.
+ * rows = roundup16(Cout) padded up to a power-of-two number of 16-row tiles; K is laid out as
+ * [chunk][tap][channel-in-chunk] with `cch` channels per chunk, padded to a multiple of 32.        */
+typedef struct {
+    int32_t cch;        /* channels staged per K-chunk (multiple of 8)      */
+    int32_t nchunks;
+    int32_t kchunk;     /* padded K elements per chunk (multiple of 32)     */
+    int32_t rows;       /* padded rows                                      */
+    int64_t bytes;      /* total bytes of the packed image                  */
+} msau_conv_pack_geom;
+
+int msau_conv_pack_geometry(int dtype, int C1_stored, int C2_stored, int Cout_stored, int KH, int KW, int dil,
+                            int stride, int ups, msau_conv_pack_geom* out);
+int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight / bias gradient of the same convolution (autograd of torch.nn.Conv2d reached from
+ * train_chargrid_funsd_msau.py:57 `loss.backward()`), and with stride=2 of the transposed conv
+ * (roles of input and output-gradient swapped, see msau_amd/plan.py).
+ *   slab[s][co][k]  partial sums over the pixel tiles workgroup s visited (deterministic, no atomics)
+ *   k = [chunk][tap][channel] as in the forward pack, plus one extra column holding sum(g) = dbias.
+ * msau_wgrad_reduce() sums the slabs and scatters into the flat fp32 gradient buffer.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t B, Hin, Win, Hout, Wout;
+    int32_t C1, C2, Cout;
+    int32_t KH, KW, dil, pad_t, pad_l, stride;
+    int32_t flags;              /* MSAU_CONV_RELU_IN only                                           */
+    const void* x1;
+    const void* x2;
+    const void* g;              /* [B][Hout][Wout][Cout] gradient w.r.t. the conv's pre-activation  */
+    float* slabs;               /* [nslabs][Cout][kext] fp32                                        */
+    int32_t nslabs;             /* number of workgroups per chunk to launch (<= tiles)              */
+} msau_wgrad_desc;
+
+typedef struct {
+    int32_t cch, nchunks;
+    int32_t kext;               /* columns per row of a slab: nchunks*taps*cch + 8, rounded to 16   */
+    int32_t max_slabs;          /* number of pixel tiles (upper bound for nslabs)                   */
+    int64_t slab_bytes;         /* bytes of ONE slab                                                */
+} msau_wgrad_geom;
+
+int msau_wgrad_geometry(int dtype, const msau_wgrad_desc* d, msau_wgrad_geom* out);
+int msau_conv2d_wgrad(void* stream, int dtype, const msau_wgrad_desc* d);
+
+/* ------------------------------------------------------------------------------------------
+ * Parameter packing (fp32 master parameters in the reference's OIHW / IOHW layouts -> packed
+ * images for msau_conv2d) and gradient un-packing (slabs -> flat fp32 gradient in the reference's
+ * layouts).  One launch handles a whole table.  The table lives in DEVICE memory.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int64_t src_off;        /* element offset of the parameter in the flat fp32 parameter buffer         */
+    int64_t dst_off;        /* BYTE offset of the packed image in the pack arena                        */
+    int32_t kind;           /* 0 = weight image, 1 = bias vector (fp32, padded to rows_store)           */
+    int32_t dim0, dim1;     /* parameter dims 0 and 1 (OIHW: O,I ; ConvTranspose IOHW: I,O)             */
+    int32_t KH, KW;
+    int32_t row_is_dim0;    /* 1: image rows index dim0 (conv fwd, deconv dgrad); 0: rows index dim1   */
+    int32_t flip;           /* 1: taps reversed (data-gradient / transposed-conv forward)              */
+    int32_t row_off;        /* first parameter index (along the row dim) covered by this image          */
+    int32_t rows_real;      /* valid rows                                                               */
+    int32_t rows_pad;       /* geometry.rows                                                            */
+    int32_t k1_real, k1_store, k2_real, k2_store;   /* channel split of the K dim (source 1 | source 2)  */
+    int32_t cch, nchunks, kchunk;
+    int32_t dtype;
+} msau_pack_entry;
+
+int msau_pack_params(void* stream, const float* flat_params, void* pack_arena,
+                     const msau_pack_entry* table_dev, int n_entries, int max_elems_per_entry);
+
+typedef struct {
+    int64_t slab_off;       /* element offset of slab 0 in the fp32 slab arena                          */
+    int64_t w_off;          /* element offset of the weight gradient in the flat gradient buffer        */
+    int64_t b_off;          /* element offset of the bias gradient, or -1                               */
+    int64_t b_src_off;      /* bias partial sums: element (slab s, channel r) of the slab arena is      */
+    int64_t b_slab_stride;  /*   b_src_off + s*b_slab_stride + r*b_elem_stride, s < b_nslabs            */
+    int32_t b_elem_stride;  /*   (the "ones" column of a wgrad slab, or msau_channel_sum partials)      */
+    int32_t b_nslabs;
+    int32_t nslabs;
+    int32_t slab_elems;     /* nchunks * Cout_store * kext                                              */
+    int32_t kext;
+    int32_t dim0, dim1, KH, KW;
+    int32_t row_is_dim0;    /* 1: slab rows index dim0, slab channels index dim1 ; 0: the other way     */
+    int32_t rows_real;
+    int32_t k1_real, k1_store, k2_real, k2_store;
+    int32_t cch, nchunks;
+    int32_t accumulate;     /* 1: add to the existing gradient (second wgrad of the same parameter)     */
+} msau_unpack_entry;
+
+int msau_wgrad_reduce(void* stream, const float* slab_arena, float* flat_grads,
+                      const msau_unpack_entry* table_dev, int n_entries, int max_elems_per_entry);
+
+/* partial per-channel sums of a gradient tensor (bias gradient of the transposed conv, whose wgrad
+ * runs with swapped roles): partials[blk][c] = sum over the pixels block blk visited; nblk rows. */
+int msau_channel_sum(void* stream, int dtype, const void* g, int64_t npix, int Cs, float* partials, int nblk);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout conversion at the boundary: the reference API speaks NCHW fp32
+ * (train_chargrid_funsd_msau.py:50-53, model/model.py:435-437).
+ * ------------------------------------------------------------------------------------------ */
+int msau_nchw_to_nhwc(void* stream, int dtype, const float* src, void* dst, int B, int C, int Cs, int H, int W);
+int msau_nhwc_to_nchw(void* stream, int dtype, const void* src, float* dst, int B, int C, int Cs, int H, int W);
+/* gradient of nhwc_to_nchw: dst[b][h][w][c] (+)= src[b][c][h][w] ; padded channels written as 0 */
+int msau_nchw_grad_to_nhwc(void* stream, int dtype, const float* src, void* dst, int B, int C, int Cs, int H, int W,
+                           int accumulate);
+
+/* ------------------------------------------------------------------------------------------
+ * LocalResponseNorm(size = n) across channels, alpha=1e-4, beta=0.75, k=1
+ * (model/layers/layers.py:145,161-162 -> torch.nn.LocalResponseNorm).  C = real channels.
+ *   y_c = a_c * (k + alpha/n * sum_{c' in [c-n/2, c+(n-1)/2]} a_c'^2)^-beta
+ * ------------------------------------------------------------------------------------------ */
+int msau_lrn_fwd(void* stream, int dtype, const void* a, void* y, int64_t npix, int C, int Cs, int n,
+                 float alpha, float beta, float k);
+int msau_lrn_bwd(void* stream, int dtype, const void* a, const void* dy, void* da, int64_t npix, int C, int Cs,
+                 int n, float alpha, float beta, float k);
+
+/* ------------------------------------------------------------------------------------------
+ * 2x2 stride-2 max pool after zero SAME padding (model/model.py:158-160).  idx = argmax position
+ * (0..3, first maximum in row-major window order, as torch CPU) kept as one byte per output element.
+ * bwd: dx = (accumulate ? dx : 0) + scatter(dy); dx *= (mask > 0) if mask != NULL.
+ * ------------------------------------------------------------------------------------------ */
+int msau_maxpool2x2_fwd(void* stream, int dtype, const void* x, void* y, uint8_t* idx, int B, int H, int W, int Cs);
+int msau_maxpool2x2_bwd(void* stream, int dtype, const void* dy, const uint8_t* idx, void* dx, const void* mask,
+                        int B, int H, int W, int Cs, int accumulate);
+
+/* ------------------------------------------------------------------------------------------
+ * Bottleneck self-attention core (model/layers/attention.py:156-162), given the 1x1 projections
+ * f, g ([B][N][Ds]) and h ([B][N][Cs]):   y = x + h . softmax_rows(g^T f)
+ * Two passes, no N x N matrix: stats (row max m_i and row sum Z_i of exp), then the output.
+ * bwd: df, dg, dh from dy (the residual path dx += dy is the caller's).  ws: B*N*(Cs+4) floats.
+ * ------------------------------------------------------------------------------------------ */
+int msau_selfattn_fwd(void* stream, int dtype, const void* f, const void* g, const void* h, const void* x, void* y,
+                      float* stats /* [B][N][2] */, int B, int N, int Ds, int Cs);
+int msau_selfattn_bwd(void* stream, int dtype, const void* f, const void* g, const void* h, const void* dy,
+                      const float* stats, void* df, void* dg, void* dh, float* ws, int B, int N, int Ds, int Cs);
+
+/* ------------------------------------------------------------------------------------------
+ * Masked cross entropy (model/model.py:446-459) with the batch rule of SURVEY 8(e):
+ *   loss = scale * sum_b 1/max(cnt_b,1) * sum_{p: label!=0} -log softmax(logits_p)[label_p]
+ *   dlogits = scale/cnt_b * (softmax - onehot) at labelled pixels, 0 elsewhere (and in padded channels)
+ * counts: [B] int32 (written by msau_label_counts).  loss_accum: one float, += (deterministic:
+ * per-block partials then one ordered pass).  ws: >= msau_ce_ws_floats(npix) floats.
+ * ------------------------------------------------------------------------------------------ */
+int msau_label_counts(void* stream, const int64_t* labels, int32_t* counts, int B, int64_t hw);
+int64_t msau_ce_ws_floats(int64_t npix_total);
+int msau_masked_ce(void* stream, int dtype, const void* logits, const int64_t* labels, const int32_t* counts,
+                   void* dlogits, float* loss_accum, float* ws, int B, int64_t hw, int C, int Cs, float scale);
+
+/* ------------------------------------------------------------------------------------------
+ * Global-norm clip + Adam on flat fp32 buffers (train_chargrid_funsd_msau.py:24-26,58-59).
+ * state (device, 8 floats): [0]=step count, [1]=grad norm (after grad_scale), [2]=clip coef,
+ *                           [3]=1-b1^t, [4]=1-b2^t.   step is incremented by the call.
+ * grad_scale is applied to the gradient first (1/world after an all-reduce sum).
+ * ------------------------------------------------------------------------------------------ */
+int64_t msau_adam_ws_floats(int64_t n);
+int msau_clip_adam_step(void* stream, float* params, const float* grads, float* m, float* v, float* state,
+                        float* ws, int64_t n, float lr, float beta1, float beta2, float eps, float max_norm,
+                        float grad_scale);
+
+/* misc */
+int msau_fill_zero(void* stream, void* p, int64_t bytes);
+int msau_softmax_channels_nchw(void* stream, const float* logits, float* pred, int B, int C, int64_t hw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSAU_HIP_H */

@@ -1,0 +1,118 @@
+"""ctypes binding of libmsau_hip.so (C ABI declared in include/msau_hip.h).
+
+There is no CPU fallback: if the library is missing or a symbol is absent this module raises, and
+every op that would have used it fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmsau_hip.so")
+
+F32, BF16 = 0, 1
+
+CONV_RELU_IN, CONV_RELU_OUT, CONV_ADD, CONV_ACCUM, CONV_MASK_A, CONV_MASK_B = 1, 2, 4, 8, 16, 32
+
+i32, i64, vp, f32 = C.c_int32, C.c_int64, C.c_void_p, C.c_float
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, i32) for n in ("B", "Hin", "Win", "Hout", "Wout", "C1", "C2", "Cout", "KH", "KW", "dil",
+                                   "pad_t", "pad_l", "stride", "ups", "flags")] + \
+               [(n, vp) for n in ("x1", "x2", "wpack", "bias", "add", "mask_a", "mask_b", "y")]
+
+
+class ConvPackGeom(C.Structure):
+    _fields_ = [("cch", i32), ("nchunks", i32), ("kchunk", i32), ("rows", i32), ("bytes", i64)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [(n, i32) for n in ("B", "Hin", "Win", "Hout", "Wout", "C1", "C2", "Cout", "KH", "KW", "dil",
+                                   "pad_t", "pad_l", "stride", "flags")] + \
+               [(n, vp) for n in ("x1", "x2", "g", "slabs")] + [("nslabs", i32)]
+
+
+class WgradGeom(C.Structure):
+    _fields_ = [("cch", i32), ("nchunks", i32), ("kext", i32), ("max_slabs", i32), ("slab_bytes", i64)]
+
+
+class PackEntry(C.Structure):
+    _fields_ = [("src_off", i64), ("dst_off", i64)] + \
+               [(n, i32) for n in ("kind", "dim0", "dim1", "KH", "KW", "row_is_dim0", "flip", "row_off", "rows_real",
+                                   "rows_pad", "k1_real", "k1_store", "k2_real", "k2_store", "cch", "nchunks",
+                                   "kchunk", "dtype")]
+
+
+class UnpackEntry(C.Structure):
+    _fields_ = [("slab_off", i64), ("w_off", i64), ("b_off", i64), ("b_src_off", i64), ("b_slab_stride", i64)] + \
+               [(n, i32) for n in ("b_elem_stride", "b_nslabs", "nslabs", "slab_elems", "kext", "dim0", "dim1", "KH",
+                                   "KW", "row_is_dim0", "rows_real", "k1_real", "k1_store", "k2_real", "k2_store",
+                                   "cch", "nchunks", "accumulate")]
+
+
+_SIGNATURES = {
+    "msau_last_error": (C.c_char_p, []),
+    "msau_version": (C.c_int, []),
+    "msau_conv_pack_geometry": (C.c_int, [C.c_int] * 9 + [C.POINTER(ConvPackGeom)]),
+    "msau_conv2d": (C.c_int, [vp, C.c_int, C.POINTER(ConvDesc)]),
+    "msau_wgrad_geometry": (C.c_int, [C.c_int, C.POINTER(WgradDesc), C.POINTER(WgradGeom)]),
+    "msau_conv2d_wgrad": (C.c_int, [vp, C.c_int, C.POINTER(WgradDesc)]),
+    "msau_pack_params": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int]),
+    "msau_wgrad_reduce": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int]),
+    "msau_channel_sum": (C.c_int, [vp, C.c_int, vp, i64, C.c_int, vp, C.c_int]),
+    "msau_nchw_to_nhwc": (C.c_int, [vp, C.c_int, vp, vp] + [C.c_int] * 5),
+    "msau_nhwc_to_nchw": (C.c_int, [vp, C.c_int, vp, vp] + [C.c_int] * 5),
+    "msau_nchw_grad_to_nhwc": (C.c_int, [vp, C.c_int, vp, vp] + [C.c_int] * 6),
+    "msau_lrn_fwd": (C.c_int, [vp, C.c_int, vp, vp, i64, C.c_int, C.c_int, C.c_int, f32, f32, f32]),
+    "msau_lrn_bwd": (C.c_int, [vp, C.c_int, vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, f32, f32, f32]),
+    "msau_maxpool2x2_fwd": (C.c_int, [vp, C.c_int, vp, vp, vp] + [C.c_int] * 4),
+    "msau_maxpool2x2_bwd": (C.c_int, [vp, C.c_int, vp, vp, vp, vp] + [C.c_int] * 5),
+    "msau_selfattn_fwd": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp] + [C.c_int] * 4),
+    "msau_selfattn_bwd": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 4),
+    "msau_label_counts": (C.c_int, [vp, vp, vp, C.c_int, i64]),
+    "msau_ce_ws_floats": (i64, [i64]),
+    "msau_masked_ce": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, C.c_int, f32]),
+    "msau_adam_ws_floats": (i64, [i64]),
+    "msau_clip_adam_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32]),
+    "msau_fill_zero": (C.c_int, [vp, vp, i64]),
+    "msau_softmax_channels_nchw": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, i64]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class MsauHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the library (once).  Raises if it is missing -- build it with `python -m msau_amd.build`."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MsauHipError(f"{LIB_PATH} not found: the MSAU HIP kernels are not built "
+                           f"(run `python -m msau_amd.build`); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError if the ABI and this table disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().msau_last_error().decode("utf-8", "replace")
+        raise MsauHipError(f"{what or 'msau call'} failed (status {rc}): {msg}")
+
+
+def call(name: str, *args):
+    """Call an int-status entry point and raise on failure."""
+    check(getattr(load(), name)(*args), name)

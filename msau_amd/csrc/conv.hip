@@ -1,0 +1,309 @@
+// Implicit-GEMM convolution for gfx950: NHWC activations, a (4*PT) x 16 output-pixel tile per
+// 256-thread workgroup, the input halo tile and the weight chunk staged once in LDS, MFMA
+// 16x16x32 (bf16) / 16x16x4 (fp32) with output channels on the MFMA rows and pixels on the
+// columns, so every lane ends up with 4 consecutive output channels of one pixel and the
+// epilogue (bias, masks, residual, accumulate, ReLU) is vector loads/stores along C.
+//
+// Replaces torch.nn.Conv2d + utils.pad_2d (model/layers/layers.py:82-102,152-164), the concat
+// feeding it (model/model.py:147,242,251), ConvTranspose2d (layers.py:249-250) and their data
+// gradients.  See include/msau_hip.h for the exact arithmetic.
+#include "msau_common.h"
+
+namespace {
+
+struct ConvGeom {
+    int esz, taps, cch, nchunks, kchunk, rows, CT, ngroups;   // ngroups = kchunk / 8
+};
+
+__host__ __device__ inline int pix_stride_bytes(int cch, int esz) {
+    int ps = cch * esz;
+    if (((ps >> 4) & 1) == 0) ps += 16;      // odd number of 16-B slots per pixel: conflict-free b128 reads
+    return ps;
+}
+
+struct TileGeom { int TH, TIH, TIW, PS, WS, in_bytes, w_bytes, tab_bytes, total; };
+
+inline TileGeom tile_geom(const ConvGeom& g, int PT, int KH, int KW, int dil, int stride) {
+    TileGeom t;
+    t.TH = 4 * PT;
+    t.TIH = (t.TH - 1) * stride + (KH - 1) * dil + 1;
+    t.TIW = 15 * stride + (KW - 1) * dil + 1;
+    t.PS = pix_stride_bytes(g.cch, g.esz);
+    t.WS = g.kchunk * g.esz + 16;
+    t.in_bytes = roundup(t.TIH * t.TIW * t.PS, 16);
+    t.w_bytes = roundup(g.rows * t.WS, 16);
+    t.tab_bytes = roundup(g.ngroups * 4, 16);
+    t.total = t.in_bytes + t.w_bytes + t.tab_bytes;
+    return t;
+}
+
+int conv_geom(int dtype, int C1, int C2, int Cout, int KH, int KW, int dil, int stride, int ups, ConvGeom* out) {
+    const int Cin = C1 + C2;
+    MSAU_CHECK_ARG(dtype == MSAU_F32 || dtype == MSAU_BF16, "conv: bad dtype %d", dtype);
+    MSAU_CHECK_ARG(C1 > 0 && C1 % 8 == 0 && C2 >= 0 && C2 % 8 == 0, "conv: bad source channels (%d,%d)", C1, C2);
+    MSAU_CHECK_ARG(Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 8 == 0, "conv: channels must be multiples of 8 (%d,%d)", Cin, Cout);
+    MSAU_CHECK_ARG(KH >= 1 && KW >= 1 && KH <= 7 && KW <= 7 && dil >= 1, "conv: bad kernel %dx%d dil %d", KH, KW, dil);
+    MSAU_CHECK_ARG((stride == 1 || stride == 2) && (ups == 1 || ups == 2) && !(stride == 2 && ups == 2), "conv: bad stride/ups");
+    MSAU_CHECK_ARG(Cout <= 128, "conv: Cout %d > 128 unsupported", Cout);
+    ConvGeom g;
+    g.esz = dtype == MSAU_F32 ? 4 : 2;
+    g.taps = KH * KW;
+    int ct = cdiv(Cout, 16);
+    g.CT = ct <= 1 ? 1 : ct <= 2 ? 2 : ct <= 4 ? 4 : 8;
+    g.rows = g.CT * 16;
+    int best = 0;
+    for (int pass = 0; pass < 2 && !best; ++pass) {
+        for (int c = (Cin < 128 ? Cin : 128); c >= 8; c -= 8) {
+            if (Cin % c) continue;
+            if (C2 && C1 % c) continue;                      // a chunk never straddles the two sources
+            g.cch = c;
+            g.kchunk = roundup(g.taps * c, 32);
+            g.ngroups = g.kchunk / 8;
+            TileGeom t = tile_geom(g, pass == 0 ? 4 : 1, KH, KW, dil, stride);
+            if (t.total <= (pass == 0 ? 72 * 1024 : 150 * 1024)) { best = c; break; }
+        }
+    }
+    if (!best) return msau_set_error(MSAU_ERR_LDS, "conv: no channel chunk fits LDS (Cin %d Cout %d k %dx%d dil %d)", Cin, Cout, KH, KW, dil);
+    g.cch = best;
+    g.nchunks = Cin / best;
+    g.kchunk = roundup(g.taps * best, 32);
+    g.ngroups = g.kchunk / 8;
+    *out = g;
+    return 0;
+}
+
+struct ConvArgs {
+    msau_conv_desc d;
+    int cch, nchunks, kchunk, ngroups;
+    int TIH, TIW, PS, WS;
+    int in_bytes, w_bytes;
+    int tiles_x, tiles_y;
+};
+
+template <typename T, int CT, int PT>
+__global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
+    typedef typename Vec8<T>::type V8;
+    typedef typename Vec4<T>::type V4;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* lds_in = smem;
+    unsigned char* lds_w = smem + a.in_bytes;
+    int* koff_tab = reinterpret_cast<int*>(smem + a.in_bytes + a.w_bytes);
+
+    const msau_conv_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    constexpr int TH = 4 * PT;
+
+    int bid = blockIdx.x;
+    const int txi = bid % a.tiles_x; bid /= a.tiles_x;
+    const int tyi = bid % a.tiles_y; bid /= a.tiles_y;
+    const int b = bid;
+    const int oy0 = tyi * TH, ox0 = txi * 16;
+    const int vy0 = oy0 * d.stride - d.pad_t, vx0 = ox0 * d.stride - d.pad_l;
+    const int cg_per_chunk = a.cch >> 3;
+    const int taps = d.KH * d.KW;
+
+    // k-group -> byte offset (relative to the lane's pixel) of its 8 channels in the LDS input tile
+    for (int G = tid; G < a.ngroups; G += 256) {
+        int off = 0;
+        if (G < taps * cg_per_chunk) {
+            int tap = G / cg_per_chunk, cg = G - tap * cg_per_chunk;
+            int ky = tap / d.KW, kx = tap - ky * d.KW;
+            off = ((ky * d.dil) * a.TIW + kx * d.dil) * a.PS + cg * 8 * (int)sizeof(T);
+        }
+        koff_tab[G] = off;
+    }
+
+    int pixoff[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        int ty = wave * PT + pt;
+        pixoff[pt] = ((ty * d.stride) * a.TIW + lr * d.stride) * a.PS;
+    }
+
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const T* x1 = static_cast<const T*>(d.x1);
+    const T* x2 = static_cast<const T*>(d.x2);
+    const T* wp = static_cast<const T*>(d.wpack);
+    const bool relu_in = d.flags & MSAU_CONV_RELU_IN;
+    const int npix_in = a.TIH * a.TIW;
+    const int rows = CT * 16;
+    const int wg_per_row = a.kchunk >> 3;
+    const int nks = a.kchunk >> 5;
+
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        if (chunk) __syncthreads();
+        // ---- stage the input halo tile for this channel chunk (zero padding / zero stuffing here)
+        for (int idx = tid; idx < npix_in * cg_per_chunk; idx += 256) {
+            int pix = idx / cg_per_chunk, cg = idx - pix * cg_per_chunk;
+            int iy = pix / a.TIW, ix = pix - iy * a.TIW;
+            int vy = vy0 + iy, vx = vx0 + ix;
+            bool ok = vy >= 0 && vx >= 0;
+            int ry = vy, rx = vx;
+            if (d.ups == 2) { ok = ok && !((vy | vx) & 1); ry = vy >> 1; rx = vx >> 1; }
+            ok = ok && ry < d.Hin && rx < d.Win;
+            V8 v = zero8<T>();
+            if (ok) {
+                int cs = chunk * a.cch + cg * 8;
+                size_t p = ((size_t)b * d.Hin + ry) * d.Win + rx;
+                const T* src = cs < d.C1 ? x1 + p * d.C1 + cs : x2 + p * d.C2 + (cs - d.C1);
+                v = load8<T>(src);
+                if (relu_in) v = relu8<T>(v);
+            }
+            *reinterpret_cast<V8*>(lds_in + pix * a.PS + cg * 8 * (int)sizeof(T)) = v;
+        }
+        // ---- stage this chunk's packed weights: global [chunk][row][kchunk] -> LDS rows of WS bytes
+        const T* wsrc = wp + (size_t)chunk * rows * a.kchunk;
+        for (int idx = tid; idx < rows * wg_per_row; idx += 256) {
+            int r = idx / wg_per_row, g8 = idx - r * wg_per_row;
+            *reinterpret_cast<V8*>(lds_w + r * a.WS + g8 * 8 * (int)sizeof(T)) = load8<T>(wsrc + (size_t)r * a.kchunk + g8 * 8);
+        }
+        __syncthreads();
+        // ---- MFMA over this chunk's K
+        for (int ks = 0; ks < nks; ++ks) {
+            const int G = ks * 4 + lg;
+            const int koff = koff_tab[G];
+            V8 bfrag[PT];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) bfrag[pt] = *reinterpret_cast<const V8*>(lds_in + pixoff[pt] + koff);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                V8 afrag = *reinterpret_cast<const V8*>(lds_w + (ct * 16 + lr) * a.WS + G * 8 * (int)sizeof(T));
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = mma8(afrag, bfrag[pt], acc[ct][pt]);
+            }
+        }
+    }
+
+    // ---- epilogue: lane (pixel lr of row ty, q = lg) owns channels q*CT*4 + ct*4 + {0..3}
+    const int Cout = d.Cout;
+    T* y = static_cast<T*>(d.y);
+    const T* add = static_cast<const T*>(d.add);
+    const T* mask_a = static_cast<const T*>(d.mask_a);
+    const T* mask_b = static_cast<const T*>(d.mask_b);
+    const int flags = d.flags;
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int oy = oy0 + wave * PT + pt, ox = ox0 + lr;
+        if (oy >= d.Hout || ox >= d.Wout) continue;
+        const size_t pbase = (((size_t)b * d.Hout + oy) * d.Wout + ox) * Cout;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int co = lg * (CT * 4) + ct * 4;
+            if (co >= Cout) continue;
+            f32x4 v = acc[ct][pt];
+            if (d.bias) {
+                f32x4 bv = *reinterpret_cast<const f32x4*>(d.bias + co);
+                v += bv;
+            }
+            if (flags & MSAU_CONV_MASK_A) {
+                V4 m = load4<T>(mask_a + pbase + co);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : 0.f;
+            }
+            if (flags & MSAU_CONV_ADD) {
+                V4 r = load4<T>(add + pbase + co);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+            }
+            if (flags & MSAU_CONV_ACCUM) {
+                V4 r = load4<T>(y + pbase + co);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+            }
+            if (flags & MSAU_CONV_RELU_OUT) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            if (flags & MSAU_CONV_MASK_B) {
+                V4 m = load4<T>(mask_b + pbase + co);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : 0.f;
+            }
+            V4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
+            store4<T>(y + pbase + co, o);
+        }
+    }
+}
+
+template <typename T, int CT, int PT>
+int launch_conv(hipStream_t s, const ConvArgs& a, int nblocks, int lds) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, CT, PT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
+        if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_kernel<T, CT, PT>), dim3(nblocks), dim3(256), lds, s, a);
+    MSAU_CHECK_LAUNCH("conv_kernel");
+    return 0;
+}
+
+template <typename T, int CT>
+int launch_conv_pt(hipStream_t s, const ConvArgs& a, int PT, int nblocks, int lds) {
+    switch (PT) {
+        case 4: return launch_conv<T, CT, 4>(s, a, nblocks, lds);
+        case 2: return launch_conv<T, CT, 2>(s, a, nblocks, lds);
+        default: return launch_conv<T, CT, 1>(s, a, nblocks, lds);
+    }
+}
+
+template <typename T>
+int launch_conv_ct(hipStream_t s, const ConvArgs& a, int CT, int PT, int nblocks, int lds) {
+    switch (CT) {
+        case 1: return launch_conv_pt<T, 1>(s, a, PT, nblocks, lds);
+        case 2: return launch_conv_pt<T, 2>(s, a, PT, nblocks, lds);
+        case 4: return launch_conv_pt<T, 4>(s, a, PT, nblocks, lds);
+        default: return launch_conv_pt<T, 8>(s, a, PT, nblocks, lds);
+    }
+}
+
+}  // namespace
+
+extern "C" int msau_conv_pack_geometry(int dtype, int C1, int C2, int Cout, int KH, int KW, int dil, int stride, int ups,
+                                       msau_conv_pack_geom* out) {
+    ConvGeom g;
+    int rc = conv_geom(dtype, C1, C2, Cout, KH, KW, dil, stride, ups, &g);
+    if (rc) return rc;
+    out->cch = g.cch; out->nchunks = g.nchunks; out->kchunk = g.kchunk; out->rows = g.rows;
+    out->bytes = (int64_t)g.nchunks * g.rows * g.kchunk * g.esz;
+    return 0;
+}
+
+extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
+    MSAU_CHECK_ARG(d && d->x1 && d->wpack && d->y, "conv2d: null pointer");
+    MSAU_CHECK_ARG(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->Hout > 0 && d->Wout > 0, "conv2d: bad dims");
+    MSAU_CHECK_ARG(d->C1 % 8 == 0 && d->C2 % 8 == 0 && (d->C2 == 0 || d->x2), "conv2d: bad sources");
+    MSAU_CHECK_ARG(!(d->flags & MSAU_CONV_ADD) || d->add, "conv2d: ADD without pointer");
+    MSAU_CHECK_ARG(!(d->flags & MSAU_CONV_MASK_A) || d->mask_a, "conv2d: MASK_A without pointer");
+    MSAU_CHECK_ARG(!(d->flags & MSAU_CONV_MASK_B) || d->mask_b, "conv2d: MASK_B without pointer");
+    ConvGeom g;
+    int rc = conv_geom(dtype, d->C1, d->C2, d->Cout, d->KH, d->KW, d->dil, d->stride, d->ups, &g);
+    if (rc) return rc;
+    // sanity of the caller's output size against the conv arithmetic (every output pixel's taps are
+    // bounds-checked in the kernel, so this only guards against nonsense)
+    int PT = 4;
+    auto ntiles = [&](int pt) { return (int64_t)d->B * cdiv(d->Hout, 4 * pt) * cdiv(d->Wout, 16); };
+    if (ntiles(4) < 512) PT = ntiles(2) >= 384 ? 2 : 1;
+    TileGeom t = tile_geom(g, PT, d->KH, d->KW, d->dil, d->stride);
+    while (t.total > 150 * 1024 && PT > 1) { PT >>= 1; t = tile_geom(g, PT, d->KH, d->KW, d->dil, d->stride); }
+    if (t.total > 150 * 1024) return msau_set_error(MSAU_ERR_LDS, "conv2d: tile needs %d B of LDS", t.total);
+    ConvArgs a;
+    a.d = *d;
+    a.cch = g.cch; a.nchunks = g.nchunks; a.kchunk = g.kchunk; a.ngroups = g.ngroups;
+    a.TIH = t.TIH; a.TIW = t.TIW; a.PS = t.PS; a.WS = t.WS; a.in_bytes = t.in_bytes; a.w_bytes = t.w_bytes;
+    a.tiles_x = cdiv(d->Wout, 16); a.tiles_y = cdiv(d->Hout, 4 * PT);
+    int64_t nb = ntiles(PT);
+    MSAU_CHECK_ARG(nb < (1ll << 31), "conv2d: grid too large");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == MSAU_F32) return launch_conv_ct<float>(s, a, g.CT, PT, (int)nb, t.total);
+    return launch_conv_ct<bf16_t>(s, a, g.CT, PT, (int)nb, t.total);
+}

@@ -1,0 +1,318 @@
+// Weight / bias gradient of the implicit-GEMM convolution for gfx950.
+//
+//   dW[co][k] = sum_pix g[pix][co] * xin[pix (+) tap(k)][c(k)]        k = [tap][channel-in-chunk]
+//   db[co]    = sum_pix g[pix][co]                                     (the extra "ones" column)
+//
+// GEMM with the PIXELS on the MFMA reduction dimension: rows = output channels, columns = k.
+// Both operands are stored pixel-major (NHWC) in LDS, i.e. transposed w.r.t. what the MFMA wants;
+// bf16 uses ds_read_b64_tr_b16 (hardware transpose read, per-lane addresses make the tap shift a
+// plain address offset), fp32 uses ds_read_b32 (one element per lane per 16x16x4 MFMA).
+// A workgroup walks a strided list of 16x16 pixel tiles with its accumulators in registers and
+// writes ONE slab at the end: no atomics, results are bitwise reproducible for a fixed nslabs.
+//
+// Replaces autograd's conv2d weight/bias gradient reached from train_chargrid_funsd_msau.py:57.
+#include "msau_common.h"
+
+namespace {
+
+struct WGeom {
+    int esz, taps, cch, nchunks, kreal, kextc, NKT, NKW, CTN;
+    int TIH, TIW, PSx, PSg, x_bytes, g_bytes, tab_bytes, total;
+};
+
+inline int pix_stride(int c, int esz) {
+    int ps = c * esz;
+    if (((ps >> 4) & 1) == 0) ps += 16;
+    return ps;
+}
+
+int wgrad_geom(int dtype, const msau_wgrad_desc* d, WGeom* out) {
+    MSAU_CHECK_ARG(dtype == MSAU_F32 || dtype == MSAU_BF16, "wgrad: bad dtype");
+    const int Cin = d->C1 + d->C2;
+    MSAU_CHECK_ARG(Cin > 0 && Cin % 8 == 0 && d->Cout > 0 && d->Cout % 8 == 0 && d->Cout <= 128, "wgrad: bad channels");
+    MSAU_CHECK_ARG(d->KH >= 1 && d->KW >= 1 && d->KH <= 7 && d->KW <= 7 && d->dil >= 1 && (d->stride == 1 || d->stride == 2), "wgrad: bad kernel");
+    WGeom g;
+    g.esz = dtype == MSAU_F32 ? 4 : 2;
+    g.taps = d->KH * d->KW;
+    g.CTN = cdiv(d->Cout, 16);
+    g.TIH = 15 * d->stride + (d->KH - 1) * d->dil + 1;
+    g.TIW = 15 * d->stride + (d->KW - 1) * d->dil + 1;
+    g.PSg = pix_stride(d->Cout, g.esz);
+    g.g_bytes = roundup(256 * g.PSg, 16);
+    int best = 0;
+    for (int c = (Cin < 64 ? Cin : 64); c >= 8; c -= 8) {
+        if (Cin % c) continue;
+        if (d->C2 && d->C1 % c) continue;                    // a chunk never straddles the two sources
+        int kext = roundup(g.taps * c + 8, 16);
+        int nkw = cdiv(kext / 16, 4);
+        if (nkw * g.CTN > 40 || nkw > 10) continue;           // accumulator registers per wave
+        int xb = roundup(g.TIH * g.TIW * pix_stride(c, g.esz), 16);
+        if (xb + g.g_bytes + (kext / 4) * 4 + 64 > 150 * 1024) continue;
+        best = c; break;
+    }
+    if (!best) return msau_set_error(MSAU_ERR_LDS, "wgrad: no chunk fits (Cin %d Cout %d k %dx%d dil %d)", Cin, d->Cout, d->KH, d->KW, d->dil);
+    g.cch = best;
+    g.nchunks = Cin / best;
+    g.kreal = g.taps * best;
+    g.kextc = roundup(g.kreal + 8, 16);
+    g.NKT = g.kextc / 16;
+    int nkw = cdiv(g.NKT, 4);
+    g.NKW = nkw <= 1 ? 1 : nkw <= 2 ? 2 : nkw <= 3 ? 3 : nkw <= 5 ? 5 : 10;
+    g.PSx = pix_stride(best, g.esz);
+    g.x_bytes = roundup(g.TIH * g.TIW * g.PSx, 16);
+    g.tab_bytes = roundup((g.kextc / 4) * 4, 16);
+    g.total = g.x_bytes + g.g_bytes + g.tab_bytes + 64;
+    *out = g;
+    return 0;
+}
+
+struct WArgs {
+    msau_wgrad_desc d;
+    int cch, nchunks, kreal, kextc, NKT;
+    int TIH, TIW, PSx, PSg, x_bytes, g_bytes, tab_bytes;
+    int tiles_x, tiles_y, ntiles;
+};
+
+#define TAB_ABS 0x40000000
+
+template <typename T, int CTN, int NKW>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
+    typedef typename Vec8<T>::type V8;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* lds_x = smem;
+    unsigned char* lds_g = smem + a.x_bytes;
+    int* tab = reinterpret_cast<int*>(smem + a.x_bytes + a.g_bytes);          // per 4-column group
+    unsigned char* lds_ones = smem + a.x_bytes + a.g_bytes + a.tab_bytes;     // {1,0,0,0,0,0,0,0}
+    const int ones_off = a.x_bytes + a.g_bytes + a.tab_bytes - 0;             // relative to lds_x base (= smem)
+
+    const msau_wgrad_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int chunk = blockIdx.y;
+    const int cg_per_chunk = a.cch >> 3;
+
+    // column-group table: byte offset (relative to the pixel's slot in lds_x) of 4 consecutive k
+    for (int c4 = tid; c4 < a.kextc / 4; c4 += 256) {
+        int k = c4 * 4, off;
+        if (k < a.kreal) {
+            int tap = k / a.cch, c = k - tap * a.cch;
+            int ky = tap / d.KW, kx = tap - ky * d.KW;
+            off = ((ky * d.dil) * a.TIW + kx * d.dil) * a.PSx + c * (int)sizeof(T);
+        } else if (k == a.kreal) {
+            off = TAB_ABS | ones_off;                                         // column kreal = ones (bias)
+        } else {
+            off = TAB_ABS | (ones_off + 4 * (int)sizeof(T));                  // padding columns: zeros
+        }
+        tab[c4] = off;
+    }
+    if (tid < 8) reinterpret_cast<T*>(lds_ones)[tid] = (T)(tid == 0 ? 1.0f : 0.0f);
+
+    f32x4 acc[NKW][CTN];
+#pragma unroll
+    for (int i = 0; i < NKW; ++i)
+#pragma unroll
+        for (int ct = 0; ct < CTN; ++ct) acc[i][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const T* x1 = static_cast<const T*>(d.x1);
+    const T* x2 = static_cast<const T*>(d.x2);
+    const T* gp = static_cast<const T*>(d.g);
+    const bool relu_in = d.flags & MSAU_CONV_RELU_IN;
+    const int npix_in = a.TIH * a.TIW;
+    const int cog = d.Cout >> 3;
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int txi = t % a.tiles_x; t /= a.tiles_x;
+        const int tyi = t % a.tiles_y; t /= a.tiles_y;
+        const int b = t;
+        const int oy0 = tyi * 16, ox0 = txi * 16;
+        const int vy0 = oy0 * d.stride - d.pad_t, vx0 = ox0 * d.stride - d.pad_l;
+        __syncthreads();                       // previous tile's reads done (also orders the table writes)
+        for (int idx = tid; idx < npix_in * cg_per_chunk; idx += 256) {
+            int pix = idx / cg_per_chunk, cg = idx - pix * cg_per_chunk;
+            int iy = pix / a.TIW, ix = pix - iy * a.TIW;
+            int ry = vy0 + iy, rx = vx0 + ix;
+            V8 v = zero8<T>();
+            if (ry >= 0 && rx >= 0 && ry < d.Hin && rx < d.Win) {
+                int cs = chunk * a.cch + cg * 8;
+                size_t p = ((size_t)b * d.Hin + ry) * d.Win + rx;
+                const T* src = cs < d.C1 ? x1 + p * d.C1 + cs : x2 + p * d.C2 + (cs - d.C1);
+                v = load8<T>(src);
+                if (relu_in) v = relu8<T>(v);
+            }
+            *reinterpret_cast<V8*>(lds_x + pix * a.PSx + cg * 8 * (int)sizeof(T)) = v;
+        }
+        for (int idx = tid; idx < 256 * cog; idx += 256) {
+            int m = idx / cog, cg = idx - m * cog;
+            int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
+            V8 v = zero8<T>();                                   // pixels outside the image contribute 0
+            if (oy < d.Hout && ox < d.Wout)
+                v = load8<T>(gp + (((size_t)b * d.Hout + oy) * d.Wout + ox) * d.Cout + cg * 8);
+            *reinterpret_cast<V8*>(lds_g + m * a.PSg + cg * 8 * (int)sizeof(T)) = v;
+        }
+        __syncthreads();
+
+        if constexpr (sizeof(T) == 2) {
+            // ---- bf16: 8 blocks of 32 pixels; lane (column li, pixel group lg) needs pixels 8*lg..8*lg+7.
+            // tr-read: lane 16*lg + 4*q + p supplies the address of row (pixel) q, columns 4p..4p+3 and
+            // receives column li of the 4 rows.  EXEC stays all-ones through this section.
+            typedef __attribute__((address_space(3))) bf16x4* lds_v4;
+            const int q = li >> 2, p = li & 3;
+            for (int blk = 0; blk < 8; ++blk) {
+                const int m0 = blk * 32 + lg * 8 + q;             // first-read pixel of this lane's address
+                const int m1 = m0 + 4;
+                bf16x8 afrag[CTN];
+#pragma unroll
+                for (int ct = 0; ct < CTN; ++ct) {
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(lds_g + m0 * a.PSg + (ct * 16 + 4 * p) * 2));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(lds_g + m1 * a.PSg + (ct * 16 + 4 * p) * 2));
+                    afrag[ct] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                const int pb0 = (((m0 >> 4) * d.stride) * a.TIW + (m0 & 15) * d.stride) * a.PSx;
+                const int pb1 = (((m1 >> 4) * d.stride) * a.TIW + (m1 & 15) * d.stride) * a.PSx;
+#pragma unroll
+                for (int i = 0; i < NKW; ++i) {
+                    const int nkt = wave + 4 * i;
+                    if (nkt < a.NKT) {                                // wave-uniform
+                        const int e = tab[nkt * 4 + p];
+                        const int o0 = (e & TAB_ABS) ? (e & ~TAB_ABS) : pb0 + e;
+                        const int o1 = (e & TAB_ABS) ? (e & ~TAB_ABS) : pb1 + e;
+                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o0));
+                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o1));
+                        bf16x8 bfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                        for (int ct = 0; ct < CTN; ++ct)
+                            acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[ct], bfrag, acc[i][ct], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            // ---- fp32: 64 steps of 4 pixels; lane (li, lg) supplies pixel 4*step + lg
+            int colofs[NKW];
+#pragma unroll
+            for (int i = 0; i < NKW; ++i) {
+                const int nkt = wave + 4 * i;
+                int e = 0;
+                if (nkt < a.NKT) {
+                    e = tab[nkt * 4 + (li >> 2)];
+                    e += (li & 3) * 4;
+                }
+                colofs[i] = e;
+            }
+            for (int step = 0; step < 64; ++step) {
+                const int m = step * 4 + lg;
+                float afrag[CTN];
+#pragma unroll
+                for (int ct = 0; ct < CTN; ++ct)
+                    afrag[ct] = *reinterpret_cast<const float*>(lds_g + m * a.PSg + (ct * 16 + li) * 4);
+                const int pb = (((m >> 4) * d.stride) * a.TIW + (m & 15) * d.stride) * a.PSx;
+#pragma unroll
+                for (int i = 0; i < NKW; ++i) {
+                    const int nkt = wave + 4 * i;
+                    if (nkt < a.NKT) {
+                        const int e = colofs[i];
+                        const int o = (e & TAB_ABS) ? (e & ~TAB_ABS) : pb + e;
+                        const float bv = *reinterpret_cast<const float*>(smem + o);
+#pragma unroll
+                        for (int ct = 0; ct < CTN; ++ct)
+                            acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ct], bv, acc[i][ct], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- write this workgroup's slab: slabs[blockIdx.x][chunk][co][k]
+    float* slab = d.slabs + ((size_t)blockIdx.x * a.nchunks + chunk) * d.Cout * a.kextc;
+#pragma unroll
+    for (int i = 0; i < NKW; ++i) {
+        const int nkt = wave + 4 * i;
+        if (nkt >= a.NKT) continue;
+#pragma unroll
+        for (int ct = 0; ct < CTN; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = ct * 16 + lg * 4 + j;
+                if (co < d.Cout) slab[(size_t)co * a.kextc + nkt * 16 + li] = acc[i][ct][j];
+            }
+    }
+}
+
+template <typename T, int CTN, int NKW>
+int launch_wgrad(hipStream_t s, const WArgs& a, dim3 grid, int lds) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, CTN, NKW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
+        if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_kernel<T, CTN, NKW>), grid, dim3(256), lds, s, a);
+    MSAU_CHECK_LAUNCH("wgrad_kernel");
+    return 0;
+}
+
+template <typename T, int CTN>
+int launch_wgrad_nkw(hipStream_t s, const WArgs& a, int NKW, dim3 grid, int lds) {
+    if constexpr (CTN == 8) {
+        switch (NKW) {
+            case 1: return launch_wgrad<T, CTN, 1>(s, a, grid, lds);
+            case 2: return launch_wgrad<T, CTN, 2>(s, a, grid, lds);
+            case 3: return launch_wgrad<T, CTN, 3>(s, a, grid, lds);
+            default: return launch_wgrad<T, CTN, 5>(s, a, grid, lds);
+        }
+    } else {
+        switch (NKW) {
+            case 1: return launch_wgrad<T, CTN, 1>(s, a, grid, lds);
+            case 2: return launch_wgrad<T, CTN, 2>(s, a, grid, lds);
+            case 3: return launch_wgrad<T, CTN, 3>(s, a, grid, lds);
+            case 5: return launch_wgrad<T, CTN, 5>(s, a, grid, lds);
+            default: return launch_wgrad<T, CTN, 10>(s, a, grid, lds);
+        }
+    }
+}
+
+template <typename T>
+int launch_wgrad_ct(hipStream_t s, const WArgs& a, int CTN, int NKW, dim3 grid, int lds) {
+    switch (CTN) {
+        case 1: return launch_wgrad_nkw<T, 1>(s, a, NKW, grid, lds);
+        case 2: return launch_wgrad_nkw<T, 2>(s, a, NKW, grid, lds);
+        case 3: case 4: return launch_wgrad_nkw<T, 4>(s, a, NKW, grid, lds);
+        default: return launch_wgrad_nkw<T, 8>(s, a, NKW, grid, lds);
+    }
+}
+
+}  // namespace
+
+extern "C" int msau_wgrad_geometry(int dtype, const msau_wgrad_desc* d, msau_wgrad_geom* out) {
+    WGeom g;
+    int rc = wgrad_geom(dtype, d, &g);
+    if (rc) return rc;
+    out->cch = g.cch; out->nchunks = g.nchunks; out->kext = g.kextc;
+    out->max_slabs = d->B * cdiv(d->Hout, 16) * cdiv(d->Wout, 16);
+    out->slab_bytes = (int64_t)g.nchunks * d->Cout * g.kextc * 4;
+    return 0;
+}
+
+extern "C" int msau_conv2d_wgrad(void* stream, int dtype, const msau_wgrad_desc* d) {
+    MSAU_CHECK_ARG(d && d->x1 && d->g && d->slabs, "wgrad: null pointer");
+    MSAU_CHECK_ARG(d->C2 == 0 || d->x2, "wgrad: x2 missing");
+    WGeom g;
+    int rc = wgrad_geom(dtype, d, &g);
+    if (rc) return rc;
+    WArgs a;
+    a.d = *d;
+    a.cch = g.cch; a.nchunks = g.nchunks; a.kreal = g.kreal; a.kextc = g.kextc; a.NKT = g.NKT;
+    a.TIH = g.TIH; a.TIW = g.TIW; a.PSx = g.PSx; a.PSg = g.PSg;
+    a.x_bytes = g.x_bytes; a.g_bytes = g.g_bytes; a.tab_bytes = g.tab_bytes;
+    a.tiles_x = cdiv(d->Wout, 16); a.tiles_y = cdiv(d->Hout, 16);
+    a.ntiles = d->B * a.tiles_x * a.tiles_y;
+    MSAU_CHECK_ARG(d->nslabs >= 1 && d->nslabs <= a.ntiles, "wgrad: nslabs %d not in [1,%d]", d->nslabs, a.ntiles);
+    // CTN as instantiated (3 -> 4)
+    int CTN = g.CTN == 3 ? 4 : (g.CTN > 4 ? 8 : g.CTN);
+    MSAU_CHECK_ARG(!(CTN == 8 && g.NKW > 5), "wgrad: Cout %d with K %d unsupported", d->Cout, g.kextc);
+    dim3 grid(d->nslabs, g.nchunks);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == MSAU_F32) return launch_wgrad_ct<float>(s, a, CTN, g.NKW, grid, g.total);
+    return launch_wgrad_ct<bf16_t>(s, a, CTN, g.NKW, grid, g.total);
+}

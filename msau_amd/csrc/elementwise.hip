@@ -1,0 +1,629 @@
+// HBM-bound kernels of the MSAU train path: boundary layout conversion, cross-channel LRN,
+// 2x2 max pool, masked cross entropy, clip+Adam.  All vectorised 16 B per lane along the
+// channel (NHWC) dimension; accumulation in fp32.
+#include "msau_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+inline int grid_for(int64_t work, int cap = 256 * 16) {
+    int64_t b = cdiv64(work, kThreads);
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// =============================================================================================
+// layout: NCHW fp32 (reference API, train_chargrid_funsd_msau.py:50-53) <-> NHWC T
+// =============================================================================================
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int C, int Cs, int64_t HW) {
+    const int cgs = Cs >> 3;
+    const int64_t total = (int64_t)B * cgs * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t p = i % HW;                      // pixel fastest: coalesced plane reads
+        int64_t r = i / HW;
+        int cg = (int)(r % cgs);
+        int b = (int)(r / cgs);
+        typename Vec8<T>::type v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int c = cg * 8 + j;
+            v[j] = (T)(c < C ? src[((int64_t)b * C + c) * HW + p] : 0.f);
+        }
+        store8<T>(dst + ((int64_t)b * HW + p) * Cs + cg * 8, v);
+    }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int B, int C, int Cs, int64_t HW) {
+    const int cgs = Cs >> 3;
+    const int64_t total = (int64_t)B * cgs * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t p = i % HW;
+        int64_t r = i / HW;
+        int cg = (int)(r % cgs);
+        int b = (int)(r / cgs);
+        typename Vec8<T>::type v = load8<T>(src + ((int64_t)b * HW + p) * Cs + cg * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int c = cg * 8 + j;
+            if (c < C) dst[((int64_t)b * C + c) * HW + p] = (float)v[j];
+        }
+    }
+}
+
+template <typename T>
+__global__ void nchw_grad_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int C, int Cs,
+                                         int64_t HW, int accumulate) {
+    const int cgs = Cs >> 3;
+    const int64_t total = (int64_t)B * cgs * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t p = i % HW;
+        int64_t r = i / HW;
+        int cg = (int)(r % cgs);
+        int b = (int)(r / cgs);
+        T* q = dst + ((int64_t)b * HW + p) * Cs + cg * 8;
+        typename Vec8<T>::type v = accumulate ? load8<T>(q) : zero8<T>();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int c = cg * 8 + j;
+            float a = accumulate ? (float)v[j] : 0.f;
+            v[j] = (T)(c < C ? a + src[((int64_t)b * C + c) * HW + p] : 0.f);
+        }
+        store8<T>(q, v);
+    }
+}
+
+// =============================================================================================
+// LRN across channels.  Fast path: C == Cs == n == 8*G, G a power of two: G lanes per pixel,
+// each holding 8 channels; window sums are differences of prefix sums, fetched from the lane
+// G/2 away with one xor-shuffle per channel.  Generic path: one thread per pixel.
+//   forward window of c : [c - n/2, c + (n-1)/2]         (torch.nn.LocalResponseNorm)
+//   adjoint window of j : [j - (n-1)/2, j + n/2]
+// =============================================================================================
+__device__ __forceinline__ float pow_neg_beta(float d, float beta, bool beta075) {
+    if (beta075) { float r = rsqrtf(d); return r * sqrtf(r); }       // d^-0.75, ~2 ulp, 3 VALU ops
+    return __expf(-beta * __logf(d));
+}
+
+template <typename T, int G, bool BWD>
+__global__ void lrn_fast_kernel(const T* __restrict__ a, const T* __restrict__ dy, T* __restrict__ out,
+                                int64_t npix, float alpha_over_n, float beta, float k, bool beta075) {
+    const int64_t total = npix * G;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // all lanes of a G-group run the same number of iterations (total % G == 0, stride % G == 0)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int l = (int)(i % G);
+        typename Vec8<T>::type av = load8<T>(a + i * 8);
+        float x[8], sq[8], P[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { x[j] = (float)av[j]; sq[j] = x[j] * x[j]; }
+        float win[8];
+        if constexpr (G == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) if (c >= j - 4 && c <= j + 3) s += sq[c];
+                win[j] = s;
+            }
+        } else {
+            float run = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { run += sq[j]; P[j] = run; }
+            float E = 0.f, tot;
+            {   // exclusive scan of the lane totals across the G lanes of the pixel
+                float t = run, inc = run;
+#pragma unroll
+                for (int o = 1; o < G; o <<= 1) { float n = __shfl_up(inc, o, G); if (l >= o) inc += n; }
+                E = inc - t;
+                tot = __shfl(inc, G - 1, G);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float X = E + (j ? P[j - 1] : 0.f);            // exclusive prefix at channel 8l+j
+                float Xo = __shfl_xor(X, G / 2, G);
+                win[j] = (l < G / 2) ? Xo : tot - Xo;
+            }
+        }
+        float d[8], dnb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { d[j] = k + alpha_over_n * win[j]; dnb[j] = pow_neg_beta(d[j], beta, beta075); }
+        typename Vec8<T>::type ov;
+        if constexpr (!BWD) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = (T)(x[j] * dnb[j]);
+        } else {
+            typename Vec8<T>::type gv = load8<T>(dy + i * 8);
+            float g[8], qv[8], adj[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { g[j] = (float)gv[j]; qv[j] = g[j] * x[j] * dnb[j] / d[j]; }
+            if constexpr (G == 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) if (c >= j - 3 && c <= j + 4) s += qv[c];
+                    adj[j] = s;
+                }
+            } else {
+                float run = 0.f, Q[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { run += qv[j]; Q[j] = run; }
+                float t = run, inc = run;
+#pragma unroll
+                for (int o = 1; o < G; o <<= 1) { float n = __shfl_up(inc, o, G); if (l >= o) inc += n; }
+                float E = inc - t;
+                float tot = __shfl(inc, G - 1, G);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float I = E + Q[j];                         // inclusive prefix at channel 8l+j
+                    float Io = __shfl_xor(I, G / 2, G);
+                    adj[j] = (l < G / 2) ? Io : tot - Io;
+                }
+            }
+            const float c2 = 2.f * beta * alpha_over_n;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = (T)(g[j] * dnb[j] - c2 * x[j] * adj[j]);
+        }
+        store8<T>(out + i * 8, ov);
+    }
+}
+
+template <typename T, bool BWD>
+__global__ void lrn_generic_kernel(const T* __restrict__ a, const T* __restrict__ dy, T* __restrict__ out,
+                                   int64_t npix, int C, int Cs, int n, float alpha_over_n, float beta, float k, bool beta075) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        float x[128], q[128];
+        for (int c = 0; c < Cs; c += 8) {
+            typename Vec8<T>::type v = load8<T>(a + p * Cs + c);
+            for (int j = 0; j < 8; ++j) x[c + j] = (float)v[j];
+        }
+        if (BWD)
+            for (int c = 0; c < Cs; c += 8) {
+                typename Vec8<T>::type v = load8<T>(dy + p * Cs + c);
+                for (int j = 0; j < 8; ++j) q[c + j] = (float)v[j];      // q holds dy for now
+            }
+        float dnb[128], dd[128];
+        for (int c = 0; c < C; ++c) {
+            float s = 0.f;
+            int lo = c - n / 2, hi = c + (n - 1) / 2;
+            for (int cc = (lo < 0 ? 0 : lo); cc <= hi && cc < C; ++cc) s += x[cc] * x[cc];
+            dd[c] = k + alpha_over_n * s;
+            dnb[c] = pow_neg_beta(dd[c], beta, beta075);
+        }
+        for (int c0 = 0; c0 < Cs; c0 += 8) {
+            typename Vec8<T>::type ov;
+            for (int j = 0; j < 8; ++j) {
+                int c = c0 + j;
+                float o = 0.f;
+                if (c < C) {
+                    if (!BWD) o = x[c] * dnb[c];
+                    else {
+                        float s = 0.f;
+                        int lo = c - (n - 1) / 2, hi = c + n / 2;
+                        for (int cc = (lo < 0 ? 0 : lo); cc <= hi && cc < C; ++cc) s += q[cc] * x[cc] * dnb[cc] / dd[cc];
+                        o = q[c] * dnb[c] - 2.f * beta * alpha_over_n * x[c] * s;
+                    }
+                }
+                ov[j] = (T)o;
+            }
+            store8<T>(out + p * Cs + c0, ov);
+        }
+    }
+}
+
+template <typename T, bool BWD>
+int lrn_dispatch(hipStream_t s, const void* a, const void* dy, void* out, int64_t npix, int C, int Cs, int n,
+                 float alpha, float beta, float k) {
+    MSAU_CHECK_ARG(a && out && (!BWD || dy), "lrn: null pointer");
+    MSAU_CHECK_ARG(npix > 0 && C > 0 && C <= Cs && Cs % 8 == 0 && Cs <= 128 && n >= 1, "lrn: bad dims C=%d Cs=%d n=%d", C, Cs, n);
+    const float aon = alpha / (float)n;
+    const bool b075 = beta == 0.75f;
+    const T* ap = static_cast<const T*>(a);
+    const T* gp = static_cast<const T*>(dy);
+    T* op = static_cast<T*>(out);
+    const int G = Cs / 8;
+    const bool fast = (C == Cs) && (n == C) && ((G & (G - 1)) == 0) && G <= 16;
+    if (fast) {
+        int grid = grid_for(npix * G);
+        switch (G) {
+            case 1: hipLaunchKernelGGL((lrn_fast_kernel<T, 1, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, b075); break;
+            case 2: hipLaunchKernelGGL((lrn_fast_kernel<T, 2, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, b075); break;
+            case 4: hipLaunchKernelGGL((lrn_fast_kernel<T, 4, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, b075); break;
+            case 8: hipLaunchKernelGGL((lrn_fast_kernel<T, 8, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, b075); break;
+            default: hipLaunchKernelGGL((lrn_fast_kernel<T, 16, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, b075); break;
+        }
+    } else {
+        hipLaunchKernelGGL((lrn_generic_kernel<T, BWD>), dim3(grid_for(npix)), dim3(kThreads), 0, s, ap, gp, op, npix, C, Cs, n, aon, beta, k, b075);
+    }
+    MSAU_CHECK_LAUNCH("lrn_kernel");
+    return 0;
+}
+
+// =============================================================================================
+// 2x2/2 max pool after zero SAME padding (bottom/right only, for odd sizes): model/model.py:158-160
+// =============================================================================================
+template <typename T>
+__global__ void pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx,
+                                int B, int H, int W, int Ho, int Wo, int Cs) {
+    const int cgs = Cs >> 3;
+    const int64_t total = (int64_t)B * Ho * Wo * cgs;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int cg = (int)(i % cgs);
+        int64_t p = i / cgs;
+        int ox = (int)(p % Wo); p /= Wo;
+        int oy = (int)(p % Ho);
+        int b = (int)(p / Ho);
+        float best[8]; int bi[8];
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            int iy = 2 * oy + (pos >> 1), ix = 2 * ox + (pos & 1);
+            typename Vec8<T>::type v = zero8<T>();                // the pad value is 0, not -inf
+            if (iy < H && ix < W) v = load8<T>(x + (((int64_t)b * H + iy) * W + ix) * Cs + cg * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = (float)v[j];
+                if (pos == 0 || f > best[j]) { best[j] = f; bi[j] = pos; }     // strict >: first maximum wins
+            }
+        }
+        typename Vec8<T>::type o;
+        uint64_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o[j] = (T)best[j]; packed |= (uint64_t)bi[j] << (8 * j); }
+        store8<T>(y + i * 8, o);
+        *reinterpret_cast<uint64_t*>(idx + i * 8) = packed;
+    }
+}
+
+template <typename T>
+__global__ void pool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx,
+                                const T* __restrict__ mask, int B, int H, int W, int Ho, int Wo, int Cs, int accumulate) {
+    const int cgs = Cs >> 3;
+    const int64_t total = (int64_t)B * H * W * cgs;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int cg = (int)(i % cgs);
+        int64_t p = i / cgs;
+        int ix = (int)(p % W); p /= W;
+        int iy = (int)(p % H);
+        int b = (int)(p / H);
+        const int pos = ((iy & 1) << 1) | (ix & 1);
+        const int64_t o = ((((int64_t)b * Ho + (iy >> 1)) * Wo + (ix >> 1)) * cgs + cg) * 8;
+        typename Vec8<T>::type g = load8<T>(dy + o);
+        uint64_t packed = *reinterpret_cast<const uint64_t*>(idx + o);
+        typename Vec8<T>::type old = accumulate ? load8<T>(dx + i * 8) : zero8<T>();
+        typename Vec8<T>::type m;
+        if (mask) m = load8<T>(mask + i * 8);
+        typename Vec8<T>::type r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = (float)old[j] + ((int)((packed >> (8 * j)) & 0xff) == pos ? (float)g[j] : 0.f);
+            if (mask && !((float)m[j] > 0.f)) v = 0.f;
+            r[j] = (T)v;
+        }
+        store8<T>(dx + i * 8, r);
+    }
+}
+
+// =============================================================================================
+// masked cross entropy (model/model.py:446-459), batch rule of SURVEY 8(e)
+// =============================================================================================
+__global__ void label_count_kernel(const int64_t* __restrict__ labels, int32_t* __restrict__ counts, int64_t hw) {
+    const int b = blockIdx.y;
+    int local = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (int64_t)gridDim.x * blockDim.x)
+        local += labels[(int64_t)b * hw + i] != 0;
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&counts[b], local);            // integer: order-independent
+}
+
+template <typename T>
+__global__ void masked_ce_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels,
+                                 const int32_t* __restrict__ counts, T* __restrict__ dlogits, float* __restrict__ partials,
+                                 int B, int64_t hw, int C, int Cs, float scale) {
+    __shared__ float red[kThreads / 64];
+    float local = 0.f;
+    const int64_t total = (int64_t)B * hw;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(p / hw);
+        const int64_t lab = labels[p];
+        const bool on = lab != 0 && lab < C;
+        const float w = on ? scale / (float)max(counts[b], 1) : 0.f;
+        float x[16];
+        float mx = -INFINITY;
+        for (int c0 = 0; c0 < Cs && c0 < 16; c0 += 8) {
+            typename Vec8<T>::type v = load8<T>(logits + p * Cs + c0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { x[c0 + j] = (float)v[j]; if (c0 + j < C) mx = fmaxf(mx, x[c0 + j]); }
+        }
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += __expf(x[c] - mx);
+        const float lse = mx + __logf(se);
+        if (on) local += w * (lse - x[(int)lab]);
+        for (int c0 = 0; c0 < Cs; c0 += 8) {
+            typename Vec8<T>::type o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int c = c0 + j;
+                float g = 0.f;
+                if (on && c < C) g = w * (__expf(x[c] - lse) - (c == (int)lab ? 1.f : 0.f));
+                o[j] = (T)g;
+            }
+            store8<T>(dlogits + p * Cs + c0, o);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < kThreads / 64; ++i) s += red[i];
+        partials[blockIdx.x] = s;
+    }
+}
+
+__global__ void ordered_sum_kernel(const float* __restrict__ partials, int n, float* __restrict__ accum) {
+    // one wave, fixed association order -> reproducible
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) s += partials[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (threadIdx.x == 0) *accum += s;
+}
+
+// =============================================================================================
+// per-channel sums (bias gradient of the transposed conv)
+// =============================================================================================
+template <typename T>
+__global__ void channel_sum_kernel(const T* __restrict__ g, int64_t npix, int Cs, float* __restrict__ partials) {
+    // thread t of the block owns channel group (t % cgs); rows of pixels strided by blockDim/cgs
+    extern __shared__ float sm[];
+    const int cgs = Cs >> 3;
+    const int cg = threadIdx.x % cgs, lane_p = threadIdx.x / cgs, ppb = blockDim.x / cgs;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (lane_p < ppb)
+        for (int64_t p = (int64_t)blockIdx.x * ppb + lane_p; p < npix; p += (int64_t)gridDim.x * ppb) {
+            typename Vec8<T>::type v = load8<T>(g + p * Cs + cg * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+        }
+    float* mine = sm + threadIdx.x * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mine[j] = acc[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < Cs; c += blockDim.x) {
+        int cgc = c >> 3, j = c & 7;
+        float s = 0.f;
+        for (int r = 0; r < ppb; ++r) s += sm[(r * cgs + cgc) * 8 + j];
+        partials[(int64_t)blockIdx.x * Cs + c] = s;
+    }
+}
+
+// =============================================================================================
+// global-norm clip + Adam (train_chargrid_funsd_msau.py:24-26,58-59)
+// =============================================================================================
+__global__ void sqsum_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partials) {
+    __shared__ float red[kThreads / 64];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = g[i];
+        s += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < kThreads / 64; ++i) t += red[i];
+        partials[blockIdx.x] = t;
+    }
+}
+
+__global__ void adam_prep_kernel(const float* __restrict__ partials, int n, float* __restrict__ state,
+                                 float beta1, float beta2, float max_norm, float grad_scale) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) s += partials[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (threadIdx.x == 0) {
+        float step = state[0] + 1.f;
+        float norm = sqrtf(s) * grad_scale;
+        float coef = max_norm / (norm + 1e-6f);               // torch.nn.utils.clip_grad_norm_
+        state[0] = step;
+        state[1] = norm;
+        state[2] = coef < 1.f ? coef : 1.f;
+        state[3] = (float)(1.0 - pow((double)beta1, (double)step));
+        state[4] = (float)(1.0 - pow((double)beta2, (double)step));
+    }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            const float* __restrict__ state, int64_t n, float lr, float beta1, float beta2, float eps,
+                            float grad_scale) {
+    const float gs = state[2] * grad_scale;
+    const float bc1 = state[3], bc2s = sqrtf(state[4]);
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i] * gs;
+        float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        float denom = sqrtf(vi) / bc2s + eps;
+        p[i] -= step_size * (mi / denom);
+    }
+}
+
+__global__ void softmax_nchw_kernel(const float* __restrict__ logits, float* __restrict__ pred, int B, int C, int64_t hw) {
+    const int64_t total = (int64_t)B * hw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t b = i / hw, p = i % hw;
+        const float* src = logits + b * C * hw + p;
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, src[c * hw]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += __expf(src[c * hw] - mx);
+        float inv = 1.f / se;
+        for (int c = 0; c < C; ++c) pred[b * C * hw + c * hw + p] = __expf(src[c * hw] - mx) * inv;
+    }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16)                          \
+    do {                                                                \
+        if ((dtype) == MSAU_F32) { CALL_F32; }                          \
+        else if ((dtype) == MSAU_BF16) { CALL_BF16; }                   \
+        else return msau_set_error(MSAU_ERR_ARG, "bad dtype %d", (int)(dtype)); \
+    } while (0)
+
+extern "C" int msau_nchw_to_nhwc(void* stream, int dtype, const float* src, void* dst, int B, int C, int Cs, int H, int W) {
+    MSAU_CHECK_ARG(src && dst && B > 0 && C > 0 && Cs >= C && Cs % 8 == 0 && H > 0 && W > 0, "nchw_to_nhwc: bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int64_t HW = (int64_t)H * W;
+    int grid = grid_for((int64_t)B * (Cs / 8) * HW);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(kThreads), 0, s, src, static_cast<float*>(dst), B, C, Cs, HW),
+               hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid), dim3(kThreads), 0, s, src, static_cast<bf16_t*>(dst), B, C, Cs, HW));
+    MSAU_CHECK_LAUNCH("nchw_to_nhwc");
+    return 0;
+}
+
+extern "C" int msau_nhwc_to_nchw(void* stream, int dtype, const void* src, float* dst, int B, int C, int Cs, int H, int W) {
+    MSAU_CHECK_ARG(src && dst && B > 0 && C > 0 && Cs >= C && Cs % 8 == 0 && H > 0 && W > 0, "nhwc_to_nchw: bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int64_t HW = (int64_t)H * W;
+    int grid = grid_for((int64_t)B * (Cs / 8) * HW);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid), dim3(kThreads), 0, s, static_cast<const float*>(src), dst, B, C, Cs, HW),
+               hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid), dim3(kThreads), 0, s, static_cast<const bf16_t*>(src), dst, B, C, Cs, HW));
+    MSAU_CHECK_LAUNCH("nhwc_to_nchw");
+    return 0;
+}
+
+extern "C" int msau_nchw_grad_to_nhwc(void* stream, int dtype, const float* src, void* dst, int B, int C, int Cs, int H, int W,
+                                      int accumulate) {
+    MSAU_CHECK_ARG(src && dst && B > 0 && C > 0 && Cs >= C && Cs % 8 == 0 && H > 0 && W > 0, "nchw_grad_to_nhwc: bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int64_t HW = (int64_t)H * W;
+    int grid = grid_for((int64_t)B * (Cs / 8) * HW);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(nchw_grad_to_nhwc_kernel<float>, dim3(grid), dim3(kThreads), 0, s, src, static_cast<float*>(dst), B, C, Cs, HW, accumulate),
+               hipLaunchKernelGGL(nchw_grad_to_nhwc_kernel<bf16_t>, dim3(grid), dim3(kThreads), 0, s, src, static_cast<bf16_t*>(dst), B, C, Cs, HW, accumulate));
+    MSAU_CHECK_LAUNCH("nchw_grad_to_nhwc");
+    return 0;
+}
+
+extern "C" int msau_lrn_fwd(void* stream, int dtype, const void* a, void* y, int64_t npix, int C, int Cs, int n,
+                            float alpha, float beta, float k) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == MSAU_F32) return lrn_dispatch<float, false>(s, a, nullptr, y, npix, C, Cs, n, alpha, beta, k);
+    if (dtype == MSAU_BF16) return lrn_dispatch<bf16_t, false>(s, a, nullptr, y, npix, C, Cs, n, alpha, beta, k);
+    return msau_set_error(MSAU_ERR_ARG, "lrn_fwd: bad dtype");
+}
+
+extern "C" int msau_lrn_bwd(void* stream, int dtype, const void* a, const void* dy, void* da, int64_t npix, int C, int Cs,
+                            int n, float alpha, float beta, float k) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == MSAU_F32) return lrn_dispatch<float, true>(s, a, dy, da, npix, C, Cs, n, alpha, beta, k);
+    if (dtype == MSAU_BF16) return lrn_dispatch<bf16_t, true>(s, a, dy, da, npix, C, Cs, n, alpha, beta, k);
+    return msau_set_error(MSAU_ERR_ARG, "lrn_bwd: bad dtype");
+}
+
+extern "C" int msau_maxpool2x2_fwd(void* stream, int dtype, const void* x, void* y, uint8_t* idx, int B, int H, int W, int Cs) {
+    MSAU_CHECK_ARG(x && y && idx && B > 0 && H > 0 && W > 0 && Cs % 8 == 0, "maxpool_fwd: bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    int grid = grid_for((int64_t)B * Ho * Wo * (Cs / 8));
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(pool_fwd_kernel<float>, dim3(grid), dim3(kThreads), 0, s, static_cast<const float*>(x), static_cast<float*>(y), idx, B, H, W, Ho, Wo, Cs),
+               hipLaunchKernelGGL(pool_fwd_kernel<bf16_t>, dim3(grid), dim3(kThreads), 0, s, static_cast<const bf16_t*>(x), static_cast<bf16_t*>(y), idx, B, H, W, Ho, Wo, Cs));
+    MSAU_CHECK_LAUNCH("pool_fwd");
+    return 0;
+}
+
+extern "C" int msau_maxpool2x2_bwd(void* stream, int dtype, const void* dy, const uint8_t* idx, void* dx, const void* mask,
+                                   int B, int H, int W, int Cs, int accumulate) {
+    MSAU_CHECK_ARG(dy && dx && idx && B > 0 && H > 0 && W > 0 && Cs % 8 == 0, "maxpool_bwd: bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    int grid = grid_for((int64_t)B * H * W * (Cs / 8));
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(pool_bwd_kernel<float>, dim3(grid), dim3(kThreads), 0, s, static_cast<const float*>(dy), idx, static_cast<float*>(dx), static_cast<const float*>(mask), B, H, W, Ho, Wo, Cs, accumulate),
+               hipLaunchKernelGGL(pool_bwd_kernel<bf16_t>, dim3(grid), dim3(kThreads), 0, s, static_cast<const bf16_t*>(dy), idx, static_cast<bf16_t*>(dx), static_cast<const bf16_t*>(mask), B, H, W, Ho, Wo, Cs, accumulate));
+    MSAU_CHECK_LAUNCH("pool_bwd");
+    return 0;
+}
+
+extern "C" int msau_label_counts(void* stream, const int64_t* labels, int32_t* counts, int B, int64_t hw) {
+    MSAU_CHECK_ARG(labels && counts && B > 0 && hw > 0, "label_counts: bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * B, s);
+    if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "label_counts: memset: %s", hipGetErrorString(e));
+    int gx = grid_for(hw, 64);
+    hipLaunchKernelGGL(label_count_kernel, dim3(gx, B), dim3(kThreads), 0, s, labels, counts, hw);
+    MSAU_CHECK_LAUNCH("label_count");
+    return 0;
+}
+
+static int ce_blocks(int64_t npix) { return grid_for(npix, 1024); }
+extern "C" int64_t msau_ce_ws_floats(int64_t npix_total) { return ce_blocks(npix_total); }
+
+extern "C" int msau_masked_ce(void* stream, int dtype, const void* logits, const int64_t* labels, const int32_t* counts,
+                              void* dlogits, float* loss_accum, float* ws, int B, int64_t hw, int C, int Cs, float scale) {
+    MSAU_CHECK_ARG(logits && labels && counts && dlogits && loss_accum && ws, "masked_ce: null pointer");
+    MSAU_CHECK_ARG(B > 0 && hw > 0 && C > 0 && C <= Cs && Cs % 8 == 0 && Cs <= 16, "masked_ce: bad dims (n_class <= 16)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int nb = ce_blocks((int64_t)B * hw);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(masked_ce_kernel<float>, dim3(nb), dim3(kThreads), 0, s, static_cast<const float*>(logits), labels, counts, static_cast<float*>(dlogits), ws, B, hw, C, Cs, scale),
+               hipLaunchKernelGGL(masked_ce_kernel<bf16_t>, dim3(nb), dim3(kThreads), 0, s, static_cast<const bf16_t*>(logits), labels, counts, static_cast<bf16_t*>(dlogits), ws, B, hw, C, Cs, scale));
+    MSAU_CHECK_LAUNCH("masked_ce");
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(64), 0, s, ws, nb, loss_accum);
+    MSAU_CHECK_LAUNCH("ordered_sum");
+    return 0;
+}
+
+extern "C" int msau_channel_sum(void* stream, int dtype, const void* g, int64_t npix, int Cs, float* partials, int nblk) {
+    MSAU_CHECK_ARG(g && partials && npix > 0 && Cs % 8 == 0 && Cs <= 128 && nblk > 0, "channel_sum: bad args");
+    MSAU_CHECK_ARG(kThreads % (Cs / 8) == 0, "channel_sum: Cs/8 must divide %d", kThreads);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    size_t lds = kThreads * 8 * sizeof(float);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nblk), dim3(kThreads), lds, s, static_cast<const float*>(g), npix, Cs, partials),
+               hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(nblk), dim3(kThreads), lds, s, static_cast<const bf16_t*>(g), npix, Cs, partials));
+    MSAU_CHECK_LAUNCH("channel_sum");
+    return 0;
+}
+
+static int adam_blocks(int64_t n) { return grid_for(n, 512); }
+extern "C" int64_t msau_adam_ws_floats(int64_t n) { return adam_blocks(n); }
+
+extern "C" int msau_clip_adam_step(void* stream, float* params, const float* grads, float* m, float* v, float* state,
+                                   float* ws, int64_t n, float lr, float beta1, float beta2, float eps, float max_norm,
+                                   float grad_scale) {
+    MSAU_CHECK_ARG(params && grads && m && v && state && ws && n > 0, "clip_adam: bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int nb = adam_blocks(n);
+    hipLaunchKernelGGL(sqsum_kernel, dim3(nb), dim3(kThreads), 0, s, grads, n, ws);
+    MSAU_CHECK_LAUNCH("sqsum");
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, ws, nb, state, beta1, beta2, max_norm, grad_scale);
+    MSAU_CHECK_LAUNCH("adam_prep");
+    hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(kThreads), 0, s, params, grads, m, v, state, n, lr, beta1, beta2, eps, grad_scale);
+    MSAU_CHECK_LAUNCH("adam");
+    return 0;
+}
+
+extern "C" int msau_fill_zero(void* stream, void* p, int64_t bytes) {
+    MSAU_CHECK_ARG(p && bytes >= 0, "fill_zero: bad args");
+    hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "fill_zero: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int msau_softmax_channels_nchw(void* stream, const float* logits, float* pred, int B, int C, int64_t hw) {
+    MSAU_CHECK_ARG(logits && pred && B > 0 && C > 0 && hw > 0, "softmax: bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(softmax_nchw_kernel, dim3(grid_for((int64_t)B * hw)), dim3(kThreads), 0, s, logits, pred, B, C, hw);
+    MSAU_CHECK_LAUNCH("softmax_nchw");
+    return 0;
+}

@@ -1,0 +1,82 @@
+// Internal helpers shared by the kernels of libmsau_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/msau_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+#define MSAU_LDS_LIMIT (160 * 1024)
+
+int msau_set_error(int code, const char* fmt, ...);
+
+#define MSAU_CHECK_ARG(cond, ...)                                   \
+    do {                                                            \
+        if (!(cond)) return msau_set_error(MSAU_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+#define MSAU_CHECK_LAUNCH(name)                                                         \
+    do {                                                                                \
+        hipError_t e__ = hipGetLastError();                                             \
+        if (e__ != hipSuccess)                                                          \
+            return msau_set_error(MSAU_ERR_HIP, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int roundup(int a, int b) { return cdiv(a, b) * b; }
+
+// ---- storage-type traits --------------------------------------------------------------------
+template <typename T> struct Vec8;
+template <> struct Vec8<float>  { typedef f32x8 type; };
+template <> struct Vec8<bf16_t> { typedef bf16x8 type; };
+template <typename T> struct Vec4;
+template <> struct Vec4<float>  { typedef f32x4 type; };
+template <> struct Vec4<bf16_t> { typedef bf16x4 type; };
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+template <typename T> __device__ __forceinline__ typename Vec8<T>::type zero8() {
+    typename Vec8<T>::type z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (T)0.0f;
+    return z;
+}
+template <typename T> __device__ __forceinline__ typename Vec8<T>::type relu8(typename Vec8<T>::type v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = ((float)v[i] > 0.0f) ? v[i] : (T)0.0f;
+    return v;
+}
+template <typename T> __device__ __forceinline__ typename Vec8<T>::type load8(const T* p) {
+    return *reinterpret_cast<const typename Vec8<T>::type*>(p);
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, typename Vec8<T>::type v) {
+    *reinterpret_cast<typename Vec8<T>::type*>(p) = v;
+}
+template <typename T> __device__ __forceinline__ typename Vec4<T>::type load4(const T* p) {
+    return *reinterpret_cast<const typename Vec4<T>::type*>(p);
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, typename Vec4<T>::type v) {
+    *reinterpret_cast<typename Vec4<T>::type*>(p) = v;
+}
+
+// one "k-group" step of the implicit GEMM: 8 k-values per lane.
+//   bf16: a single v_mfma_f32_16x16x32_bf16 (lane l holds k = 8*(l>>4) + j)
+//   f32 : eight v_mfma_f32_16x16x4_f32; instruction j takes element j of each lane's group, so the
+//         4 k-slots of instruction j are k = 8*(l>>4) + j for the 4 lane groups -- A and B agree,
+//         which is all the MFMA needs.  Exact fp32 products and sums.
+__device__ __forceinline__ f32x4 mma8(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma8(f32x8 a, f32x8 b, f32x4 c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+    return c;
+}

@@ -1,0 +1,386 @@
+"""Drop-in counterpart of the reference's model API (model/model.py:399-459 `MSAUWrapper`).
+
+Same constructor, `forward -> (pred, logits, aux_logits)`, `loss`, `save`, `load_weights`, the same
+`state_dict` keys / shapes (fp32, OIHW / IOHW), but the network itself runs as a static plan of
+hand-written HIP kernels (msau_amd/plan.py, msau_amd/csrc/*).  There is no PyTorch-op fallback: on a
+machine without the HIP library or without a GPU the compute entry points raise.
+
+Two ways to train:
+  * reference style -- `model(x)`, `model.loss(...)`, `loss.backward()`, `clip_grad_norm_`, `Adam.step()`
+    (train_chargrid_funsd_msau.py:46-59): the whole net is ONE autograd node;
+  * `TrainEngine.step(x, labels)` -- the same kernels plus fused masked-CE, RCCL gradient
+    all-reduce and a fused clip+Adam over the flat parameter buffer, optionally replayed as a HIP graph.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .plan import Plan
+
+DTYPES = {"fp32": L.F32, "float32": L.F32, "bf16": L.BF16, "bfloat16": L.BF16}
+
+
+def param_shapes(cfg: dict) -> "OrderedDict[str, Tuple[int, ...]]":
+    """state_dict key -> shape in the reference's registration order
+    (model/model.py:98-127 encoder, :197-222 decoder, :356-376 stages and end convs)."""
+    S, R, Fr = cfg["scale_space_num"], cfg["res_depth"], cfg["featRoot"]
+    k, nb = cfg["filter_size"], cfg.get("num_blocks", 3)
+    out: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+
+    def conv(prefix, co, ci, kk):
+        out[prefix + ".weight"] = (co, ci, kk, kk)
+        out[prefix + ".bias"] = (co,)
+
+    for b in range(nb):
+        cin = cfg["channels"] if b == 0 else cfg["n_class"]
+        pd = f"msau_net.blocks.{b}.downsamplingblock"
+        pu = f"msau_net.blocks.{b}.upsamplingblock"
+        for l in range(S):
+            for r in range(R):
+                conv(f"{pd}.conv_res_list.{l}.conv_res_list.{r}.custom_conv", Fr * 2 ** l, Fr * 2 ** l, k)
+        last = cin
+        for l in range(S):
+            conv(f"{pd}.conv1s.{l}.conv", Fr * 2 ** l, last, k)
+            last = Fr * 2 ** l
+        if b > 0:
+            for l in range(S):
+                conv(f"{pd}.conv1_1s.{l}.custom_conv", Fr * 2 ** l, 2 * Fr * 2 ** l, 1)
+        Cb = Fr * 2 ** (S - 1)
+        for nm, co in (("f", Cb // 8), ("g", Cb // 8), ("h", Cb)):
+            conv(f"{pd}.layer_attentions.attention_block.{nm}.conv", co, Cb, 1)
+        for l in range(S - 1):
+            for r in range(R):
+                conv(f"{pu}.conv_res_list.{l}.conv_res_list.{r}.custom_conv", Fr * 2 ** l, Fr * 2 ** l, k)
+        for l in range(S - 1):
+            conv(f"{pu}.conv1s.{l}.custom_conv", Fr * 2 ** l, 2 * Fr * 2 ** l, k)
+        if b > 0:
+            for l in range(S - 1):
+                conv(f"{pu}.conv1_1s.{l}.custom_conv", Fr * 2 ** l, 2 * Fr * 2 ** l, 1)
+        for l in range(S - 1):
+            c = Fr * 2 ** l
+            out[f"{pu}.deconvs.{l}.conv.weight"] = (2 * c, c, k, k)        # ConvTranspose2d: [in, out, k, k]
+            out[f"{pu}.deconvs.{l}.conv.bias"] = (c,)
+    for b in range(nb):
+        conv(f"msau_net.end_convs.{b}.custom_conv", cfg["n_class"], Fr, 4)
+    return out
+
+
+def _init_param(key: str, shape, gen: Optional[torch.Generator], fan_in: int = 0) -> torch.Tensor:
+    """Reference initialisation statistics: W ~ N(0, sqrt(2/(kh*kw*K2+K3))), b ~ N(0.1, 1e-5)
+    (layers.py:33-36,59-60,111-114,130-131,216,227-228); attention 1x1 convs keep torch's Conv2d
+    default (attention.py:19-21)."""
+    if ".attention_block." in key:
+        # kaiming_uniform(a=sqrt(5)) weights and U(-1/sqrt(fan_in), +) biases share the same bound
+        bound = 1.0 / math.sqrt(fan_in)
+        return (torch.rand(shape, generator=gen) * 2 - 1) * bound
+    if len(shape) == 1:
+        return 0.1 + 1e-5 * torch.randn(shape, generator=gen)
+    std = math.sqrt(2.0 / (shape[2] * shape[3] * shape[1] + shape[0]))
+    return std * torch.randn(shape, generator=gen)
+
+
+class _Node(nn.Module):
+    """Name-only container used to reproduce the reference's module tree (and thereby its state_dict keys)."""
+
+
+class _MSAUFunction(torch.autograd.Function):
+    """The whole network as one autograd node: forward / backward are the plan's kernel sequences."""
+
+    @staticmethod
+    def forward(ctx, wrapper, x, *params):
+        plan = wrapper._plan_for(x, training=True)
+        logits, aux = plan.forward(wrapper._flat, x)
+        ctx.wrapper, ctx.plan = wrapper, plan
+        outs = (logits.clone(), aux.clone() if aux is not None else None)
+        ctx.has_aux = aux is not None
+        return outs if aux is not None else (outs[0],)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        w, plan = ctx.wrapper, ctx.plan
+        g_logits = gouts[0]
+        g_aux = gouts[1] if ctx.has_aux else None
+        plan.set_external_grads(g_logits, g_aux)
+        flat_g = torch.zeros_like(w._flat)               # fresh buffer: no aliasing between backward calls
+        plan.backward(flat_g)
+        grads = []
+        for key, p in w._named:
+            off, n = w._poff[key], p.numel()
+            grads.append(flat_g[off:off + n].view(p.shape) if key not in w._dead else None)
+        return (None, None, *grads)
+
+
+class _MaskedCEFunction(torch.autograd.Function):
+    """MSAUWrapper.loss (model/model.py:446-459) on NCHW fp32 logits, batch rule of SURVEY 8(e)."""
+
+    @staticmethod
+    def forward(ctx, logits, aux, label):
+        B, C, H, W = logits.shape
+        dev = logits.device
+        Cs = -(-C // 8) * 8
+        s = torch.cuda.current_stream().cuda_stream
+        label = label.reshape(B, H, W).contiguous().long()
+        counts = torch.zeros((B,), dtype=torch.int32, device=dev)
+        L.call("msau_label_counts", s, label.data_ptr(), counts.data_ptr(), B, H * W)
+        loss = torch.zeros((1,), dtype=torch.float32, device=dev)
+        ws = torch.zeros((int(L.load().msau_ce_ws_floats(B * H * W)),), dtype=torch.float32, device=dev)
+        grads = []
+        for t in (logits, aux):
+            if t is None:
+                grads.append(None)
+                continue
+            t = t.contiguous().float()
+            nhwc = torch.empty((B, H, W, Cs), dtype=torch.float32, device=dev)
+            dn = torch.empty_like(nhwc)
+            L.call("msau_nchw_to_nhwc", s, L.F32, t.data_ptr(), nhwc.data_ptr(), B, C, Cs, H, W)
+            L.call("msau_masked_ce", s, L.F32, nhwc.data_ptr(), label.data_ptr(), counts.data_ptr(), dn.data_ptr(),
+                   loss.data_ptr(), ws.data_ptr(), B, H * W, C, Cs, 1.0 / B)
+            g = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
+            L.call("msau_nhwc_to_nchw", s, L.F32, dn.data_ptr(), g.data_ptr(), B, C, Cs, H, W)
+            grads.append(g)
+        ctx.save_for_backward(*[g for g in grads if g is not None])
+        ctx.has_aux = aux is not None
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, go):
+        saved = ctx.saved_tensors
+        g_logits = saved[0] * go
+        g_aux = saved[1] * go if ctx.has_aux else None
+        return g_logits, g_aux, None
+
+
+class MSAUWrapper(nn.Module):
+    """API-compatible with model/model.py:399-459.  Extra model_kwargs: `num_blocks` (stages,
+    reference hard-codes 3: model.py:355) and `dtype` ("fp32" | "bf16" activation/weight storage)."""
+
+    def __init__(self, channels=1, n_class=2, model_kwargs={}):
+        super().__init__()
+        self.n_class = n_class
+        self.channels = channels
+        kw = dict(model_kwargs)
+        self.scale_space_num = kw.get("scale_space_num", 6)
+        self.res_depth = kw.get("res_depth", 3)
+        self.featRoot = kw.get("featRoot", 8)
+        self.filter_size = kw.get("filter_size", 3)
+        self.pool_size = kw.get("pool_size", 2)
+        self.activation_name = kw.get("activation_name", "relu")
+        if self.activation_name != "relu":
+            raise NotImplementedError("only activation_name='relu' has HIP kernels")
+        self.model = kw.get("model", "msau")
+        self.num_scales = kw.get("num_scales", 3)
+        self.final_act = kw.get("final_act", "softmax")
+        if self.final_act not in ("softmax", "identity"):
+            # the reference's default "sigmoid" raises TypeError in its own constructor (model.py:429)
+            raise ValueError("final_act must be 'softmax' or 'identity'")
+        self.num_blocks = kw.get("num_blocks", 3)
+        self.dtype_name = kw.get("dtype", "fp32")
+        self._dtype = DTYPES[self.dtype_name]
+        if self.pool_size != 2 or self.filter_size % 2 != 1:
+            raise NotImplementedError("pool_size must be 2 and filter_size odd")
+        self.cfg = dict(channels=channels, n_class=n_class, scale_space_num=self.scale_space_num,
+                        res_depth=self.res_depth, featRoot=self.featRoot, filter_size=self.filter_size,
+                        pool_size=self.pool_size, num_blocks=self.num_blocks)
+
+        shapes = param_shapes(self.cfg)
+        self._poff: Dict[str, int] = {}
+        self._pshape: Dict[str, Tuple[int, ...]] = dict(shapes)
+        off = 0
+        for k, shp in shapes.items():
+            self._poff[k] = off
+            off += _ru4(int(math.prod(shp)))
+        self._total = off
+        self._flat = torch.zeros(self._total, dtype=torch.float32)
+        gen = torch.Generator().manual_seed(int(kw.get("seed", torch.initial_seed() % (2 ** 31))))
+        self._named = []
+        self.msau_net = _Node()
+        for k, shp in shapes.items():
+            n = int(math.prod(shp))
+            wshp = shapes[k[:-4] + "weight"] if k.endswith(".bias") else shp
+            self._flat[self._poff[k]:self._poff[k] + n] = _init_param(k, shp, gen, wshp[1] * wshp[2] * wshp[3]).reshape(-1)
+            p = nn.Parameter(self._flat[self._poff[k]:self._poff[k] + n].view(shp))
+            self._named.append((k, p))
+            node = self
+            parts = k.split(".")
+            for part in parts[:-1]:
+                if part not in node._modules:
+                    node.add_module(part, _Node())
+                node = node._modules[part]
+            node.register_parameter(parts[-1], p)
+        # parameters that never receive a gradient: the last stage's attention (model.py:149-150)
+        self._dead = {k for k in shapes
+                      if f"blocks.{self.num_blocks - 1}.downsamplingblock.layer_attentions" in k}
+        self.predictor = nn.Softmax(dim=1) if self.final_act == "softmax" else nn.Sequential()
+        self.criterion = nn.CrossEntropyLoss()
+        self._plans: "OrderedDict[tuple, Plan]" = OrderedDict()
+        self.max_cached_plans = 4
+
+    # ---- flat parameter storage ---------------------------------------------------------------
+    def _rebind(self):
+        for k, p in self._named:
+            n = p.numel()
+            p.data = self._flat[self._poff[k]:self._poff[k] + n].view(self._pshape[k])
+            p.grad = None
+        self._plans.clear()
+
+    def _apply(self, fn, recurse=True):
+        new_flat = fn(self._flat)
+        if new_flat.dtype != torch.float32:
+            raise TypeError("MSAUWrapper keeps fp32 master parameters; choose bf16 storage with model_kwargs['dtype']")
+        self._flat = new_flat
+        self._rebind()
+        return self
+
+    @property
+    def flat_parameters(self) -> torch.Tensor:
+        return self._flat
+
+    # ---- plans ----------------------------------------------------------------------------------
+    def _plan_for(self, x: torch.Tensor, training: bool) -> Plan:
+        if not x.is_cuda:
+            raise RuntimeError("MSAUWrapper runs on an MI355X through libmsau_hip.so; input must be a CUDA/HIP tensor "
+                               "(there is no CPU fallback)")
+        if self._flat.device != x.device:
+            raise RuntimeError(f"model is on {self._flat.device}, input on {x.device}")
+        B, C, H, W = x.shape
+        if C != self.channels:
+            raise ValueError(f"expected {self.channels} input channels, got {C}")
+        key = (B, H, W, training)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = Plan(self.cfg, B, H, W, self._dtype, x.device, self._poff, self._pshape, training=training)
+            self._plans[key] = plan
+            while len(self._plans) > self.max_cached_plans:
+                self._plans.popitem(last=False)
+        else:
+            self._plans.move_to_end(key)
+        return plan
+
+    # ---- reference API ----------------------------------------------------------------------------
+    def forward(self, inp):
+        x = inp.contiguous().float()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for _, p in self._named)
+        if need_grad:
+            outs = _MSAUFunction.apply(self, x, *[p for _, p in self._named])
+            logits = outs[0]
+            aux = outs[1] if len(outs) > 1 else None
+        else:
+            plan = self._plan_for(x, training=False)
+            lg, ax = plan.forward(self._flat, x)
+            logits, aux = lg.clone(), (ax.clone() if ax is not None else None)
+        if self.final_act == "softmax":
+            with torch.no_grad():
+                B, C, H, W = logits.shape
+                pred = torch.empty_like(logits)
+                L.call("msau_softmax_channels_nchw", torch.cuda.current_stream().cuda_stream, logits.data_ptr(),
+                       pred.data_ptr(), B, C, H * W)
+        else:
+            pred = logits
+        return pred, logits, aux
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load_weights(self, path):
+        self.load_state_dict(torch.load(path, map_location=self._flat.device))
+
+    def loss(self, out_grid, out_grid_aux, label_mask):
+        """Masked CE of final + aux logits over pixels with label != 0 (model/model.py:446-459).
+        Accepts label_mask [B,H,W] (the reference: B = 1): per-sample masked mean, then mean over B."""
+        return _MaskedCEFunction.apply(out_grid, out_grid_aux, label_mask)
+
+
+def _ru4(n: int) -> int:
+    return -(-n // 4) * 4          # keep every parameter 16-byte aligned inside the flat buffer
+
+
+class TrainEngine:
+    """Fused training step on one GPU (one process per GPU under data parallelism).
+
+    forward -> masked CE (+grad) -> backward -> [RCCL all-reduce of the flat gradient] ->
+    global-norm clip + Adam, all on the flat fp32 parameter buffer of `model`
+    (train_chargrid_funsd_msau.py:46-59 with lr 1e-4, clip 1.0)."""
+
+    def __init__(self, model: MSAUWrapper, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
+                 max_norm: float = 1.0, process_group=None, use_graph: bool = False):
+        self.model, self.lr, self.betas, self.eps, self.max_norm = model, lr, betas, eps, max_norm
+        flat = model._flat
+        if not flat.is_cuda:
+            raise RuntimeError("TrainEngine needs the model on a GPU (model.cuda())")
+        self.flat_grad = torch.zeros_like(flat)
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+        self.state = torch.zeros(8, dtype=torch.float32, device=flat.device)
+        self.adam_ws = torch.zeros(int(L.load().msau_adam_ws_floats(flat.numel())), dtype=torch.float32, device=flat.device)
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self.use_graph = use_graph
+        self._graphs = {}
+        self._static = {}
+
+    # -- pieces (each is a fixed launch sequence on the current stream) --
+    def _fwd_bwd(self, plan: Plan, x, labels):
+        plan.forward(self.model._flat, x, export=False)
+        loss = plan.loss_grads(labels)
+        plan.backward(self.flat_grad)
+        return loss
+
+    def _optim(self):
+        b1, b2 = self.betas
+        n = self.model._flat.numel()
+        L.call("msau_clip_adam_step", torch.cuda.current_stream().cuda_stream, self.model._flat.data_ptr(),
+               self.flat_grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.state.data_ptr(),
+               self.adam_ws.data_ptr(), n, self.lr, b1, b2, self.eps, self.max_norm, 1.0 / self.world)
+
+    def _allreduce(self):
+        if self.world > 1:
+            torch.distributed.all_reduce(self.flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+
+    def step(self, x: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        """One optimisation step.  Returns the (local) loss as a 1-element device tensor (no host sync)."""
+        x = x.contiguous().float()
+        labels = labels.reshape(x.shape[0], x.shape[2], x.shape[3]).contiguous().long()
+        plan = self.model._plan_for(x, training=True)
+        if not self.use_graph:
+            loss = self._fwd_bwd(plan, x, labels)
+            self._allreduce()
+            self._optim()
+            return loss
+        key = (x.shape[0], x.shape[2], x.shape[3])
+        if key not in self._graphs:
+            sx, sl = x.clone(), labels.clone()
+            # warm up outside capture (hipFuncSetAttribute, lazy allocations)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._fwd_bwd(plan, sx, sl)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                loss = self._fwd_bwd(plan, sx, sl)
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                self._optim()
+            self._graphs[key] = (g1, g2, loss)
+            self._static[key] = (sx, sl)
+        g1, g2, loss = self._graphs[key]
+        sx, sl = self._static[key]
+        sx.copy_(x, non_blocking=True)
+        sl.copy_(labels, non_blocking=True)
+        g1.replay()
+        self._allreduce()
+        g2.replay()
+        return loss
+
+    @property
+    def grad_norm(self) -> torch.Tensor:
+        return self.state[1]

@@ -1,0 +1,624 @@
+"""Static execution plan of the MSAU forward / backward for one (batch, H, W) shape.
+
+The plan is the MI355X-side counterpart of the reference's module graph
+(model/model.py:129-164 encoder, :224-259 decoder, :328-344 stage, :378-396 net): it is built once
+per shape, owns every activation / gradient buffer (NHWC, padded to 8 channels, fp32 or bf16
+storage), and is a flat list of kernel launches through the C ABI of libmsau_hip.so.  Because the
+launch sequence and all pointers are static it can be captured into a HIP graph and replayed.
+
+Gradient bookkeeping: every activation knows how many consumers contribute to its gradient.
+Contributions run in reverse forward order; the first one to run writes, later ones accumulate
+(MSAU_CONV_ACCUM) and the last one multiplies by the ReLU mask of the activation's producer
+(MSAU_CONV_MASK_B), so that a gradient buffer always ends up holding dL/d(pre-activation).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+def same_pads(in_size: int, k: int, stride: int = 1, dilation: int = 1) -> Tuple[int, int]:
+    """TF "SAME" padding (before, after) -- host restatement of model/layers/utils.py:5-28."""
+    k_eff = k + (k - 1) * (dilation - 1)
+    out = -(-in_size // stride)
+    pad = max((out - 1) * stride + k_eff - in_size, 0)
+    return pad // 2, pad - pad // 2
+
+
+def _ru(a: int, b: int) -> int:
+    return -(-a // b) * b
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class Act:
+    """An activation tensor [B,H,W,Cs] (+ its gradient buffer)."""
+
+    def __init__(self, plan: "Plan", name: str, H: int, W: int, C: int, relu_out: bool = False,
+                 needs_grad: bool = True):
+        self.plan, self.name, self.H, self.W, self.C = plan, name, H, W, C
+        self.Cs = _ru(C, 8)
+        self.relu_out = relu_out
+        self.needs_grad = needs_grad and plan.training
+        self.data = torch.zeros((plan.B, H, W, self.Cs), dtype=plan.tdtype, device=plan.device)
+        self.grad: Optional[torch.Tensor] = None
+        self.n_contrib = 0
+        plan.acts.append(self)
+
+    @property
+    def npix(self) -> int:
+        return self.plan.B * self.H * self.W
+
+    def register(self) -> int:
+        k = self.n_contrib
+        self.n_contrib += 1
+        return k
+
+    def slot_flags(self, k: int) -> Tuple[bool, bool]:
+        """(accumulate, apply producer's ReLU mask) for contribution k (forward-order index)."""
+        return k != self.n_contrib - 1, (k == 0 and self.relu_out)
+
+    def alloc_grad(self):
+        if self.needs_grad and self.n_contrib > 0 and self.grad is None:
+            self.grad = torch.zeros_like(self.data)
+
+
+class Op:
+    name = "op"
+
+    def finalize(self):
+        pass
+
+    def fwd(self, s):
+        raise NotImplementedError
+
+    def bwd(self, s):
+        pass
+
+
+class ConvOp(Op):
+    """SAME conv (3x3 / dilated / 1x1 / 4x4; layers.py:82-102,152-164) or transposed conv
+    (layers.py:249-250), with the concat of its two sources, input ReLU, bias, residual add and
+    output ReLU fused."""
+
+    def __init__(self, plan: "Plan", name: str, x1: Act, x2: Optional[Act], wname: str, bname: str, out: Act,
+                 k: int, dil: int = 1, relu_in: bool = False, relu_out: bool = False,
+                 fwd_add: Optional[Act] = None, kind: str = "conv"):
+        self.plan, self.name, self.x1, self.x2, self.out = plan, name, x1, x2, out
+        self.wname, self.bname, self.k, self.dil, self.kind = wname, bname, k, dil, kind
+        self.relu_in, self.relu_out, self.fwd_add = relu_in, relu_out, fwd_add
+        self.bwd_add: Optional[Act] = None
+        assert out.relu_out == relu_out
+        if kind == "conv":
+            assert out.H == x1.H and out.W == x1.W
+            self.pad_t = same_pads(x1.H, k, 1, dil)[0]
+            self.pad_l = same_pads(x1.W, k, 1, dil)[0]
+        else:
+            assert x2 is None and dil == 1 and not relu_in
+            p = k // 2
+            for o, i in ((out.H, x1.H), (out.W, x1.W)):
+                op = o - ((i - 1) * 2 - 2 * p + k)
+                assert 0 <= op < 2, f"{name}: output size {o} unreachable from {i}"
+            self.pad_t = self.pad_l = k - 1 - p
+        self.slots = []
+        for x in (x1, x2):
+            self.slots.append(x.register() if (x is not None and x.needs_grad) else None)
+        plan.ops.append(self)
+
+    # ---- helpers -------------------------------------------------------------------------
+    def _geom(self, C1, C2, Cout, dil, stride, ups):
+        g = L.ConvPackGeom()
+        L.call("msau_conv_pack_geometry", self.plan.dtype, C1, C2, Cout, self.k, self.k, dil, stride, ups, C.byref(g))
+        return g
+
+    def _pack_entry(self, g, off, row_is_dim0, flip, row_off, rows_real, k1, k2):
+        shp = self.plan.pshape[self.wname]
+        e = L.PackEntry()
+        e.src_off = self.plan.poff[self.wname]
+        e.dst_off = off
+        e.kind, e.dim0, e.dim1, e.KH, e.KW = 0, shp[0], shp[1], self.k, self.k
+        e.row_is_dim0, e.flip, e.row_off, e.rows_real, e.rows_pad = int(row_is_dim0), int(flip), row_off, rows_real, g.rows
+        e.k1_real, e.k1_store = k1
+        e.k2_real, e.k2_store = k2
+        e.cch, e.nchunks, e.kchunk, e.dtype = g.cch, g.nchunks, g.kchunk, self.plan.dtype
+        return e, g.nchunks * g.rows * g.kchunk
+
+    def finalize(self):
+        P = self.plan
+        x1, x2, out = self.x1, self.x2, self.out
+        C2s = x2.Cs if x2 is not None else 0
+        C2r = x2.C if x2 is not None else 0
+        conv = self.kind == "conv"
+        # ---- forward image + bias
+        g = self._geom(x1.Cs, C2s, out.Cs, self.dil, 1, 1 if conv else 2)
+        self.w_off = P.alloc_pack(g.bytes)
+        e, n = self._pack_entry(g, self.w_off, row_is_dim0=conv, flip=not conv, row_off=0, rows_real=out.C,
+                                k1=(x1.C, x1.Cs), k2=(C2r, C2s))
+        P.add_pack_entry(e, n)
+        self.b_off = P.alloc_pack(out.Cs * 4)
+        be = L.PackEntry()
+        be.src_off, be.dst_off, be.kind = P.poff[self.bname], self.b_off, 1
+        be.row_off, be.rows_real, be.rows_pad = 0, out.C, out.Cs
+        P.add_pack_entry(be, out.Cs)
+        # ---- data-gradient images
+        self.d_off = [None, None]
+        if P.training:
+            for si, x in enumerate((x1, x2)):
+                if x is None or self.slots[si] is None:
+                    continue
+                if conv:
+                    gd = self._geom(out.Cs, 0, x.Cs, self.dil, 1, 1)
+                    self.d_off[si] = P.alloc_pack(gd.bytes)
+                    e, n = self._pack_entry(gd, self.d_off[si], row_is_dim0=False, flip=True,
+                                            row_off=(0 if si == 0 else x1.C), rows_real=x.C,
+                                            k1=(out.C, out.Cs), k2=(0, 0))
+                else:
+                    gd = self._geom(out.Cs, 0, x.Cs, 1, 2, 1)
+                    self.d_off[si] = P.alloc_pack(gd.bytes)
+                    e, n = self._pack_entry(gd, self.d_off[si], row_is_dim0=True, flip=False, row_off=0,
+                                            rows_real=x.C, k1=(out.C, out.Cs), k2=(0, 0))
+                P.add_pack_entry(e, n)
+
+    def bind(self):
+        """Create the launch descriptors (all buffers exist now)."""
+        P = self.plan
+        x1, x2, out = self.x1, self.x2, self.out
+        conv = self.kind == "conv"
+        d = L.ConvDesc()
+        d.B, d.Hin, d.Win, d.Hout, d.Wout = P.B, x1.H, x1.W, out.H, out.W
+        d.C1, d.C2, d.Cout = x1.Cs, (x2.Cs if x2 is not None else 0), out.Cs
+        d.KH = d.KW = self.k
+        d.dil, d.pad_t, d.pad_l, d.stride, d.ups = self.dil, self.pad_t, self.pad_l, 1, (1 if conv else 2)
+        d.flags = (L.CONV_RELU_IN if self.relu_in else 0) | (L.CONV_RELU_OUT if self.relu_out else 0) | \
+                  (L.CONV_ADD if self.fwd_add is not None else 0)
+        d.x1, d.x2 = _ptr(x1.data), _ptr(x2.data if x2 is not None else None)
+        d.wpack, d.bias = P.pack_ptr(self.w_off), P.pack_ptr(self.b_off)
+        d.add = _ptr(self.fwd_add.data) if self.fwd_add is not None else None
+        d.y = _ptr(out.data)
+        self.fdesc = d
+        self.ddesc = [None, None]
+        self.wdesc = None
+        if not P.training or out.grad is None:
+            return
+        for si, x in enumerate((x1, x2)):
+            if x is None or self.slots[si] is None:
+                continue
+            accum, maskb = x.slot_flags(self.slots[si])
+            dd = L.ConvDesc()
+            dd.B = P.B
+            dd.Hin, dd.Win, dd.Hout, dd.Wout = out.H, out.W, x.H, x.W
+            dd.C1, dd.C2, dd.Cout = out.Cs, 0, x.Cs
+            dd.KH = dd.KW = self.k
+            if conv:
+                dd.dil, dd.stride, dd.ups = self.dil, 1, 1
+                dd.pad_t = (self.k - 1) * self.dil - self.pad_t
+                dd.pad_l = (self.k - 1) * self.dil - self.pad_l
+            else:
+                dd.dil, dd.stride, dd.ups = 1, 2, 1
+                dd.pad_t = dd.pad_l = self.k // 2
+            fl = 0
+            if self.relu_in:
+                fl |= L.CONV_MASK_A
+                dd.mask_a = _ptr(x.data)
+            if si == 0 and self.bwd_add is not None:
+                fl |= L.CONV_ADD
+                dd.add = _ptr(self.bwd_add.grad)
+            if accum:
+                fl |= L.CONV_ACCUM
+            if maskb:
+                fl |= L.CONV_MASK_B
+                dd.mask_b = _ptr(x.data)
+            dd.flags = fl
+            dd.x1, dd.wpack, dd.bias, dd.y = _ptr(out.grad), P.pack_ptr(self.d_off[si]), None, _ptr(x.grad)
+            self.ddesc[si] = dd
+        # ---- weight gradient
+        w = L.WgradDesc()
+        w.B = P.B
+        w.KH = w.KW = self.k
+        if conv:
+            w.Hin, w.Win, w.Hout, w.Wout = x1.H, x1.W, out.H, out.W
+            w.C1, w.C2, w.Cout = x1.Cs, (x2.Cs if x2 is not None else 0), out.Cs
+            w.dil, w.pad_t, w.pad_l, w.stride = self.dil, self.pad_t, self.pad_l, 1
+            w.flags = L.CONV_RELU_IN if self.relu_in else 0
+            w.x1, w.x2, w.g = _ptr(x1.data), _ptr(x2.data if x2 is not None else None), _ptr(out.grad)
+            rows_real, k1, k2 = out.C, (x1.C, x1.Cs), ((x2.C, x2.Cs) if x2 is not None else (0, 0))
+        else:
+            # transposed conv: dWt[ci][co][ky][kx] = sum x[iy,ix,ci] * dy[2iy-1+ky, 2ix-1+kx, co]
+            # = the wgrad of the stride-2 conv that maps dy -> dx, i.e. roles swapped.
+            w.Hin, w.Win, w.Hout, w.Wout = out.H, out.W, x1.H, x1.W
+            w.C1, w.C2, w.Cout = out.Cs, 0, x1.Cs
+            w.dil, w.pad_t, w.pad_l, w.stride = 1, self.k // 2, self.k // 2, 2
+            w.flags = 0
+            w.x1, w.x2, w.g = _ptr(out.grad), None, _ptr(x1.data)
+            rows_real, k1, k2 = x1.C, (out.C, out.Cs), (0, 0)
+        wg = L.WgradGeom()
+        w.nslabs = 1
+        L.call("msau_wgrad_geometry", P.dtype, C.byref(w), C.byref(wg))
+        nslabs = max(1, min(wg.max_slabs, 512, (32 << 20) // max(wg.slab_bytes, 1)))
+        w.nslabs = nslabs
+        slab_elems = wg.slab_bytes // 4
+        self.slab_off = P.alloc_slab(nslabs * slab_elems)
+        self.wdesc, self.wgeom = w, wg
+        shp = P.pshape[self.wname]
+        taps = self.k * self.k
+        u = L.UnpackEntry()
+        u.slab_off, u.w_off, u.b_off = self.slab_off, P.poff[self.wname], P.poff[self.bname]
+        u.nslabs, u.slab_elems, u.kext = nslabs, slab_elems, wg.kext
+        u.dim0, u.dim1, u.KH, u.KW, u.row_is_dim0, u.rows_real = shp[0], shp[1], self.k, self.k, 1, rows_real
+        u.k1_real, u.k1_store = k1
+        u.k2_real, u.k2_store = k2
+        u.cch, u.nchunks, u.accumulate = wg.cch, wg.nchunks, 0
+        if conv:
+            u.b_src_off, u.b_slab_stride, u.b_elem_stride, u.b_nslabs = self.slab_off + taps * wg.cch, slab_elems, wg.kext, nslabs
+        else:
+            self.csum_blocks = max(1, min(256, out.npix // 1024))
+            self.csum_off = P.alloc_slab(self.csum_blocks * out.Cs)
+            u.b_src_off, u.b_slab_stride, u.b_elem_stride, u.b_nslabs = self.csum_off, out.Cs, 1, self.csum_blocks
+        P.add_unpack_entry(u, rows_real * wg.nchunks * taps * wg.cch)
+
+    def late_bind(self):
+        P = self.plan
+        if self.wdesc is not None:
+            self.wdesc.slabs = P.slab_ptr(self.slab_off)
+
+    def fwd(self, s):
+        L.call("msau_conv2d", s, self.plan.dtype, C.byref(self.fdesc))
+
+    def bwd(self, s):
+        if self.wdesc is None:
+            return
+        P = self.plan
+        L.call("msau_conv2d_wgrad", s, P.dtype, C.byref(self.wdesc))
+        if self.kind != "conv":
+            L.call("msau_channel_sum", s, P.dtype, _ptr(self.out.grad), self.out.npix, self.out.Cs,
+                   P.slab_ptr(self.csum_off), self.csum_blocks)
+        for dd in self.ddesc:
+            if dd is not None:
+                L.call("msau_conv2d", s, P.dtype, C.byref(dd))
+
+
+class LrnOp(Op):
+    """LocalResponseNorm(size=C) after the dilated conv: layers.py:145,161-162."""
+
+    def __init__(self, plan, name, a: Act, y: Act):
+        self.plan, self.name, self.a, self.y = plan, name, a, y
+        self.slot = a.register() if a.needs_grad else None
+        plan.ops.append(self)
+
+    def fwd(self, s):
+        a, y = self.a, self.y
+        L.call("msau_lrn_fwd", s, self.plan.dtype, _ptr(a.data), _ptr(y.data), a.npix, a.C, a.Cs, a.C, 1e-4, 0.75, 1.0)
+
+    def bwd(self, s):
+        a, y = self.a, self.y
+        if y.grad is None or a.grad is None:
+            return
+        assert a.n_contrib == 1 and not a.relu_out
+        L.call("msau_lrn_bwd", s, self.plan.dtype, _ptr(a.data), _ptr(y.grad), _ptr(a.grad), a.npix, a.C, a.Cs, a.C,
+               1e-4, 0.75, 1.0)
+
+
+class PoolOp(Op):
+    """zero SAME pad + MaxPool2d(2,2): model/model.py:158-160."""
+
+    def __init__(self, plan, name, x: Act, y: Act):
+        self.plan, self.name, self.x, self.y = plan, name, x, y
+        assert y.H == (x.H + 1) // 2 and y.W == (x.W + 1) // 2 and y.Cs == x.Cs
+        self.idx = torch.zeros((plan.B, y.H, y.W, y.Cs), dtype=torch.uint8, device=plan.device)
+        self.slot = x.register() if x.needs_grad else None
+        plan.ops.append(self)
+
+    def fwd(self, s):
+        x, y = self.x, self.y
+        L.call("msau_maxpool2x2_fwd", s, self.plan.dtype, _ptr(x.data), _ptr(y.data), _ptr(self.idx), self.plan.B, x.H, x.W, x.Cs)
+
+    def bwd(self, s):
+        x, y = self.x, self.y
+        if y.grad is None or x.grad is None:
+            return
+        accum, maskb = x.slot_flags(self.slot)
+        L.call("msau_maxpool2x2_bwd", s, self.plan.dtype, _ptr(y.grad), _ptr(self.idx), _ptr(x.grad),
+               _ptr(x.data) if maskb else None, self.plan.B, x.H, x.W, x.Cs, int(accum))
+
+
+class AttnCoreOp(Op):
+    """y = x + h . softmax_rows(g^T f): model/layers/attention.py:156-162 (f, g, h are ConvOps)."""
+
+    def __init__(self, plan, name, f: Act, g: Act, h: Act, x: Act, y: Act):
+        self.plan, self.name, self.f, self.g, self.h, self.x, self.y = plan, name, f, g, h, x, y
+        self.N = x.H * x.W
+        self.stats = torch.zeros((plan.B, self.N, 2), dtype=torch.float32, device=plan.device)
+        self.ws = torch.zeros((plan.B, self.N), dtype=torch.float32, device=plan.device)
+        for t in (f, g, h):
+            t.register()
+        # the residual path (dx += dy) is folded into the h-projection's data gradient (ConvOp.bwd_add)
+        plan.ops.append(self)
+
+    def fwd(self, s):
+        L.call("msau_selfattn_fwd", s, self.plan.dtype, _ptr(self.f.data), _ptr(self.g.data), _ptr(self.h.data),
+               _ptr(self.x.data), _ptr(self.y.data), _ptr(self.stats), self.plan.B, self.N, self.f.Cs, self.h.Cs)
+
+    def bwd(self, s):
+        if self.y.grad is None:
+            return
+        L.call("msau_selfattn_bwd", s, self.plan.dtype, _ptr(self.f.data), _ptr(self.g.data), _ptr(self.h.data),
+               _ptr(self.y.grad), _ptr(self.stats), _ptr(self.f.grad), _ptr(self.g.grad), _ptr(self.h.grad),
+               _ptr(self.ws), self.plan.B, self.N, self.f.Cs, self.h.Cs)
+
+
+class Plan:
+    def __init__(self, cfg: dict, B: int, H: int, W: int, dtype: int, device, poff: Dict[str, int],
+                 pshape: Dict[str, Tuple[int, ...]], training: bool = True, builder=None):
+        self.cfg, self.B, self.H, self.W, self.dtype, self.device = cfg, B, H, W, dtype, device
+        self.tdtype = torch.float32 if dtype == L.F32 else torch.bfloat16
+        self.poff, self.pshape, self.training = poff, pshape, training
+        self.acts: List[Act] = []
+        self.ops: List[Op] = []
+        self._pack_bytes = 0
+        self._slab_elems = 0
+        self._pack_entries: List[L.PackEntry] = []
+        self._unpack_entries: List[L.UnpackEntry] = []
+        self._pack_max = 1
+        self._unpack_max = 1
+        self.x_in = Act(self, "input", H, W, cfg["channels"], needs_grad=bool(cfg.get("input_grad", False)))
+        self.logits: Optional[Act] = None
+        self.aux: Optional[Act] = None
+        if builder is None:
+            self._build_net()
+        else:
+            builder(self)               # custom graph (op-level tests): must set self.logits (and maybe self.aux)
+        self._finish()
+
+    # ---- arenas -----------------------------------------------------------------------------
+    def alloc_pack(self, nbytes: int) -> int:
+        off = self._pack_bytes
+        self._pack_bytes += _ru(int(nbytes), 256)
+        return off
+
+    def alloc_slab(self, nelems: int) -> int:
+        off = self._slab_elems
+        self._slab_elems += _ru(int(nelems), 64)
+        return off
+
+    def add_pack_entry(self, e, nelems):
+        self._pack_entries.append(e)
+        self._pack_max = max(self._pack_max, int(nelems))
+
+    def add_unpack_entry(self, e, nelems):
+        self._unpack_entries.append(e)
+        self._unpack_max = max(self._unpack_max, int(nelems))
+
+    def pack_ptr(self, off: int) -> int:
+        return self.pack_arena.data_ptr() + off
+
+    def slab_ptr(self, off: int) -> int:
+        return self.slab_arena.data_ptr() + 4 * off
+
+    # ---- graph construction -------------------------------------------------------------------
+    def _res_block(self, x0: Act, prefix: str, tag: str) -> Act:
+        """MultiConvResidualBlock: model/model.py:37-50."""
+        R, k = self.cfg["res_depth"], self.cfg["filter_size"]
+        r_in, first = x0, None
+        for i in range(R):
+            o = Act(self, f"{tag}.res{i}", x0.H, x0.W, x0.C, relu_out=True)
+            op = ConvOp(self, f"{tag}.res{i}", r_in, None, f"{prefix}.conv_res_list.{i}.custom_conv.weight",
+                        f"{prefix}.conv_res_list.{i}.custom_conv.bias", o, k, relu_in=(i == 0), relu_out=True,
+                        fwd_add=(x0 if i == R - 1 else None))
+            first = first or op
+            r_in = o
+        first.bwd_add = r_in                    # d(x0) += g(block output): the in-place residual add
+        return r_in
+
+    def _build_net(self):
+        cfg = self.cfg
+        S, Fr, k, nb = cfg["scale_space_num"], cfg["featRoot"], cfg["filter_size"], cfg.get("num_blocks", 3)
+        ncls = cfg["n_class"]
+        assert cfg["pool_size"] == 2
+        inp = self.x_in
+        prev_dw = prev_up = None
+        self.stage_logits: List[Act] = []
+        for b in range(nb):
+            coupled, last = b > 0, b == nb - 1
+            pd = f"msau_net.blocks.{b}.downsamplingblock"
+            pu = f"msau_net.blocks.{b}.upsamplingblock"
+            dw: Dict[int, Act] = {}
+            x_in = inp
+            x2 = None
+            for l in range(S):                                            # model.py:136-162
+                c = Fr * 2 ** l
+                t = f"s{b}.d{l}"
+                a = Act(self, t + ".a", x_in.H, x_in.W, c)
+                ConvOp(self, t + ".dil", x_in, None, f"{pd}.conv1s.{l}.conv.weight", f"{pd}.conv1s.{l}.conv.bias", a, k,
+                       dil=2 ** l)
+                x0 = Act(self, t + ".lrn", a.H, a.W, c)
+                LrnOp(self, t + ".lrn", a, x0)
+                x1 = self._res_block(x0, f"{pd}.conv_res_list.{l}", t)
+                if coupled:                                               # model.py:143-148
+                    x2 = Act(self, t + ".cpl", a.H, a.W, c, relu_out=True)
+                    ConvOp(self, t + ".cpl", prev_dw[l], x1, f"{pd}.conv1_1s.{l}.custom_conv.weight",
+                           f"{pd}.conv1_1s.{l}.custom_conv.bias", x2, 1, relu_out=True)
+                else:
+                    x2 = x1
+                if l == S - 1 and not last:                               # model.py:149-150 (dead in the last stage)
+                    pa = f"{pd}.layer_attentions.attention_block"
+                    fa = Act(self, t + ".f", a.H, a.W, c // 8)
+                    ga = Act(self, t + ".g", a.H, a.W, c // 8)
+                    ha = Act(self, t + ".h", a.H, a.W, c)
+                    ConvOp(self, t + ".f", x2, None, f"{pa}.f.conv.weight", f"{pa}.f.conv.bias", fa, 1)
+                    ConvOp(self, t + ".g", x2, None, f"{pa}.g.conv.weight", f"{pa}.g.conv.bias", ga, 1)
+                    hop = ConvOp(self, t + ".h", x2, None, f"{pa}.h.conv.weight", f"{pa}.h.conv.bias", ha, 1)
+                    y = Act(self, t + ".attn", a.H, a.W, c)
+                    AttnCoreOp(self, t + ".attn", fa, ga, ha, x2, y)
+                    hop.bwd_add = y
+                    dw[l] = y
+                else:
+                    dw[l] = x2
+                if l < S - 1:                                             # model.py:158-160
+                    pooled = Act(self, t + ".pool", (x2.H + 1) // 2, (x2.W + 1) // 2, c, relu_out=False)
+                    PoolOp(self, t + ".pool", x2, pooled)
+                    x_in = pooled
+            cur = x2                                                      # pre-attention tensor: model.py:162-164
+            up: Dict[int, Act] = {}
+            for l in range(S - 2, -1, -1):                                # model.py:226-254
+                c = Fr * 2 ** l
+                t = f"s{b}.u{l}"
+                skip = dw[l]
+                d = Act(self, t + ".deconv", skip.H, skip.W, c)
+                ConvOp(self, t + ".deconv", cur, None, f"{pu}.deconvs.{l}.conv.weight", f"{pu}.deconvs.{l}.conv.bias", d, k,
+                       kind="deconv")
+                xm = Act(self, t + ".merge", skip.H, skip.W, c)
+                ConvOp(self, t + ".merge", skip, d, f"{pu}.conv1s.{l}.custom_conv.weight",
+                       f"{pu}.conv1s.{l}.custom_conv.bias", xm, k)
+                x1 = self._res_block(xm, f"{pu}.conv_res_list.{l}", t)
+                if coupled:
+                    x2 = Act(self, t + ".cpl", skip.H, skip.W, c, relu_out=True)
+                    ConvOp(self, t + ".cpl", prev_up[l], x1, f"{pu}.conv1_1s.{l}.custom_conv.weight",
+                           f"{pu}.conv1_1s.{l}.custom_conv.bias", x2, 1, relu_out=True)
+                else:
+                    x2 = x1
+                up[l] = x2
+                cur = x2
+            logits = Act(self, f"s{b}.logits", self.H, self.W, ncls)
+            ConvOp(self, f"s{b}.end", cur, None, f"msau_net.end_convs.{b}.custom_conv.weight",
+                   f"msau_net.end_convs.{b}.custom_conv.bias", logits, 4)          # model.py:390, 375-376
+            self.stage_logits.append(logits)
+            inp, prev_dw, prev_up = logits, dw, up
+        self.logits = self.stage_logits[-1]
+        self.aux = self.stage_logits[-2] if nb >= 2 else None              # model.py:392-393
+
+    def _finish(self):
+        # external gradient (loss) contributions come last in forward order -> first in backward
+        self.ext_slot = {}
+        if self.training:
+            for t in (self.logits, self.aux):
+                if t is not None:
+                    self.ext_slot[t.name] = t.register()
+        # ---- allocate gradients, pack images, descriptors
+        for a in self.acts:
+            a.alloc_grad()
+        for op in self.ops:
+            op.finalize()
+        self.pack_arena = torch.zeros(max(self._pack_bytes, 256), dtype=torch.uint8, device=self.device)
+        for op in self.ops:
+            if isinstance(op, ConvOp):
+                op.bind()
+        self.slab_arena = torch.zeros(max(self._slab_elems, 64), dtype=torch.float32, device=self.device)
+        for op in self.ops:
+            if isinstance(op, ConvOp):
+                op.late_bind()
+        self.pack_table = self._upload(self._pack_entries, L.PackEntry) if self._pack_entries else None
+        self.unpack_table = self._upload(self._unpack_entries, L.UnpackEntry) if self._unpack_entries else None
+        HW = self.H * self.W
+        lg = self.logits
+        self.out_logits = torch.zeros((self.B, lg.C, lg.H, lg.W), dtype=torch.float32, device=self.device)
+        self.out_aux = torch.zeros((self.B, self.aux.C, self.aux.H, self.aux.W), dtype=torch.float32,
+                                   device=self.device) if self.aux is not None else None
+        if self.training:
+            self.counts = torch.zeros((self.B,), dtype=torch.int32, device=self.device)
+            self.ce_ws = torch.zeros((int(L.load().msau_ce_ws_floats(self.B * HW)),), dtype=torch.float32, device=self.device)
+            self.loss_buf = torch.zeros((1,), dtype=torch.float32, device=self.device)
+
+    def _upload(self, entries, ctype):
+        n = len(entries)
+        arr = (ctype * n)(*entries)
+        raw = bytes(memoryview(arr))
+        host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        return host.to(self.device)
+
+    # ---- execution ----------------------------------------------------------------------------
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    def pack(self, flat_params: torch.Tensor):
+        if self.pack_table is None:
+            return
+        L.call("msau_pack_params", self._stream(), flat_params.data_ptr(), self.pack_arena.data_ptr(),
+               self.pack_table.data_ptr(), len(self._pack_entries), self._pack_max)
+
+    def load_input(self, x_nchw: torch.Tensor):
+        assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and tuple(x_nchw.shape) == \
+            (self.B, self.cfg["channels"], self.H, self.W), (x_nchw.shape, x_nchw.dtype)
+        a = self.x_in
+        L.call("msau_nchw_to_nhwc", self._stream(), self.dtype, x_nchw.data_ptr(), a.data.data_ptr(), self.B, a.C, a.Cs, self.H, self.W)
+
+    def forward(self, flat_params: torch.Tensor, x_nchw: torch.Tensor, export: bool = True):
+        s = self._stream()
+        self.pack(flat_params)
+        self.load_input(x_nchw)
+        for op in self.ops:
+            op.fwd(s)
+        if export:
+            self.export_logits()
+        return self.out_logits, self.out_aux
+
+    def export_logits(self):
+        s = self._stream()
+        for act, dst in ((self.logits, self.out_logits), (self.aux, self.out_aux)):
+            if act is not None:
+                L.call("msau_nhwc_to_nchw", s, self.dtype, act.data.data_ptr(), dst.data_ptr(), self.B, act.C, act.Cs, act.H, act.W)
+
+    def set_external_grads(self, g_logits: Optional[torch.Tensor], g_aux: Optional[torch.Tensor]):
+        """Gradients w.r.t. the NCHW fp32 outputs (the autograd path)."""
+        s = self._stream()
+        for act, g in ((self.logits, g_logits), (self.aux, g_aux)):
+            if act is None:
+                continue
+            accum, maskb = act.slot_flags(self.ext_slot[act.name])
+            assert not accum
+            if g is None:
+                act.grad.zero_()
+            else:
+                g = g.contiguous().float()
+                L.call("msau_nchw_grad_to_nhwc", s, self.dtype, g.data_ptr(), act.grad.data_ptr(), self.B, act.C, act.Cs,
+                       act.H, act.W, 0)
+                if maskb:       # output produced through a ReLU and consumed by nothing else (op-level tests only)
+                    act.grad.mul_(act.data > 0)
+
+    def loss_grads(self, labels: torch.Tensor) -> torch.Tensor:
+        """Masked CE (model/model.py:446-459, batch rule SURVEY 8e) fused with its gradient:
+        writes d(logits), d(aux) in place and returns the loss as a 1-element device tensor."""
+        assert labels.dtype == torch.int64 and labels.is_contiguous() and tuple(labels.shape) == (self.B, self.H, self.W)
+        s = self._stream()
+        HW = self.H * self.W
+        L.call("msau_label_counts", s, labels.data_ptr(), self.counts.data_ptr(), self.B, HW)
+        self.loss_buf.zero_()
+        for act in (self.logits, self.aux):
+            if act is None:
+                continue
+            L.call("msau_masked_ce", s, self.dtype, act.data.data_ptr(), labels.data_ptr(), self.counts.data_ptr(),
+                   act.grad.data_ptr(), self.loss_buf.data_ptr(), self.ce_ws.data_ptr(), self.B, HW, act.C, act.Cs,
+                   1.0 / self.B)
+        return self.loss_buf
+
+    def backward(self, flat_grads: torch.Tensor):
+        """Run the backward sweep (external gradients must already be in place) and write the
+        flat fp32 parameter gradient."""
+        s = self._stream()
+        for op in reversed(self.ops):
+            op.bwd(s)
+        if self.unpack_table is not None:
+            L.call("msau_wgrad_reduce", s, self.slab_arena.data_ptr(), flat_grads.data_ptr(), self.unpack_table.data_ptr(),
+                   len(self._unpack_entries), self._unpack_max)
+
+    def input_grad_nchw(self) -> torch.Tensor:
+        """d(loss)/d(input) as NCHW fp32 (only with cfg['input_grad'], used by the op-level tests)."""
+        a = self.x_in
+        out = torch.empty((self.B, a.C, a.H, a.W), dtype=torch.float32, device=self.device)
+        L.call("msau_nhwc_to_nchw", self._stream(), self.dtype, a.grad.data_ptr(), out.data_ptr(), self.B, a.C, a.Cs, a.H, a.W)
+        return out
+
+    def activation_bytes(self) -> int:
+        n = 0
+        for a in self.acts:
+            n += a.data.numel() * a.data.element_size()
+            if a.grad is not None:
+                n += a.grad.numel() * a.grad.element_size()
+        return n

@@ -1,0 +1,126 @@
+"""CPU: host-side logic of the product (no kernels run): the C-ABI library loads and exports every
+symbol include/msau_hip.h declares, parameter naming/shapes mirror the reference, plans for every
+BASELINE configuration fit the LDS / register geometry, SAME-padding arithmetic."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from msau_amd import _lib as L
+from msau_amd.model import MSAUWrapper, param_shapes
+from msau_amd.plan import ConvOp, Plan, same_pads
+from oracle import msau_oracle as O
+from tests.golden_util import NET_CASES, load_net_case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    hdr = open(os.path.join(ROOT, "include", "msau_hip.h")).read()
+    declared = set(re.findall(r"\b(msau_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/msau_hip.h but not exported"
+    assert declared == set(L.EXPORTED_SYMBOLS), declared ^ set(L.EXPORTED_SYMBOLS)
+    assert lib.msau_version() >= 1
+
+
+def test_error_reporting_across_the_abi():
+    g = L.ConvPackGeom()
+    import ctypes as C
+    rc = L.load().msau_conv_pack_geometry(L.F32, 7, 0, 8, 3, 3, 1, 1, 1, C.byref(g))
+    assert rc == -1 and b"multiples of 8" in L.load().msau_last_error() or b"channels" in L.load().msau_last_error()
+    with pytest.raises(L.MsauHipError):
+        L.call("msau_conv_pack_geometry", 5, 8, 0, 8, 3, 3, 1, 1, 1, C.byref(g))
+
+
+def test_same_pads_matches_reference_pad_2d():
+    assert same_pads(9, 4) == (1, 2) and same_pads(336, 4) == (1, 2)
+    assert same_pads(42, 3, 1, 8) == (8, 8)
+    assert same_pads(7, 2, 2) == (0, 1) and same_pads(8, 2, 2) == (0, 0)
+    for n in range(1, 40):
+        for k, d in ((3, 1), (3, 2), (3, 8), (4, 1), (1, 1)):
+            assert same_pads(n, k, 1, d) == O.same_pads(n, k, 1, d)
+
+
+@pytest.mark.parametrize("cfg", [dict(O.DEFAULT_CFG), dict(O.DEFAULT_CFG, channels=768, num_blocks=2),
+                                 dict(O.DEFAULT_CFG, channels=32, num_blocks=1),
+                                 dict(O.DEFAULT_CFG, channels=13, featRoot=4, res_depth=3, scale_space_num=3)])
+def test_param_shapes_match_oracle_and_reference_order(cfg):
+    assert list(param_shapes(cfg).items()) == list(O.param_shapes(cfg).items())
+
+
+def test_state_dict_keys_are_the_references():
+    g, cfg, sd, x, label = load_net_case("net_f8_c13_33x26")
+    m = MSAUWrapper(13, 5, dict(scale_space_num=4, res_depth=2, featRoot=8, final_act="softmax"))
+    keys = list(m.state_dict().keys())
+    assert keys == [str(s) for s in g["param_names"]]          # names + order recorded from the reference
+    assert sum(p.numel() for p in m.parameters()) == sum(v.numel() for v in sd.values())
+    m.load_state_dict(sd)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k])
+    # parameters are views of one flat fp32 buffer
+    assert all(p.data_ptr() >= m.flat_parameters.data_ptr() for p in m.parameters())
+    n636 = MSAUWrapper(64, 5, dict(scale_space_num=4, res_depth=2, featRoot=8, final_act="softmax"))
+    assert sum(p.numel() for p in n636.parameters()) == 636167 and len(n636.state_dict()) == 196
+
+
+def test_save_load_roundtrip(tmp_path):
+    m = MSAUWrapper(13, 5, dict(scale_space_num=3, res_depth=2, featRoot=8, final_act="softmax", seed=3))
+    m.save(str(tmp_path / "w.pth"))
+    m2 = MSAUWrapper(13, 5, dict(scale_space_num=3, res_depth=2, featRoot=8, final_act="softmax", seed=4))
+    assert not torch.equal(m.flat_parameters, m2.flat_parameters)
+    m2.load_weights(str(tmp_path / "w.pth"))
+    assert torch.equal(m.flat_parameters, m2.flat_parameters)
+
+
+def test_init_statistics_follow_reference_formulae():
+    m = MSAUWrapper(64, 5, dict(scale_space_num=4, res_depth=2, featRoot=8, final_act="softmax", seed=0))
+    sd = m.state_dict()
+    w = sd["msau_net.blocks.0.downsamplingblock.conv_res_list.3.conv_res_list.0.custom_conv.weight"]
+    assert abs(float(w.std()) - np.sqrt(2.0 / (9 * 64 + 64))) < 0.1 * np.sqrt(2.0 / (9 * 64 + 64))
+    b = sd["msau_net.blocks.0.downsamplingblock.conv1s.0.conv.bias"]
+    assert abs(float(b.mean()) - 0.1) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.BF16])
+@pytest.mark.parametrize("case", [
+    dict(channels=32, num_blocks=1, B=2, H=128, W=128),          # BASELINE cfg 1
+    dict(channels=64, num_blocks=3, B=2, H=336, W=256),          # cfg 2 / 3 geometry
+    dict(channels=768, num_blocks=2, B=1, H=336, W=256),         # cfg 4
+    dict(channels=64, num_blocks=3, B=1, H=512, W=384),          # cfg 5 geometry (plain blocks)
+    dict(channels=13, num_blocks=3, B=1, H=33, W=26),
+])
+def test_plans_build_for_baseline_configs(case, dtype):
+    """every conv / wgrad launch of every BASELINE configuration has a tile that fits LDS and registers"""
+    cfg = dict(O.DEFAULT_CFG, channels=case["channels"], num_blocks=case["num_blocks"])
+    shapes = param_shapes(cfg)
+    poff, off = {}, 0
+    for k, s in shapes.items():
+        poff[k] = off
+        off += -(-int(np.prod(s)) // 4) * 4
+    plan = Plan(cfg, case["B"], case["H"], case["W"], dtype, torch.device("cpu"), poff, dict(shapes), training=True)
+    convs = [op for op in plan.ops if isinstance(op, ConvOp)]
+    n_conv = sum(1 for op in convs if op.kind == "conv")
+    n_deconv = sum(1 for op in convs if op.kind == "deconv")
+    if case["num_blocks"] == 3:
+        # 54 + 9 + 23 + 3 convs and 9 deconvs, minus the dead last-stage attention's 3 projections
+        assert n_conv == 54 + 9 + 23 + 3 - 3 and n_deconv == 9
+    for op in convs:
+        assert op.fdesc is not None and (op.wdesc is not None or not plan.training)
+    # the two stage outputs that carry the loss
+    assert plan.logits.C == 5 and (plan.aux is not None) == (case["num_blocks"] >= 2)
+
+
+def test_dead_parameters_are_the_last_stage_attention():
+    m = MSAUWrapper(64, 5, dict(scale_space_num=4, res_depth=2, featRoot=8, final_act="softmax"))
+    assert len(m._dead) == 6 and sum(int(np.prod(m._pshape[k])) for k in m._dead) == 5200
+
+
+def test_compute_without_gpu_raises_not_falls_back():
+    m = MSAUWrapper(13, 5, dict(scale_space_num=3, res_depth=2, featRoot=8, final_act="softmax"))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 13, 16, 16))

@@ -1,0 +1,261 @@
+"""GPU: every HIP kernel, called through the C ABI, against the reference's golden vectors
+(tests/golden/ops.npz) and against the CPU oracle on seeded inputs.  fp32 storage: tolerance 1e-4
+relative to the tensor's max (fp32 MFMA sums in a different order than MKL-DNN); bf16 storage: 3e-2."""
+import numpy as np
+import pytest
+import torch
+
+from msau_amd import _lib as L
+from oracle import msau_oracle as O
+from tests.golden_util import load_ops, rel_err
+from tests.hip_harness import Act, AttnCoreOp, ConvOp, LrnOp, PoolOp, run_graph
+
+pytestmark = pytest.mark.gpu
+
+TOL = {L.F32: 1e-4, L.BF16: 3e-2}
+DT = [pytest.param(L.F32, id="f32"), pytest.param(L.BF16, id="bf16")]
+
+
+def _conv_builder(co, k, relu, dil=1, lrn=False, kind="conv", out_hw=None):
+    def build(plan):
+        x = plan.x_in
+        H, W = out_hw or (x.H, x.W)
+        if lrn:
+            a = Act(plan, "a", H, W, co)
+            ConvOp(plan, "c", x, None, "w", "b", a, k, dil=dil)
+            y = Act(plan, "y", H, W, co)
+            LrnOp(plan, "l", a, y)
+        else:
+            y = Act(plan, "y", H, W, co, relu_out=relu)
+            ConvOp(plan, "c", x, None, "w", "b", y, k, dil=dil, relu_out=relu, kind=kind)
+        plan.logits = y
+    return build
+
+
+def _check(g, tag, y, dx, grads, wkey, bkey, tol):
+    assert rel_err(y, g[f"{tag}.y"]) < tol, "fwd"
+    assert rel_err(dx, g[f"{tag}.gx"]) < tol, "dgrad"
+    assert rel_err(grads["w"], g[f"{tag}.g.{wkey}"]) < tol, "wgrad"
+    assert rel_err(grads["b"], g[f"{tag}.g.{bkey}"]) < tol, "bgrad"
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("tag,k,relu", [("conv3", 3, True), ("conv3lin", 3, False), ("conv1", 1, True),
+                                        ("conv4", 4, False), ("conv3c13", 3, False)])
+def test_conv_golden(tag, k, relu, dtype):
+    g = load_ops()
+    w, b = g[f"{tag}.p.custom_conv.weight"], g[f"{tag}.p.custom_conv.bias"]
+    y, _, dx, grads = run_graph(_conv_builder(w.shape[0], k, relu), {"w": torch.tensor(w), "b": torch.tensor(b)},
+                                g[f"{tag}.x"], g[f"{tag}.gy"], dtype)
+    _check(g, tag, y, dx, grads, "custom_conv.weight", "custom_conv.bias", TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("d", [1, 2, 4, 8])
+def test_dilconv_lrn_golden(d, dtype):
+    g = load_ops(); tag = f"dil{d}"
+    w, b = g[f"{tag}.p.conv.weight"], g[f"{tag}.p.conv.bias"]
+    y, _, dx, grads = run_graph(_conv_builder(w.shape[0], 3, False, dil=d, lrn=True),
+                                {"w": torch.tensor(w), "b": torch.tensor(b)}, g[f"{tag}.x"], g[f"{tag}.gy"], dtype)
+    _check(g, tag, y, dx, grads, "conv.weight", "conv.bias", TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("C", [8, 16, 64])
+def test_lrn_golden(C, dtype):
+    g = load_ops(); tag = f"lrn{C}"
+
+    def build(plan):
+        y = Act(plan, "y", plan.x_in.H, plan.x_in.W, C)
+        LrnOp(plan, "l", plan.x_in, y)
+        plan.logits = y
+    y, _, dx, _ = run_graph(build, {}, g[f"{tag}.x"], g[f"{tag}.gy"], dtype)
+    assert rel_err(y, g[f"{tag}.y"]) < TOL[dtype] and rel_err(dx, g[f"{tag}.gx"]) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("C,n", [(5, 5), (12, 12), (24, 24), (40, 7)])
+def test_lrn_generic_vs_oracle(C, n, dtype):
+    """channel counts that take the generic (non power-of-two / padded) LRN path"""
+    torch.manual_seed(C)
+    x = 10 * torch.randn(2, C, 6, 5); gy = torch.randn(2, C, 6, 5)
+    xr = x.clone().requires_grad_(True)
+    yr = O.lrn(xr, n); yr.backward(gy)
+
+    def build(plan):
+        y = Act(plan, "y", 6, 5, C)
+        op = LrnOp(plan, "l", plan.x_in, y)
+        plan.logits = y
+        op.n = n
+    # LrnOp uses size = C; emulate other sizes only when n == C
+    if n != C:
+        pytest.skip("plan-level LRN always uses size == channels (the only form the reference instantiates)")
+    y, _, dx, _ = run_graph(build, {}, x, gy, dtype)
+    assert rel_err(y, yr.detach()) < TOL[dtype] and rel_err(dx, xr.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("tag", ["deconv_even", "deconv_odd"])
+def test_deconv_golden(tag, dtype):
+    g = load_ops()
+    w, b = g[f"{tag}.p.conv.weight"], g[f"{tag}.p.conv.bias"]
+    hw = tuple(g[f"{tag}.y"].shape[2:])
+    y, _, dx, grads = run_graph(_conv_builder(w.shape[1], 3, False, kind="deconv", out_hw=hw),
+                                {"w": torch.tensor(w), "b": torch.tensor(b)}, g[f"{tag}.x"], g[f"{tag}.gy"], dtype)
+    _check(g, tag, y, dx, grads, "conv.weight", "conv.bias", TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_res_block_golden(dtype):
+    g = load_ops(); tag = "res"
+    params = {f"r.conv_res_list.{i}.custom_conv.{n}": torch.tensor(g[f"{tag}.p.conv_res_list.{i}.custom_conv.{n}"])
+              for i in range(2) for n in ("weight", "bias")}
+
+    def build(plan):
+        plan.cfg.update(res_depth=2, filter_size=3)
+        plan.logits = plan._res_block(plan.x_in, "r", "t")
+    y, _, dx, grads = run_graph(build, params, g[f"{tag}.x"], g[f"{tag}.gy"], dtype)
+    tol = TOL[dtype]
+    assert rel_err(y, g[f"{tag}.y"]) < tol and rel_err(dx, g[f"{tag}.gx"]) < tol
+    for k, v in grads.items():
+        assert rel_err(v, g[f"{tag}.g.{k[2:]}"]) < tol, k
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("tag", ["attn64", "attn32"])
+def test_attention_golden(tag, dtype):
+    g = load_ops()
+    params = {f"{m}.{n}": torch.tensor(g[f"{tag}.p.attention_block.{m}.conv.{n}"]) for m in "fgh" for n in ("weight", "bias")}
+    C = g[f"{tag}.x"].shape[1]
+
+    def build(plan):
+        x = plan.x_in
+        f = Act(plan, "f", x.H, x.W, C // 8); gg = Act(plan, "g", x.H, x.W, C // 8); h = Act(plan, "h", x.H, x.W, C)
+        ConvOp(plan, "f", x, None, "f.weight", "f.bias", f, 1)
+        ConvOp(plan, "g", x, None, "g.weight", "g.bias", gg, 1)
+        hop = ConvOp(plan, "h", x, None, "h.weight", "h.bias", h, 1)
+        y = Act(plan, "y", x.H, x.W, C)
+        AttnCoreOp(plan, "a", f, gg, h, x, y)
+        hop.bwd_add = y
+        plan.logits = y
+    y, _, dx, grads = run_graph(build, params, g[f"{tag}.x"], g[f"{tag}.gy"], dtype)
+    tol = TOL[dtype] * (3 if dtype == L.BF16 else 1)
+    assert rel_err(y, g[f"{tag}.y"]) < tol and rel_err(dx, g[f"{tag}.gx"]) < tol
+    for k, v in grads.items():
+        m, n = k.split(".")
+        ref = g[f"{tag}.g.attention_block.{m}.conv.{n}"]
+        # the f-bias gradient is identically 0 (softmax is invariant to it): absolute check
+        assert rel_err(v, ref) < tol or float(np.abs(ref).max()) < 1e-5, k
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_pool_golden(dtype):
+    g = load_ops()
+    x = g["pool.x"]
+
+    def build(plan):
+        xi = plan.x_in
+        y = Act(plan, "y", (xi.H + 1) // 2, (xi.W + 1) // 2, xi.C)
+        PoolOp(plan, "p", xi, y)
+        plan.logits = y
+    y, _, dx, _ = run_graph(build, {}, x, g["pool.gy"], dtype)
+    if dtype == L.F32:
+        assert np.array_equal(y.numpy(), g["pool.y"]) and np.array_equal(dx.numpy(), g["pool.gx"])   # bit exact
+    else:
+        assert rel_err(y, g["pool.y"]) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_dual_source_conv_vs_oracle(dtype):
+    """concat([x1, x2]) -> 3x3 conv and 1x1+ReLU conv (model/model.py:147-148,242-244) with two source pointers"""
+    torch.manual_seed(5)
+    B, c, H, W = 2, 16, 13, 21
+    x = torch.randn(B, 8, H, W)
+    p = {"w0": 0.2 * torch.randn(c, 8, 3, 3), "b0": 0.1 * torch.randn(c),
+         "w1": 0.2 * torch.randn(c, 8, 1, 1), "b1": 0.1 * torch.randn(c),
+         "wm": 0.1 * torch.randn(c, 2 * c, 3, 3), "bm": 0.1 * torch.randn(c),
+         "wc": 0.2 * torch.randn(c, 2 * c, 1, 1), "bc": 0.1 * torch.randn(c)}
+    gy = torch.randn(B, c, H, W)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xr = x.clone().requires_grad_(True)
+    a = O.conv_same(xr, leaves["w0"], leaves["b0"], relu=True)
+    b2 = O.conv_same(xr, leaves["w1"], leaves["b1"])
+    m = O.conv_same(torch.cat([a, b2], 1), leaves["wm"], leaves["bm"])
+    yr = O.conv_same(torch.cat([b2, m], 1), leaves["wc"], leaves["bc"], relu=True)
+    yr.backward(gy)
+
+    def build(plan):
+        xi = plan.x_in
+        A = Act(plan, "A", H, W, c, relu_out=True); Bt = Act(plan, "B", H, W, c)
+        ConvOp(plan, "a", xi, None, "w0", "b0", A, 3, relu_out=True)
+        ConvOp(plan, "b", xi, None, "w1", "b1", Bt, 1)
+        M = Act(plan, "M", H, W, c)
+        ConvOp(plan, "m", A, Bt, "wm", "bm", M, 3)
+        Y = Act(plan, "Y", H, W, c, relu_out=True)
+        ConvOp(plan, "c", Bt, M, "wc", "bc", Y, 1, relu_out=True)
+        plan.logits = Y
+    y, _, dx, grads = run_graph(build, p, x, gy, dtype)
+    tol = TOL[dtype]
+    assert rel_err(y, yr.detach()) < tol and rel_err(dx, xr.grad) < tol
+    for k in p:
+        assert rel_err(grads[k], leaves[k].grad) < tol, k
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_wide_input_chunked_K(dtype):
+    """Cin = 200 (stored 200, K chunked) and 24 -> exercises channel chunking and non power-of-two channels"""
+    torch.manual_seed(6)
+    x = torch.randn(1, 200, 9, 17)
+    p = {"w": 0.05 * torch.randn(24, 200, 3, 3), "b": 0.1 * torch.randn(24)}
+    gy = torch.randn(1, 24, 9, 17)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = O.conv_same(xr, leaves["w"], leaves["b"]); yr.backward(gy)
+    y, _, dx, grads = run_graph(_conv_builder(24, 3, False), p, x, gy, dtype)
+    tol = TOL[dtype]
+    assert rel_err(y, yr.detach()) < tol and rel_err(dx, xr.grad) < tol
+    assert rel_err(grads["w"], leaves["w"].grad) < tol and rel_err(grads["b"], leaves["b"].grad) < tol
+
+
+def test_masked_ce_golden():
+    g = load_ops()
+    from msau_amd.model import _MaskedCEFunction
+    lg = torch.tensor(g["ce.logits"], device="cuda", requires_grad=True)
+    ax = torch.tensor(g["ce.aux"], device="cuda", requires_grad=True)
+    lab = torch.tensor(g["ce.label"], device="cuda")
+    loss = _MaskedCEFunction.apply(lg, ax, lab)
+    loss.backward()
+    assert abs(float(loss) - float(g["ce.loss"])) < 1e-5
+    assert rel_err(lg.grad.cpu(), g["ce.glogits"]) < 1e-5 and rel_err(ax.grad.cpu(), g["ce.gaux"]) < 1e-5
+
+
+def test_masked_ce_batch_and_empty_sample():
+    """batch rule of SURVEY 8(e): per-sample masked mean, mean over samples; a sample without labels contributes 0"""
+    from msau_amd.model import _MaskedCEFunction
+    torch.manual_seed(3)
+    lg = torch.randn(3, 5, 9, 7); ax = torch.randn(3, 5, 9, 7)
+    lab = torch.randint(0, 5, (3, 9, 7)); lab[1] = 0
+    lr_, ar_ = lg.clone().requires_grad_(True), ax.clone().requires_grad_(True)
+    ref = O.msau_loss(lr_, ar_, lab); ref.backward()
+    lgc, axc = lg.cuda().requires_grad_(True), ax.cuda().requires_grad_(True)
+    loss = _MaskedCEFunction.apply(lgc, axc, lab.cuda()); loss.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5
+    assert rel_err(lgc.grad.cpu(), lr_.grad) < 1e-5 and rel_err(axc.grad.cpu(), ar_.grad) < 1e-5
+
+
+def test_clip_adam_vs_oracle():
+    torch.manual_seed(9)
+    n = 10007
+    p0, g0 = torch.randn(n), 3 * torch.randn(n)
+    P = {"p": p0.clone()}; M = {"p": torch.zeros(n)}; V = {"p": torch.zeros(n)}
+    dev = "cuda"
+    p, m, v = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    state = torch.zeros(8, device=dev); ws = torch.zeros(int(L.load().msau_adam_ws_floats(n)), device=dev)
+    for step in range(1, 4):
+        g = g0 * step
+        gn = O.clip_adam_step(P, {"p": g.clone()}, M, V, step)
+        gd = g.to(dev)
+        L.call("msau_clip_adam_step", torch.cuda.current_stream().cuda_stream, p.data_ptr(), gd.data_ptr(), m.data_ptr(),
+               v.data_ptr(), state.data_ptr(), ws.data_ptr(), n, 1e-4, 0.9, 0.999, 1e-8, 1.0, 1.0)
+        assert abs(float(state[1]) - gn) < 1e-4 * gn and int(state[0]) == step
+        assert float((p.cpu() - P["p"]).abs().max()) < 2e-7
