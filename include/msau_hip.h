@@ -161,6 +161,7 @@ typedef struct {
     int64_t b_slab_stride;  /*   b_src_off + s*b_slab_stride + r*b_elem_stride, s < b_nslabs            */
     int32_t b_elem_stride;  /*   (the "ones" column of a wgrad slab, or msau_channel_sum partials)      */
     int32_t b_nslabs;
+    int32_t b_count;        /* number of bias elements (conv: rows_real; transposed conv: its out channels) */
     int32_t nslabs;
     int32_t slab_elems;     /* nchunks * Cout_store * kext                                              */
     int32_t kext;

@@ -47,7 +47,7 @@ class PackEntry(C.Structure):
 
 class UnpackEntry(C.Structure):
     _fields_ = [("slab_off", i64), ("w_off", i64), ("b_off", i64), ("b_src_off", i64), ("b_slab_stride", i64)] + \
-               [(n, i32) for n in ("b_elem_stride", "b_nslabs", "nslabs", "slab_elems", "kext", "dim0", "dim1", "KH",
+               [(n, i32) for n in ("b_elem_stride", "b_nslabs", "b_count", "nslabs", "slab_elems", "kext", "dim0", "dim1", "KH",
                                    "KW", "row_is_dim0", "rows_real", "k1_real", "k1_store", "k2_real", "k2_store",
                                    "cch", "nchunks", "accumulate")]
 

@@ -91,7 +91,7 @@ __global__ void unpack_kernel(const float* __restrict__ slabs, float* __restrict
     }
     if (e.b_off >= 0 && blockIdx.x == 0) {
         // bias gradient: the "ones" column of the wgrad slabs, or channel-sum partials
-        for (int r = threadIdx.x; r < e.rows_real; r += blockDim.x) {
+        for (int r = threadIdx.x; r < e.b_count; r += blockDim.x) {
             const float* p = slabs + e.b_src_off + (int64_t)r * e.b_elem_stride;
             float sum = 0.f;
             for (int s = 0; s < e.b_nslabs; ++s) sum += p[(int64_t)s * e.b_slab_stride];

@@ -257,10 +257,12 @@ class ConvOp(Op):
         u.cch, u.nchunks, u.accumulate = wg.cch, wg.nchunks, 0
         if conv:
             u.b_src_off, u.b_slab_stride, u.b_elem_stride, u.b_nslabs = self.slab_off + taps * wg.cch, slab_elems, wg.kext, nslabs
+            u.b_count = out.C
         else:
             self.csum_blocks = max(1, min(256, out.npix // 1024))
             self.csum_off = P.alloc_slab(self.csum_blocks * out.Cs)
             u.b_src_off, u.b_slab_stride, u.b_elem_stride, u.b_nslabs = self.csum_off, out.Cs, 1, self.csum_blocks
+            u.b_count = out.C
         P.add_unpack_entry(u, rows_real * wg.nchunks * taps * wg.cch)
 
     def late_bind(self):

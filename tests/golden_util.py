@@ -46,3 +46,16 @@ def rel_err(a, b):
     a = torch.as_tensor(np.asarray(a)).double()
     b = torch.as_tensor(np.asarray(b)).double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(np.asarray(a)).double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def err(a, b, bf16=False):
+    """fp32 storage: max-norm error relative to the tensor's max.  bf16 storage: relative L2 error --
+    a ReLU whose pre-activation is within bf16 rounding of 0 legitimately flips, which moves single
+    elements of a gradient by O(1) while leaving the tensor as a whole within rounding."""
+    return rel_l2(a, b) if bf16 else rel_err(a, b)
