@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Headline benchmark: chargrid tiles/sec, MSAU train step (fwd + loss + bwd + clip + Adam, + RCCL
+gradient all-reduce when N > 1) on BASELINE.json's configs[1]: FUNSD-like one-hot chargrid,
+3-stage MSAU, 336x256x64, bf16 storage, batch 16 per GPU, synthetic data, random-init weights.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel symbol: algorithmic bytes per launch / HIP-event launch time
+  cpu_baseline -- the CPU oracle (port of the reference path) timed on this host's cores, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="tiles per GPU")
+    ap.add_argument("--height", type=int, default=336)
+    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--channels", type=int, default=64)
+    ap.add_argument("--stages", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=200)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline sample")
+    ap.add_argument("--dump-kernels", default="", help="write the per-kernel HIP-event table to this file")
+    return ap.parse_args()
+
+
+def synthetic(B, C, H, W, n_class, seed, device):
+    """one-hot chargrid, 30 % occupancy, labels = occupied * U{1..n_class-1}."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    occ = torch.rand((B, H, W), generator=g) < 0.3
+    ch = torch.randint(0, C, (B, H, W), generator=g)
+    x = torch.zeros((B, C, H, W))
+    x.scatter_(1, ch[:, None], occ[:, None].float())
+    label = torch.randint(1, n_class, (B, H, W), generator=g) * occ.long()
+    return x.to(device), label.to(device)
+
+
+def usable_cores() -> int:
+    """cores this process may actually use: min(affinity, cgroup cpu quota), never more than 64"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    env = os.environ.get("MSAU_CPU_THREADS")
+    if env:
+        n = int(env)
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(args, n_class):
+    """The CPU restatement of the reference step (oracle/, validated against the reference's own
+    outputs) on this host: fp32, batch-1 loop as in train_chargrid_funsd_msau.py:45-59."""
+    from oracle import msau_oracle as O
+    cfg = dict(O.DEFAULT_CFG, channels=args.channels, num_blocks=args.stages, n_class=n_class)
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    sd = O.init_params(cfg, seed=0)
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v = {k: torch.zeros_like(t) for k, t in sd.items()}
+    x, label = O.synthetic_batch(1, args.channels, args.height, args.width, n_class, seed=99)
+    step = 0
+    for _ in range(2):
+        step += 1
+        O.train_step(sd, m, v, step, x, label, cfg)
+    n = 0
+    t0 = time.perf_counter()
+    while n < max(1, args.cpu_steps) and (n == 0 or time.perf_counter() - t0 < args.cpu_seconds):
+        step += 1
+        n += 1
+        O.train_step(sd, m, v, step, x, label, cfg)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fp32 train steps (fwd+loss+bwd+clip+Adam) of batch 1 at {args.height}x{args.width}x{args.channels}, "
+                      f"{args.stages}-stage, PyTorch-CPU restatement in oracle/msau_oracle.py, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        # convenience: relaunch under torch.distributed.run as a CHILD process (never exec after HIP init)
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 1000), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the MSAU HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from msau_amd import _lib as L
+    from msau_amd.model import MSAUWrapper, TrainEngine
+
+    n_class = 5
+    kw = dict(scale_space_num=4, res_depth=2, featRoot=8, filter_size=3, pool_size=2, final_act="softmax",
+              num_blocks=args.stages, dtype=args.dtype, seed=0)
+    model = MSAUWrapper(args.channels, n_class, kw).to(dev)
+    eng = TrainEngine(model, lr=1e-4, use_graph=not args.no_graph)
+    x, label = synthetic(args.batch, args.channels, args.height, args.width, n_class, 1234 + rank, dev)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(max(args.warmup, 1 if not args.no_graph else 0)):
+        eng.step(x, label)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = eng.step(x, label)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    tiles = world * args.batch * args.steps
+    value = tiles / dt
+    loss_val = float(loss)
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        # per-launch HIP-event timing of the same step, eagerly, on the launch stream
+        plan = model._plan_for(x, training=True)
+        prof = L.Profiler()
+        eng_e = eng
+        eng_e.use_graph = False
+        nprof = min(args.steps, 5)
+        L.set_profiler(prof)
+        for _ in range(nprof):
+            eng_e.step(x, label)
+        torch.cuda.synchronize()
+        L.set_profiler(None)
+        summ = prof.summary()
+        rows = []
+        for key, (cnt, ms) in summ.items():
+            meta = plan.launch_meta.get(key)
+            rows.append((ms, key, cnt, meta))
+        rows.sort(reverse=True)
+        total_ms = sum(r[0] for r in rows)
+        if args.dump_kernels:
+            with open(args.dump_kernels, "w") as f:
+                f.write(f"# HIP-event per-launch timing, {nprof} eager steps, batch {args.batch}, {args.dtype}\n")
+                f.write("# kernel, launches, total_ms, avg_us, share, alg_GB/s, alg_TFLOP/s\n")
+                for ms, key, cnt, meta in rows:
+                    gbs = tfs = float("nan")
+                    if meta:
+                        gbs = meta[1] * nprof / (ms * 1e-3) / 1e9
+                        tfs = meta[2] * nprof / (ms * 1e-3) / 1e12
+                    f.write(f"{key}, {cnt}, {ms:.3f}, {1e3 * ms / cnt:.1f}, {ms / total_ms:.3f}, {gbs:.0f}, {tfs:.1f}\n")
+        ms, key, cnt, meta = next(r for r in rows if r[3])
+        n_launch, alg_bytes, alg_flops = meta
+        achieved = alg_bytes * nprof / (ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": key, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "launches_per_step": n_launch, "avg_launch_us": round(1e3 * ms / cnt, 2),
+                "alg_bytes_per_launch": round(alg_bytes / n_launch),
+                "share_of_step": round(ms / total_ms, 3),
+                "mfma_frac": round(alg_flops * nprof / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4),
+                "whole_step": {"alg_GB": round(sum(m[1] for m in plan.launch_meta.values()) / 1e9, 3),
+                               "alg_TFLOP": round(sum(m[2] for m in plan.launch_meta.values()) / 1e12, 4),
+                               "hbm_frac": round(sum(m[1] for m in plan.launch_meta.values()) * value / (world * args.batch) / 1e9 / HBM_PEAK_GBS, 4)}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, n_class)
+
+    if rank == 0:
+        out = {"metric": "chargrid tiles/sec (train fwd+bwd), 336x256x64 3-stage MSAU", "value": round(value, 2),
+               "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": f"configs[1]: one-hot chargrid {args.height}x{args.width}x{args.channels}, "
+                                      f"{args.stages}-stage MSAU (featRoot 8, 4 scales, res_depth 2), "
+                                      f"batch {args.batch}/GPU, fwd+masked-CE+bwd+clip+Adam"
+                                      + (", RCCL all-reduce" if world > 1 else ""),
+                          "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                          "graph": not args.no_graph, "loss": round(loss_val, 5)},
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -98,6 +98,10 @@ typedef struct {
 int msau_conv_pack_geometry(int dtype, int C1_stored, int C2_stored, int Cout_stored, int KH, int KW, int dil,
                             int stride, int ups, msau_conv_pack_geom* out);
 int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d);
+/* which template instance msau_conv2d launches for this descriptor (for profiling / roofline):
+ * info[0] = CT (16-row output-channel tiles), info[1] = PT (pixel tiles per wave: tile = 4*PT x 16),
+ * info[2] = dynamic LDS bytes, info[3] = workgroups, info[4] = channel chunk, info[5] = chunks */
+int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info6);
 
 /* ------------------------------------------------------------------------------------------
  * Weight / bias gradient of the same convolution (autograd of torch.nn.Conv2d reached from

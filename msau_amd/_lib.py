@@ -57,6 +57,7 @@ _SIGNATURES = {
     "msau_version": (C.c_int, []),
     "msau_conv_pack_geometry": (C.c_int, [C.c_int] * 9 + [C.POINTER(ConvPackGeom)]),
     "msau_conv2d": (C.c_int, [vp, C.c_int, C.POINTER(ConvDesc)]),
+    "msau_conv2d_launch_info": (C.c_int, [C.c_int, C.POINTER(ConvDesc), C.POINTER(i32)]),
     "msau_wgrad_geometry": (C.c_int, [C.c_int, C.POINTER(WgradDesc), C.POINTER(WgradGeom)]),
     "msau_conv2d_wgrad": (C.c_int, [vp, C.c_int, C.POINTER(WgradDesc)]),
     "msau_pack_params": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int]),
@@ -113,6 +114,39 @@ def check(rc: int, what: str = ""):
         raise MsauHipError(f"{what or 'msau call'} failed (status {rc}): {msg}")
 
 
-def call(name: str, *args):
+class Profiler:
+    """Per-call HIP-event timing of C-ABI launches on the current stream (bench / roofline only)."""
+
+    def __init__(self):
+        self.records = []          # (key, start_event, end_event)
+        self.key = None
+
+    def summary(self):
+        import collections
+        out = collections.OrderedDict()
+        for key, e0, e1 in self.records:
+            c, t = out.get(key, (0, 0.0))
+            out[key] = (c + 1, t + e0.elapsed_time(e1))
+        return out
+
+
+_profiler = None
+
+
+def set_profiler(p):
+    global _profiler
+    _profiler = p
+
+
+def call(name: str, *args, key=None):
     """Call an int-status entry point and raise on failure."""
+    if _profiler is None:
+        check(getattr(load(), name)(*args), name)
+        return
+    import torch
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(getattr(load(), name)(*args), name)
+    e1.record()
+    _profiler.records.append((key or name, e0, e1))

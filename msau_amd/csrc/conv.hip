@@ -278,6 +278,33 @@ extern "C" int msau_conv_pack_geometry(int dtype, int C1, int C2, int Cout, int 
     return 0;
 }
 
+static int conv_plan(int dtype, const msau_conv_desc* d, ConvGeom* gout, TileGeom* tout, int* PTout, int64_t* nbout);
+
+extern "C" int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info) {
+    MSAU_CHECK_ARG(d && info, "conv2d_launch_info: null pointer");
+    ConvGeom g; TileGeom t; int PT; int64_t nb;
+    int rc = conv_plan(dtype, d, &g, &t, &PT, &nb);
+    if (rc) return rc;
+    info[0] = g.CT; info[1] = PT; info[2] = t.total; info[3] = (int32_t)nb; info[4] = g.cch; info[5] = g.nchunks;
+    return 0;
+}
+
+static int conv_plan(int dtype, const msau_conv_desc* d, ConvGeom* gout, TileGeom* tout, int* PTout, int64_t* nbout) {
+    ConvGeom g;
+    int rc = conv_geom(dtype, d->C1, d->C2, d->Cout, d->KH, d->KW, d->dil, d->stride, d->ups, &g);
+    if (rc) return rc;
+    int PT = 4;
+    auto ntiles = [&](int pt) { return (int64_t)d->B * cdiv(d->Hout, 4 * pt) * cdiv(d->Wout, 16); };
+    if (ntiles(4) < 512) PT = ntiles(2) >= 384 ? 2 : 1;
+    TileGeom t = tile_geom(g, PT, d->KH, d->KW, d->dil, d->stride);
+    while (t.total > 150 * 1024 && PT > 1) { PT >>= 1; t = tile_geom(g, PT, d->KH, d->KW, d->dil, d->stride); }
+    if (t.total > 150 * 1024) return msau_set_error(MSAU_ERR_LDS, "conv2d: tile needs %d B of LDS", t.total);
+    int64_t nb = ntiles(PT);
+    MSAU_CHECK_ARG(nb < (1ll << 31), "conv2d: grid too large");
+    *gout = g; *tout = t; *PTout = PT; *nbout = nb;
+    return 0;
+}
+
 extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
     MSAU_CHECK_ARG(d && d->x1 && d->wpack && d->y, "conv2d: null pointer");
     MSAU_CHECK_ARG(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->Hout > 0 && d->Wout > 0, "conv2d: bad dims");
@@ -285,24 +312,14 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
     MSAU_CHECK_ARG(!(d->flags & MSAU_CONV_ADD) || d->add, "conv2d: ADD without pointer");
     MSAU_CHECK_ARG(!(d->flags & MSAU_CONV_MASK_A) || d->mask_a, "conv2d: MASK_A without pointer");
     MSAU_CHECK_ARG(!(d->flags & MSAU_CONV_MASK_B) || d->mask_b, "conv2d: MASK_B without pointer");
-    ConvGeom g;
-    int rc = conv_geom(dtype, d->C1, d->C2, d->Cout, d->KH, d->KW, d->dil, d->stride, d->ups, &g);
+    ConvGeom g; TileGeom t; int PT; int64_t nb;
+    int rc = conv_plan(dtype, d, &g, &t, &PT, &nb);
     if (rc) return rc;
-    // sanity of the caller's output size against the conv arithmetic (every output pixel's taps are
-    // bounds-checked in the kernel, so this only guards against nonsense)
-    int PT = 4;
-    auto ntiles = [&](int pt) { return (int64_t)d->B * cdiv(d->Hout, 4 * pt) * cdiv(d->Wout, 16); };
-    if (ntiles(4) < 512) PT = ntiles(2) >= 384 ? 2 : 1;
-    TileGeom t = tile_geom(g, PT, d->KH, d->KW, d->dil, d->stride);
-    while (t.total > 150 * 1024 && PT > 1) { PT >>= 1; t = tile_geom(g, PT, d->KH, d->KW, d->dil, d->stride); }
-    if (t.total > 150 * 1024) return msau_set_error(MSAU_ERR_LDS, "conv2d: tile needs %d B of LDS", t.total);
     ConvArgs a;
     a.d = *d;
     a.cch = g.cch; a.nchunks = g.nchunks; a.kchunk = g.kchunk; a.ngroups = g.ngroups;
     a.TIH = t.TIH; a.TIW = t.TIW; a.PS = t.PS; a.WS = t.WS; a.in_bytes = t.in_bytes; a.w_bytes = t.w_bytes;
     a.tiles_x = cdiv(d->Wout, 16); a.tiles_y = cdiv(d->Hout, 4 * PT);
-    int64_t nb = ntiles(PT);
-    MSAU_CHECK_ARG(nb < (1ll << 31), "conv2d: grid too large");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == MSAU_F32) return launch_conv_ct<float>(s, a, g.CT, PT, (int)nb, t.total);
     return launch_conv_ct<bf16_t>(s, a, g.CT, PT, (int)nb, t.total);

@@ -269,21 +269,56 @@ class ConvOp(Op):
         P = self.plan
         if self.wdesc is not None:
             self.wdesc.slabs = P.slab_ptr(self.slab_off)
+        # ---- launch metadata for profiling / roofline accounting (bench.py)
+        T = "f32" if P.dtype == L.F32 else "bf16"
+        esz = 4 if P.dtype == L.F32 else 2
+        taps = self.k * self.k
+        cin_real = self.x1.C + (self.x2.C if self.x2 is not None else 0)
+        self.flops = 2.0 * P.B * (self.out.H * self.out.W if self.kind == "conv" else self.x1.H * self.x1.W) * \
+            taps * cin_real * self.out.C
+
+        def conv_meta(d):
+            info = (L.i32 * 6)()
+            L.call("msau_conv2d_launch_info", P.dtype, C.byref(d), info)
+            nin = d.B * d.Hin * d.Win * (d.C1 + d.C2)
+            nout = d.B * d.Hout * d.Wout * d.Cout
+            extra = sum(1 for f in (L.CONV_ADD, L.CONV_ACCUM, L.CONV_MASK_A, L.CONV_MASK_B) if d.flags & f)
+            return f"conv_kernel<{T},CT{info[0]},PT{info[1]}>", (nin + nout * (1 + extra)) * esz
+
+        self.fkey, self.fbytes = conv_meta(self.fdesc)
+        P.note_launch(self.fkey, self.fbytes, self.flops)
+        self.dmeta = [None, None]
+        for si, dd in enumerate(self.ddesc):
+            if dd is not None:
+                src = (self.x1, self.x2)[si]
+                fl = 2.0 * P.B * (self.out.H * self.out.W if self.kind == "conv" else self.x1.H * self.x1.W) * taps * src.C * self.out.C
+                self.dmeta[si] = conv_meta(dd)
+                P.note_launch(self.dmeta[si][0], self.dmeta[si][1], fl)
+        if self.wdesc is not None:
+            w, wg = self.wdesc, self.wgeom
+            ctn = -(-w.Cout // 16)
+            ctn = 4 if ctn == 3 else (8 if ctn > 4 else ctn)
+            nkw = -(-(wg.kext // 16) // 4)
+            nkw = 1 if nkw <= 1 else 2 if nkw <= 2 else 3 if nkw <= 3 else 5 if nkw <= 5 else 10
+            self.wkey = f"wgrad_kernel<{T},CT{ctn},NK{nkw}>"
+            self.wbytes = (w.B * w.Hin * w.Win * (w.C1 + w.C2) * wg.nchunks // wg.nchunks + w.B * w.Hout * w.Wout * w.Cout) * esz \
+                + w.nslabs * wg.slab_bytes
+            P.note_launch(self.wkey, self.wbytes, self.flops)
 
     def fwd(self, s):
-        L.call("msau_conv2d", s, self.plan.dtype, C.byref(self.fdesc))
+        L.call("msau_conv2d", s, self.plan.dtype, C.byref(self.fdesc), key=self.fkey)
 
     def bwd(self, s):
         if self.wdesc is None:
             return
         P = self.plan
-        L.call("msau_conv2d_wgrad", s, P.dtype, C.byref(self.wdesc))
+        L.call("msau_conv2d_wgrad", s, P.dtype, C.byref(self.wdesc), key=self.wkey)
         if self.kind != "conv":
             L.call("msau_channel_sum", s, P.dtype, _ptr(self.out.grad), self.out.npix, self.out.Cs,
                    P.slab_ptr(self.csum_off), self.csum_blocks)
-        for dd in self.ddesc:
+        for si, dd in enumerate(self.ddesc):
             if dd is not None:
-                L.call("msau_conv2d", s, P.dtype, C.byref(dd))
+                L.call("msau_conv2d", s, P.dtype, C.byref(dd), key=self.dmeta[si][0])
 
 
 class LrnOp(Op):
@@ -369,6 +404,7 @@ class Plan:
         self._unpack_entries: List[L.UnpackEntry] = []
         self._pack_max = 1
         self._unpack_max = 1
+        self.launch_meta: Dict[str, Tuple[int, float, float]] = {}
         self.x_in = Act(self, "input", H, W, cfg["channels"], needs_grad=bool(cfg.get("input_grad", False)))
         self.logits: Optional[Act] = None
         self.aux: Optional[Act] = None
@@ -396,6 +432,11 @@ class Plan:
     def add_unpack_entry(self, e, nelems):
         self._unpack_entries.append(e)
         self._unpack_max = max(self._unpack_max, int(nelems))
+
+    def note_launch(self, key: str, nbytes: float, flops: float):
+        """algorithmic bytes / flops of one launch, accumulated per kernel symbol for one train step"""
+        c, b, f = self.launch_meta.get(key, (0, 0.0, 0.0))
+        self.launch_meta[key] = (c + 1, b + nbytes, f + flops)
 
     def pack_ptr(self, off: int) -> int:
         return self.pack_arena.data_ptr() + off
