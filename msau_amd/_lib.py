@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmsau_hip.so")
+LIB_PATH = os.environ.get("MSAU_HIP_LIB", os.path.join(HERE, "libmsau_hip.so"))
 
 F32, BF16 = 0, 1
 

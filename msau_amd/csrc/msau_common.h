@@ -54,6 +54,15 @@ template <typename T> __device__ __forceinline__ typename Vec8<T>::type relu8(ty
     for (int i = 0; i < 8; ++i) v[i] = ((float)v[i] > 0.0f) ? v[i] : (T)0.0f;
     return v;
 }
+// bf16 ReLU on the raw bits: a negative bf16 is a negative int16, and positive bf16 values order like
+// positive int16, so max(int16, 0) is exactly ReLU (-0.0 -> +0.0): one v_pk_max_i16 per two elements.
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+template <> __device__ __forceinline__ bf16x8 relu8<bf16_t>(bf16x8 v) {
+    s16x8 i = __builtin_bit_cast(s16x8, v);
+    s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    i = __builtin_elementwise_max(i, z);
+    return __builtin_bit_cast(bf16x8, i);
+}
 template <typename T> __device__ __forceinline__ typename Vec8<T>::type load8(const T* p) {
     return *reinterpret_cast<const typename Vec8<T>::type*>(p);
 }

@@ -64,39 +64,82 @@ __global__ void pack_kernel(const float* __restrict__ params, unsigned char* __r
     }
 }
 
-__global__ void unpack_kernel(const float* __restrict__ slabs, float* __restrict__ grads,
-                              const msau_unpack_entry* __restrict__ table) {
+// 256 threads = 16 consecutive K columns x 16 slab lanes: slab lane t sums slabs t, t+16, ... with
+// independent loads in flight, then the 16 partial sums are combined in a fixed order (reproducible).
+__global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ slabs, float* __restrict__ grads,
+                                                     const msau_unpack_entry* __restrict__ table) {
+    __shared__ float red[16][17];
     const msau_unpack_entry e = table[blockIdx.y];
     const int taps = e.KH * e.KW;
     const int kcols = e.nchunks * taps * e.cch;                 // stored K columns
+    const int kc16 = (kcols + 15) / 16;
     const int rows_store = e.slab_elems / (e.kext * e.nchunks);
-    const int64_t total = (int64_t)e.rows_real * kcols;
+    const int ngroups = e.rows_real * kc16;                     // groups of 16 consecutive columns of one row
     const float* s0 = slabs + e.slab_off;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int kk = (int)(i % kcols);
-        int r = (int)(i / kcols);
-        int chunk = kk / (taps * e.cch);
-        int k = kk - chunk * taps * e.cch;
-        int tap = k / e.cch, c = k - tap * e.cch;
-        int kc = real_channel(chunk * e.cch + c, e.k1_real, e.k1_store, e.k2_real, e.k2_store);
-        if (kc < 0) continue;
-        const float* p = s0 + ((int64_t)chunk * rows_store + r) * e.kext + k;
+    const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int r = grp / kc16;
+        const int kk = (grp - r * kc16) * 16 + col;
         float sum = 0.f;
-        for (int s = 0; s < e.nslabs; ++s) sum += p[(int64_t)s * e.slab_elems];     // fixed order: reproducible
-        int ky = tap / e.KW, kx = tap - ky * e.KW;
-        int i0 = e.row_is_dim0 ? r : kc;
-        int i1 = e.row_is_dim0 ? kc : r;
-        float* dst = grads + e.w_off + (((int64_t)i0 * e.dim1 + i1) * e.KH + ky) * e.KW + kx;
-        *dst = e.accumulate ? *dst + sum : sum;
+        int chunk = 0, k = 0, tap = 0, c = 0, kc = -1;
+        if (kk < kcols) {
+            chunk = kk / (taps * e.cch);
+            k = kk - chunk * taps * e.cch;
+            tap = k / e.cch; c = k - tap * e.cch;
+            kc = real_channel(chunk * e.cch + c, e.k1_real, e.k1_store, e.k2_real, e.k2_store);
+        }
+        if (kc >= 0) {
+            const float* p = s0 + ((int64_t)chunk * rows_store + r) * e.kext + k;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int s = sl;
+            for (; s + 48 < e.nslabs; s += 64) {
+                a0 += p[(int64_t)s * e.slab_elems];
+                a1 += p[(int64_t)(s + 16) * e.slab_elems];
+                a2 += p[(int64_t)(s + 32) * e.slab_elems];
+                a3 += p[(int64_t)(s + 48) * e.slab_elems];
+            }
+            for (; s < e.nslabs; s += 16) a0 += p[(int64_t)s * e.slab_elems];
+            sum = (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+        red[sl][col] = sum;
+        __syncthreads();
+        if (sl == 0 && kc >= 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += red[i][col];
+            int ky = tap / e.KW, kx = tap - ky * e.KW;
+            int i0 = e.row_is_dim0 ? r : kc;
+            int i1 = e.row_is_dim0 ? kc : r;
+            float* dst = grads + e.w_off + (((int64_t)i0 * e.dim1 + i1) * e.KH + ky) * e.KW + kx;
+            *dst = e.accumulate ? *dst + t : t;
+        }
     }
-    if (e.b_off >= 0 && blockIdx.x == 0) {
-        // bias gradient: the "ones" column of the wgrad slabs, or channel-sum partials
-        for (int r = threadIdx.x; r < e.b_count; r += blockDim.x) {
-            const float* p = slabs + e.b_src_off + (int64_t)r * e.b_elem_stride;
-            float sum = 0.f;
-            for (int s = 0; s < e.b_nslabs; ++s) sum += p[(int64_t)s * e.b_slab_stride];
-            float* dst = grads + e.b_off + r;
-            *dst = e.accumulate ? *dst + sum : sum;
+    if (e.b_off >= 0) {
+        // bias gradient: the "ones" column of the wgrad slabs, or channel-sum partials; same 16 x 16 scheme
+        const int bgroups = (e.b_count + 15) / 16;
+        for (int grp = blockIdx.x; grp < bgroups; grp += gridDim.x) {
+            const int r = grp * 16 + col;
+            float a0 = 0.f, a1 = 0.f;
+            if (r < e.b_count) {
+                const float* p = slabs + e.b_src_off + (int64_t)r * e.b_elem_stride;
+                int s = sl;
+                for (; s + 16 < e.b_nslabs; s += 32) {
+                    a0 += p[(int64_t)s * e.b_slab_stride];
+                    a1 += p[(int64_t)(s + 16) * e.b_slab_stride];
+                }
+                for (; s < e.b_nslabs; s += 16) a0 += p[(int64_t)s * e.b_slab_stride];
+            }
+            __syncthreads();
+            red[sl][col] = a0 + a1;
+            __syncthreads();
+            if (sl == 0 && r < e.b_count) {
+                float t = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t += red[i][col];
+                float* dst = grads + e.b_off + r;
+                *dst = e.accumulate ? *dst + t : t;
+            }
         }
     }
 }
@@ -118,8 +161,8 @@ extern "C" int msau_pack_params(void* stream, const float* flat_params, void* pa
 extern "C" int msau_wgrad_reduce(void* stream, const float* slab_arena, float* flat_grads,
                                  const msau_unpack_entry* table_dev, int n_entries, int max_elems_per_entry) {
     MSAU_CHECK_ARG(slab_arena && flat_grads && table_dev && n_entries > 0, "wgrad_reduce: bad args");
-    int bx = cdiv(max_elems_per_entry, 256);
-    if (bx > 64) bx = 64;
+    int bx = cdiv(max_elems_per_entry, 16);
+    if (bx > 96) bx = 96;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(unpack_kernel, dim3(bx, n_entries), dim3(256), 0, static_cast<hipStream_t>(stream),
                        slab_arena, flat_grads, table_dev);
