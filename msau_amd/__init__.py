@@ -1,0 +1,4 @@
+"""msau_amd -- MI355X-native training path of the Multi-Stage Attentional U-Net."""
+from .model import MSAUWrapper, TrainEngine, param_shapes  # noqa: F401
+
+__all__ = ["MSAUWrapper", "TrainEngine", "param_shapes"]

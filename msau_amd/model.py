@@ -318,10 +318,10 @@ class TrainEngine:
         self.v = torch.zeros_like(flat)
         self.state = torch.zeros(8, dtype=torch.float32, device=flat.device)
         self.adam_ws = torch.zeros(int(L.load().msau_adam_ws_floats(flat.numel())), dtype=torch.float32, device=flat.device)
+        from .dp import GradSync, stage_buckets
         self.pg = process_group
-        self.world = 1
-        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            self.world = torch.distributed.get_world_size(process_group)
+        self.sync = GradSync(self.flat_grad, stage_buckets(model._poff, model._total, model.num_blocks), process_group)
+        self.world = self.sync.world
         self.use_graph = use_graph
         self._graphs = {}
         self._static = {}
@@ -342,7 +342,8 @@ class TrainEngine:
 
     def _allreduce(self):
         if self.world > 1:
-            torch.distributed.all_reduce(self.flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            self.sync.start_all()
+            self.sync.finish()
 
     def step(self, x: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         """One optimisation step.  Returns the (local) loss as a 1-element device tensor (no host sync)."""
