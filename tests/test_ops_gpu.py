@@ -263,3 +263,30 @@ def test_clip_adam_vs_oracle():
                v.data_ptr(), state.data_ptr(), ws.data_ptr(), n, 1e-4, 0.9, 0.999, 1e-8, 1.0, 1.0)
         assert abs(float(state[1]) - gn) < 1e-4 * gn and int(state[0]) == step
         assert float((p.cpu() - P["p"]).abs().max()) < 2e-7
+
+
+@pytest.mark.parametrize("N,C", [(1344, 64), (200, 32), (77, 64)])
+def test_attention_mfma_bf16_vs_fp32_kernels(N, C):
+    """the bf16 MFMA attention kernels against the fp32 VALU kernels on the same (bf16-representable) inputs,
+    at the real bottleneck size N = 42*32 and at sizes that are not multiples of the 16/32/128 tiling"""
+    torch.manual_seed(N)
+    B, D = 2, 8
+    dev = "cuda"
+    mk = lambda *s, sc=1.0: (sc * torch.randn(*s, device=dev)).bfloat16()
+    f, g, h, x, dy = mk(B, N, D, sc=0.7), mk(B, N, D, sc=0.7), mk(B, N, C), mk(B, N, C), mk(B, N, C)
+    s = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for name, dt, cast in (("ref", L.F32, torch.float32), ("mfma", L.BF16, torch.bfloat16)):
+        ff, gg, hh, xx, dd = (t.to(cast).contiguous() for t in (f, g, h, x, dy))
+        y = torch.empty_like(xx); stats = torch.zeros(B, N, 2, device=dev); ws = torch.zeros(B, N, device=dev)
+        df, dg, dh = torch.empty_like(ff), torch.empty_like(gg), torch.empty_like(hh)
+        L.call("msau_selfattn_fwd", s, dt, ff.data_ptr(), gg.data_ptr(), hh.data_ptr(), xx.data_ptr(), y.data_ptr(),
+               stats.data_ptr(), B, N, D, C)
+        L.call("msau_selfattn_bwd", s, dt, ff.data_ptr(), gg.data_ptr(), hh.data_ptr(), dd.data_ptr(), stats.data_ptr(),
+               df.data_ptr(), dg.data_ptr(), dh.data_ptr(), ws.data_ptr(), B, N, D, C)
+        torch.cuda.synchronize()
+        outs[name] = [t.float().cpu() for t in (y, stats, df, dg, dh)]
+    from tests.golden_util import rel_l2
+    for nm, a, b in zip(("y", "stats", "df", "dg", "dh"), outs["mfma"], outs["ref"]):
+        assert torch.isfinite(a).all(), nm
+        assert rel_l2(a, b) < (1e-4 if nm == "stats" else 2e-2), (nm, rel_l2(a, b))
