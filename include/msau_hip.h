@@ -100,8 +100,9 @@ int msau_conv_pack_geometry(int dtype, int C1_stored, int C2_stored, int Cout_st
 int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d);
 /* which template instance msau_conv2d launches for this descriptor (for profiling / roofline):
  * info[0] = CT (16-row output-channel tiles), info[1] = PT (pixel tiles per wave: tile = 4*PT x 16),
- * info[2] = dynamic LDS bytes, info[3] = workgroups, info[4] = channel chunk, info[5] = chunks */
-int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info6);
+ * info[2] = dynamic LDS bytes, info[3] = workgroups, info[4] = channel chunk, info[5] = chunks,
+ * info[6] = 1 if a compile-time-specialised "lean" instance (conv_lean.hip) takes the launch, info[7] = 0 */
+int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info8);
 
 /* ------------------------------------------------------------------------------------------
  * Weight / bias gradient of the same convolution (autograd of torch.nn.Conv2d reached from

@@ -279,6 +279,9 @@ extern "C" int msau_conv_pack_geometry(int dtype, int C1, int C2, int Cout, int 
 }
 
 static int conv_plan(int dtype, const msau_conv_desc* d, ConvGeom* gout, TileGeom* tout, int* PTout, int64_t* nbout);
+// conv_lean.hip: compile-time-specialised instances for the hot layer shapes
+int msau_conv_lean_applicable(int dtype, const msau_conv_desc* d, int nchunks, int CT);
+int msau_conv_lean_try(hipStream_t s, int dtype, const msau_conv_desc* d, int kchunk, int nchunks, int CT);
 
 extern "C" int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info) {
     MSAU_CHECK_ARG(d && info, "conv2d_launch_info: null pointer");
@@ -286,6 +289,8 @@ extern "C" int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32
     int rc = conv_plan(dtype, d, &g, &t, &PT, &nb);
     if (rc) return rc;
     info[0] = g.CT; info[1] = PT; info[2] = t.total; info[3] = (int32_t)nb; info[4] = g.cch; info[5] = g.nchunks;
+    info[6] = msau_conv_lean_applicable(dtype, d, g.nchunks, g.CT);
+    info[7] = 0;
     return 0;
 }
 
@@ -315,6 +320,8 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
     ConvGeom g; TileGeom t; int PT; int64_t nb;
     int rc = conv_plan(dtype, d, &g, &t, &PT, &nb);
     if (rc) return rc;
+    rc = msau_conv_lean_try(static_cast<hipStream_t>(stream), dtype, d, g.kchunk, g.nchunks, g.CT);
+    if (rc != 0) return rc < 0 ? rc : 0;
     ConvArgs a;
     a.d = *d;
     a.cch = g.cch; a.nchunks = g.nchunks; a.kchunk = g.kchunk; a.ngroups = g.ngroups;

@@ -1,0 +1,271 @@
+// Lean instances of the implicit-GEMM convolution for the layers that dominate the step: stride 1,
+// no dilation, k in {1,3}, one K chunk, 16x16-pixel tiles, channel counts known at compile time.
+//
+// Why a second kernel: the generic conv_kernel spends ~300 VALU + 150 SALU instructions per 64-pixel
+// wave-tile on run-time index arithmetic and is instruction-issue bound.  Here
+// every divisor, LDS stride and tap offset is a compile-time constant, the grid is 3-D (no tile
+// decode), global addresses are a scalar base plus a 32-bit lane offset, LDS fragment addresses are
+// one VGPR plus immediates, and small weight sets live in registers.  Same arithmetic, same packed
+// weight image, same epilogue contract as conv.hip (include/msau_hip.h).
+#include "msau_common.h"
+
+namespace {
+
+struct LeanArgs {
+    msau_conv_desc d;
+    int kchunk;                                  // packed K elements per weight row
+    int in_px1, in_px2, in_row1, in_row2;        // bytes
+    int out_px, out_row;                         // bytes
+};
+
+template <typename T, int CIN8, int CT, int KS, bool DUAL>
+struct LeanCfg {
+    static constexpr int ESZ = (int)sizeof(T);
+    static constexpr int TI = 16 + KS - 1;
+    static constexpr int PSRAW = CIN8 * 8 * ESZ;
+    static constexpr int PS = ((PSRAW / 16) % 2 == 0) ? PSRAW + 16 : PSRAW;
+    static constexpr int NPIX = TI * TI;
+    // the packed image is chunk-major and a chunk never straddles the two sources: dual = 2 chunks
+    static constexpr int NCH = DUAL ? 2 : 1;
+    static constexpr int C8H = CIN8 / NCH;                    // 8-channel groups per chunk
+    static constexpr int NG = KS * KS * C8H;                  // real 8-channel k-groups per chunk
+    static constexpr int NKSH = (NG + 3) / 4;                 // MFMA k-steps (32 k each) per chunk
+    static constexpr int NKS = NCH * NKSH;
+    static constexpr bool WREG = CT * NKS <= 8;               // weight fragments held in registers
+    static constexpr int WS = NKSH * 32 * ESZ + 16;           // LDS weight row stride (when !WREG), per chunk
+    static constexpr int IN_BYTES = ((NPIX * PS + 15) / 16) * 16;
+    static constexpr int LDS = IN_BYTES + (WREG ? 0 : NCH * CT * 16 * WS);
+};
+
+template <typename T, int CIN8, int CT, int KS, bool DUAL>
+__global__ __launch_bounds__(256) void conv_lean_kernel(const LeanArgs a) {
+    using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL>;
+    typedef typename Vec8<T>::type V8;
+    typedef typename Vec4<T>::type V4;
+    constexpr int ESZ = Cfg::ESZ, TI = Cfg::TI, PS = Cfg::PS, NKS = Cfg::NKS, NG = Cfg::NG, NKSH = Cfg::NKSH, C8H = Cfg::C8H;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const msau_conv_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int b = blockIdx.z, oy0 = blockIdx.y * 16, ox0 = blockIdx.x * 16;
+    constexpr int PAD = KS / 2;                                // SAME pad of an odd kernel
+    const int vy0 = oy0 - PAD, vx0 = ox0 - PAD;
+    const bool relu_in = d.flags & MSAU_CONV_RELU_IN;
+
+    // ---- weights: registers (small) or LDS
+    const T* wp = static_cast<const T*>(d.wpack);
+    V8 afr[Cfg::WREG ? CT : 1][Cfg::WREG ? NKS : 1];
+    if constexpr (Cfg::WREG) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                afr[ct][ks] = load8<T>(wp + ((size_t)(ks / NKSH) * (CT * 16) + ct * 16 + lr) * a.kchunk + (ks % NKSH) * 32 + lg * 8);
+    } else {
+        unsigned char* lds_w = smem + Cfg::IN_BYTES;
+        constexpr int WG8 = NKSH * 4;                          // 8-element groups per (chunk, row)
+        for (int idx = tid; idx < Cfg::NCH * CT * 16 * WG8; idx += 256) {
+            int r = idx / WG8, g8 = idx - r * WG8;             // r = chunk * rows + row: the packed image order
+            *reinterpret_cast<V8*>(lds_w + r * Cfg::WS + g8 * 8 * ESZ) = load8<T>(wp + (size_t)r * a.kchunk + g8 * 8);
+        }
+    }
+
+    // ---- stage the (16+KS-1)^2 halo tile; one source at a time so the base pointer stays scalar
+    auto stage = [&](const char* x, int in_row, int in_px, auto c8tag, int lds_cb) {
+        constexpr int C8 = decltype(c8tag)::value;            // 8-channel groups of this source
+        constexpr int NITEMS = Cfg::NPIX * C8;
+        constexpr int NIT = (NITEMS + 255) / 256;
+        const char* base = x + (long long)b * d.Hin * in_row;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256;
+            if ((it + 1) * 256 <= NITEMS || idx < NITEMS) {
+                const int pix = idx / C8, cg = idx - pix * C8;
+                const int iy = pix / TI, ix = pix - iy * TI;
+                const int vy = vy0 + iy, vx = vx0 + ix;
+                V8 v = zero8<T>();
+                if ((unsigned)vy < (unsigned)d.Hin && (unsigned)vx < (unsigned)d.Win) {
+                    v = *reinterpret_cast<const V8*>(base + (unsigned)(vy * in_row + vx * in_px + cg * 8 * ESZ));
+                    if (relu_in) v = relu8<T>(v);
+                }
+                *reinterpret_cast<V8*>(smem + pix * PS + lds_cb + cg * 8 * ESZ) = v;
+            }
+        }
+    };
+    if constexpr (DUAL) {
+        stage(static_cast<const char*>(d.x1), a.in_row1, a.in_px1, std::integral_constant<int, CIN8 / 2>{}, 0);
+        stage(static_cast<const char*>(d.x2), a.in_row2, a.in_px2, std::integral_constant<int, CIN8 / 2>{}, (CIN8 / 2) * 8 * ESZ);
+    } else {
+        stage(static_cast<const char*>(d.x1), a.in_row1, a.in_px1, std::integral_constant<int, CIN8>{}, 0);
+    }
+
+    // ---- per-lane LDS offsets of the k-groups this lane feeds (lane group lg of every k-step)
+    int koff[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int G = (ks % NKSH) * 4 + lg;                    // k-group inside chunk ks / NKSH
+        const int tap = G / C8H, cg = G - tap * C8H;
+        const int ky = tap / KS, kx = tap - ky * KS;
+        koff[ks] = G < NG ? (ky * TI + kx) * PS + ((ks / NKSH) * C8H + cg) * 8 * ESZ : 0;
+    }
+    const unsigned char* pixp = smem + ((wave * 4) * TI + lr) * PS;
+
+    f32x4 acc[CT][4];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const unsigned char* p = pixp + koff[ks];
+        V8 bfrag[4];
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) bfrag[pt] = *reinterpret_cast<const V8*>(p + pt * TI * PS);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            V8 af;
+            if constexpr (Cfg::WREG) af = afr[ct][ks];
+            else af = *reinterpret_cast<const V8*>(smem + Cfg::IN_BYTES + ((ks / NKSH) * (CT * 16) + ct * 16 + lr) * Cfg::WS +
+                                                   ((ks % NKSH) * 32 + lg * 8) * ESZ);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = mma8(af, bfrag[pt], acc[ct][pt]);
+        }
+    }
+
+    // ---- epilogue: lane (pixel lr of row ty, q = lg) owns channels q*CT*4 + ct*4 + {0..3}
+    const int flags = d.flags;
+    const int Cout = d.Cout;
+    const int oyw = oy0 + wave * 4;
+    if (ox0 + lr >= d.Wout) return;
+    char* y = static_cast<char*>(d.y) + ((long long)(b * d.Hout + oyw)) * a.out_row + (long long)ox0 * a.out_px;
+    const long long delta_add = static_cast<const char*>(d.add) - static_cast<const char*>(d.y);
+    const long long delta_ma = static_cast<const char*>(d.mask_a) - static_cast<const char*>(d.y);
+    const long long delta_mb = static_cast<const char*>(d.mask_b) - static_cast<const char*>(d.y);
+    const int lane_out = lr * a.out_px + lg * (CT * 4) * ESZ;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int co = lg * (CT * 4) + ct * 4;
+        if (co >= Cout) continue;
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + co);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            if (oyw + pt < d.Hout) {                               // scalar
+                char* yp = y + (unsigned)(lane_out + ct * 4 * ESZ + pt * a.out_row);
+                f32x4 v = acc[ct][pt] + bv;
+                if (flags & (MSAU_CONV_MASK_A | MSAU_CONV_ADD | MSAU_CONV_ACCUM | MSAU_CONV_RELU_OUT | MSAU_CONV_MASK_B)) {
+                    if (flags & MSAU_CONV_MASK_A) {
+                        V4 m = *reinterpret_cast<const V4*>(yp + delta_ma);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : 0.f;
+                    }
+                    if (flags & MSAU_CONV_ADD) {
+                        V4 r = *reinterpret_cast<const V4*>(yp + delta_add);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                    }
+                    if (flags & MSAU_CONV_ACCUM) {
+                        V4 r = *reinterpret_cast<const V4*>(yp);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                    }
+                    if (flags & MSAU_CONV_RELU_OUT) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                    }
+                    if (flags & MSAU_CONV_MASK_B) {
+                        V4 m = *reinterpret_cast<const V4*>(yp + delta_mb);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : 0.f;
+                    }
+                }
+                V4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
+                *reinterpret_cast<V4*>(yp) = o;
+            }
+        }
+    }
+}
+
+template <typename T, int CIN8, int CT, int KS, bool DUAL>
+int launch_lean(hipStream_t s, const LeanArgs& a) {
+    using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL>;
+    static bool attr_set = false;
+    if (!attr_set && Cfg::LDS > 60 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<T, CIN8, CT, KS, DUAL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
+        if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_lean: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(a.d.Wout, 16), cdiv(a.d.Hout, 16), a.d.B);
+    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL>), grid, dim3(256), Cfg::LDS, s, a);
+    MSAU_CHECK_LAUNCH("conv_lean_kernel");
+    return 1;
+}
+
+template <typename T, int CIN8, int KS, bool DUAL>
+int lean_ct(hipStream_t s, const LeanArgs& a, int CT) {
+    if (CT == 1) return launch_lean<T, CIN8, 1, KS, DUAL>(s, a);
+    if (CT == 2) return launch_lean<T, CIN8, 2, KS, DUAL>(s, a);
+    return 0;
+}
+
+template <typename T, int KS>
+int lean_cin(hipStream_t s, const LeanArgs& a, int cin8, bool dual, int CT) {
+    if (!dual) {
+        switch (cin8) {
+            case 1: return lean_ct<T, 1, KS, false>(s, a, CT);
+            case 2: return lean_ct<T, 2, KS, false>(s, a, CT);
+            case 4: return lean_ct<T, 4, KS, false>(s, a, CT);
+            case 8: return lean_ct<T, 8, KS, false>(s, a, CT);
+            default: return 0;
+        }
+    }
+    switch (cin8) {
+        case 2: return lean_ct<T, 2, KS, true>(s, a, CT);
+        case 4: return lean_ct<T, 4, KS, true>(s, a, CT);
+        case 8: return lean_ct<T, 8, KS, true>(s, a, CT);
+        default: return 0;
+    }
+}
+
+}  // namespace
+
+// Returns 1 if a lean instance handled the launch, 0 if the caller must use the generic kernel,
+// < 0 on error.  `kchunk` / `nchunks` / `CT` come from the generic geometry (same packed image).
+int msau_conv_lean_applicable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
+    if (d->stride != 1 || d->ups != 1 || d->dil != 1 || d->KH != d->KW || (d->KH != 1 && d->KH != 3)) return 0;
+    if (nchunks != (d->C2 ? 2 : 1)) return 0;                // one chunk per source (same packed image as conv.hip)
+    if (d->Hin != d->Hout || d->Win != d->Wout) return 0;
+    if (d->pad_t != d->KH / 2 || d->pad_l != d->KW / 2) return 0;
+    if (CT > 2) return 0;
+    if ((int64_t)d->B * cdiv(d->Hout, 16) * cdiv(d->Wout, 16) < 512) return 0;
+    const bool dual = d->C2 != 0;
+    if (dual && d->C1 != d->C2) return 0;
+    const int cin8 = (d->C1 + d->C2) / 8;
+    const int esz = dtype == MSAU_F32 ? 4 : 2;
+    if ((int64_t)d->Hin * d->Win * (d->C1 > d->C2 ? d->C1 : d->C2) * esz >= (1ll << 31)) return 0;   // 32-bit lane offsets
+    if ((int64_t)d->Wout * d->Cout * esz * 20 >= (1ll << 31)) return 0;
+    if (cin8 != 1 && cin8 != 2 && cin8 != 4 && cin8 != 8) return 0;
+    if (dual && cin8 < 2) return 0;
+    return 1;
+}
+
+int msau_conv_lean_try(hipStream_t s, int dtype, const msau_conv_desc* d, int kchunk, int nchunks, int CT) {
+    if (!msau_conv_lean_applicable(dtype, d, nchunks, CT)) return 0;
+    const bool dual = d->C2 != 0;
+    const int cin8 = (d->C1 + d->C2) / 8;
+    const int esz = dtype == MSAU_F32 ? 4 : 2;
+    LeanArgs a;
+    a.d = *d;
+    a.kchunk = kchunk;
+    a.in_px1 = d->C1 * esz; a.in_px2 = d->C2 * esz;
+    a.in_row1 = d->Win * a.in_px1; a.in_row2 = d->Win * a.in_px2;
+    a.out_px = d->Cout * esz; a.out_row = d->Wout * a.out_px;
+    if (dtype == MSAU_F32) return d->KH == 3 ? lean_cin<float, 3>(s, a, cin8, dual, CT) : lean_cin<float, 1>(s, a, cin8, dual, CT);
+    return d->KH == 3 ? lean_cin<bf16_t, 3>(s, a, cin8, dual, CT) : lean_cin<bf16_t, 1>(s, a, cin8, dual, CT);
+}

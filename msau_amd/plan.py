@@ -278,12 +278,16 @@ class ConvOp(Op):
             taps * cin_real * self.out.C
 
         def conv_meta(d):
-            info = (L.i32 * 6)()
+            info = (L.i32 * 8)()
             L.call("msau_conv2d_launch_info", P.dtype, C.byref(d), info)
             nin = d.B * d.Hin * d.Win * (d.C1 + d.C2)
             nout = d.B * d.Hout * d.Wout * d.Cout
             extra = sum(1 for f in (L.CONV_ADD, L.CONV_ACCUM, L.CONV_MASK_A, L.CONV_MASK_B) if d.flags & f)
-            return f"conv_kernel<{T},CT{info[0]},PT{info[1]}>", (nin + nout * (1 + extra)) * esz
+            if info[6]:
+                name = f"conv_lean_kernel<{T},CIN{d.C1 + d.C2},CT{info[0]},K{d.KH}{',dual' if d.C2 else ''}>"
+            else:
+                name = f"conv_kernel<{T},CT{info[0]},PT{info[1]}>"
+            return name, (nin + nout * (1 + extra)) * esz
 
         self.fkey, self.fbytes = conv_meta(self.fdesc)
         P.note_launch(self.fkey, self.fbytes, self.flops)
