@@ -129,6 +129,8 @@ typedef struct {
     int32_t kext;               /* columns per row of a slab: nchunks*taps*cch + 8, rounded to 16   */
     int32_t max_slabs;          /* number of pixel tiles (upper bound for nslabs)                   */
     int64_t slab_bytes;         /* bytes of ONE slab                                                */
+    int32_t lean;               /* 1: a compile-time-specialised instance (wgrad_lean.hip) takes it */
+    int32_t reserved;
 } msau_wgrad_geom;
 
 int msau_wgrad_geometry(int dtype, const msau_wgrad_desc* d, msau_wgrad_geom* out);

@@ -35,7 +35,8 @@ class WgradDesc(C.Structure):
 
 
 class WgradGeom(C.Structure):
-    _fields_ = [("cch", i32), ("nchunks", i32), ("kext", i32), ("max_slabs", i32), ("slab_bytes", i64)]
+    _fields_ = [("cch", i32), ("nchunks", i32), ("kext", i32), ("max_slabs", i32), ("slab_bytes", i64),
+                ("lean", i32), ("reserved", i32)]
 
 
 class PackEntry(C.Structure):

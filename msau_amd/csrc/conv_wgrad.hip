@@ -284,6 +284,10 @@ int launch_wgrad_ct(hipStream_t s, const WArgs& a, int CTN, int NKW, dim3 grid, 
 
 }  // namespace
 
+// wgrad_lean.hip: compile-time-specialised instances
+int msau_wgrad_lean_applicable(int dtype, const msau_wgrad_desc* d, int cch);
+int msau_wgrad_lean_try(hipStream_t s, int dtype, const msau_wgrad_desc* d, int cch, int nchunks, int kextc);
+
 extern "C" int msau_wgrad_geometry(int dtype, const msau_wgrad_desc* d, msau_wgrad_geom* out) {
     WGeom g;
     int rc = wgrad_geom(dtype, d, &g);
@@ -291,6 +295,8 @@ extern "C" int msau_wgrad_geometry(int dtype, const msau_wgrad_desc* d, msau_wgr
     out->cch = g.cch; out->nchunks = g.nchunks; out->kext = g.kextc;
     out->max_slabs = d->B * cdiv(d->Hout, 16) * cdiv(d->Wout, 16);
     out->slab_bytes = (int64_t)g.nchunks * d->Cout * g.kextc * 4;
+    out->lean = msau_wgrad_lean_applicable(dtype, d, g.cch);
+    out->reserved = 0;
     return 0;
 }
 
@@ -308,6 +314,8 @@ extern "C" int msau_conv2d_wgrad(void* stream, int dtype, const msau_wgrad_desc*
     a.tiles_x = cdiv(d->Wout, 16); a.tiles_y = cdiv(d->Hout, 16);
     a.ntiles = d->B * a.tiles_x * a.tiles_y;
     MSAU_CHECK_ARG(d->nslabs >= 1 && d->nslabs <= a.ntiles, "wgrad: nslabs %d not in [1,%d]", d->nslabs, a.ntiles);
+    rc = msau_wgrad_lean_try(static_cast<hipStream_t>(stream), dtype, d, g.cch, g.nchunks, g.kextc);
+    if (rc != 0) return rc < 0 ? rc : 0;
     // CTN as instantiated (3 -> 4)
     int CTN = g.CTN == 3 ? 4 : (g.CTN > 4 ? 8 : g.CTN);
     MSAU_CHECK_ARG(!(CTN == 8 && g.NKW > 5), "wgrad: Cout %d with K %d unsupported", d->Cout, g.kextc);

@@ -1,0 +1,258 @@
+// Lean instances of the weight-gradient kernel (see conv_wgrad.hip for the algorithm): stride 1, no
+// dilation, k in {1,3}, channel counts per chunk known at compile time, so every divisor, LDS stride
+// and tap offset is a constant and the column-group offsets live in registers instead of an LDS table.
+// Same slab layout as wgrad_kernel: slabs[workgroup][chunk][Cout][kext], k = [tap][channel] + ones column.
+#include "msau_common.h"
+
+namespace {
+
+struct WLeanArgs {
+    msau_wgrad_desc d;
+    int kextc, nchunks;
+    int tiles_x, tiles_y, ntiles;
+    unsigned mag_tx, mag_ty;                     // ceil(2^32 / tiles_x), ceil(2^32 / tiles_y)
+};
+
+#define WL_ABS 0x40000000
+
+typedef __attribute__((address_space(3))) bf16x4* lds_v4;
+
+template <typename T, int C8, int CO8, int KS>
+struct WLeanCfg {
+    static constexpr int ESZ = (int)sizeof(T);
+    static constexpr int TI = 16 + KS - 1;
+    static constexpr int PSX = ((C8 * 8 * ESZ / 16) % 2 == 0) ? C8 * 8 * ESZ + 16 : C8 * 8 * ESZ;
+    static constexpr int PSG = ((CO8 * 8 * ESZ / 16) % 2 == 0) ? CO8 * 8 * ESZ + 16 : CO8 * 8 * ESZ;
+    static constexpr int KREAL = KS * KS * C8 * 8;
+    static constexpr int KEXT = ((KREAL + 8 + 15) / 16) * 16;
+    static constexpr int NKT = KEXT / 16;
+    static constexpr int NKW = (NKT + 3) / 4;
+    static constexpr int CTN = (CO8 + 1) / 2;
+    static constexpr int X_BYTES = ((TI * TI * PSX + 15) / 16) * 16;
+    static constexpr int G_BYTES = 256 * PSG;
+    static constexpr int LDS = X_BYTES + G_BYTES + 64;
+};
+
+template <typename T, int C8, int CO8, int KS>
+__global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanArgs a) {
+    using Cfg = WLeanCfg<T, C8, CO8, KS>;
+    typedef typename Vec8<T>::type V8;
+    constexpr int ESZ = Cfg::ESZ, TI = Cfg::TI, PSX = Cfg::PSX, PSG = Cfg::PSG, NKT = Cfg::NKT, NKW = Cfg::NKW, CTN = Cfg::CTN;
+    constexpr int PAD = KS / 2;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* lds_x = smem;
+    unsigned char* lds_g = smem + Cfg::X_BYTES;
+    constexpr int ONES = Cfg::X_BYTES + Cfg::G_BYTES;            // {1,0,0,0,0,0,0,0} of T
+
+    const msau_wgrad_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int chunk = blockIdx.y;
+    const bool relu_in = d.flags & MSAU_CONV_RELU_IN;
+
+    // source of this chunk (a chunk never straddles the two sources)
+    const int c0 = chunk * C8 * 8;                                // first stored channel of the chunk
+    const bool second = d.C2 != 0 && c0 >= d.C1;
+    const char* xsrc = static_cast<const char*>(second ? d.x2 : d.x1);
+    const int Cx = second ? d.C2 : d.C1;
+    const int cb = (second ? c0 - d.C1 : c0) * ESZ;               // byte offset of the chunk inside a source pixel
+    const int in_px = Cx * ESZ, in_row = d.Win * in_px;
+    const int g_px = d.Cout * ESZ, g_row = d.Wout * g_px;
+
+    if (tid < 8) reinterpret_cast<T*>(smem + ONES)[tid] = (T)(tid == 0 ? 1.0f : 0.0f);
+
+    // column-group byte offsets (relative to the pixel's slot in lds_x) for the k-tiles this wave owns
+    constexpr int NB = sizeof(T) == 2 ? 1 : 1;
+    int coloff[NKW];
+#pragma unroll
+    for (int i = 0; i < NKW; ++i) {
+        const int nkt = wave + 4 * i;
+        const int k = nkt * 16 + (sizeof(T) == 2 ? (li & 3) * 4 : (li >> 2) * 4);     // first k of the lane's 4-column group
+        int off;
+        if (k < Cfg::KREAL) {
+            const int tap = k / (C8 * 8), c = k - tap * (C8 * 8);
+            const int ky = tap / KS, kx = tap - ky * KS;
+            off = (ky * TI + kx) * PSX + c * ESZ;
+        } else if (k == Cfg::KREAL) off = WL_ABS | ONES;
+        else off = WL_ABS | (ONES + 4 * ESZ);
+        if (sizeof(T) == 4) off += (li & 3) * 4;
+        coloff[i] = off;
+    }
+    (void)NB;
+
+    f32x4 acc[NKW][CTN];
+#pragma unroll
+    for (int i = 0; i < NKW; ++i)
+#pragma unroll
+        for (int ct = 0; ct < CTN; ++ct) acc[i][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int t1 = a.tiles_x > 1 ? __umulhi((unsigned)tile, a.mag_tx) : tile;
+        const int txi = tile - t1 * a.tiles_x;
+        const int b = a.tiles_y > 1 ? __umulhi((unsigned)t1, a.mag_ty) : t1;
+        const int tyi = t1 - b * a.tiles_y;
+        const int oy0 = tyi * 16, ox0 = txi * 16;
+        const int vy0 = oy0 - PAD, vx0 = ox0 - PAD;
+        __syncthreads();
+        {   // x halo tile
+            constexpr int NITEMS = TI * TI * C8, NIT = (NITEMS + 255) / 256;
+            const char* base = xsrc + (long long)b * d.Hin * in_row + cb;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * 256;
+                if ((it + 1) * 256 <= NITEMS || idx < NITEMS) {
+                    const int pix = idx / C8, cg = idx - pix * C8;
+                    const int iy = pix / TI, ix = pix - iy * TI;
+                    const int vy = vy0 + iy, vx = vx0 + ix;
+                    V8 v = zero8<T>();
+                    if ((unsigned)vy < (unsigned)d.Hin && (unsigned)vx < (unsigned)d.Win) {
+                        v = *reinterpret_cast<const V8*>(base + (unsigned)(vy * in_row + vx * in_px + cg * 8 * ESZ));
+                        if (relu_in) v = relu8<T>(v);
+                    }
+                    *reinterpret_cast<V8*>(lds_x + pix * PSX + cg * 8 * ESZ) = v;
+                }
+            }
+        }
+        {   // g tile: pixels outside the image contribute 0
+            constexpr int NITEMS = 256 * CO8, NIT = NITEMS / 256;
+            const char* base = static_cast<const char*>(d.g) + (long long)b * d.Hout * g_row;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * 256;
+                const int m = idx / CO8, cg = idx - m * CO8;
+                const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
+                V8 v = zero8<T>();
+                if (oy < d.Hout && ox < d.Wout) v = *reinterpret_cast<const V8*>(base + (unsigned)(oy * g_row + ox * g_px + cg * 8 * ESZ));
+                *reinterpret_cast<V8*>(lds_g + m * PSG + cg * 8 * ESZ) = v;
+            }
+        }
+        __syncthreads();
+
+        if constexpr (sizeof(T) == 2) {
+            const int q = li >> 2, p = li & 3;
+#pragma unroll
+            for (int blk = 0; blk < 8; ++blk) {
+                // pixels m0 = blk*32 + lg*8 + q (+4): row = blk*2 + (lg>>1), col = (lg&1)*8 + q (+4)
+                const int row = blk * 2 + (lg >> 1), col = (lg & 1) * 8 + q;
+                const unsigned char* ga = lds_g + (row * 16 + col) * PSG + 4 * p * 2;
+                bf16x8 afrag[CTN];
+#pragma unroll
+                for (int ct = 0; ct < CTN; ++ct) {
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(ga + ct * 32));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(ga + 4 * PSG + ct * 32));
+                    afrag[ct] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                const int pb0 = (row * TI + col) * PSX;
+#pragma unroll
+                for (int i = 0; i < NKW; ++i) {
+                    if (wave + 4 * i < NKT) {                          // wave-uniform
+                        const int e = coloff[i];
+                        const int o0 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + e;
+                        const int o1 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + 4 * PSX + e;
+                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o0));
+                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o1));
+                        bf16x8 bfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                        for (int ct = 0; ct < CTN; ++ct)
+                            acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[ct], bfrag, acc[i][ct], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            for (int step = 0; step < 64; ++step) {
+                const int m = step * 4 + lg;
+                float afrag[CTN];
+#pragma unroll
+                for (int ct = 0; ct < CTN; ++ct) afrag[ct] = *reinterpret_cast<const float*>(lds_g + m * PSG + (ct * 16 + li) * 4);
+                const int pb = ((m >> 4) * TI + (m & 15)) * PSX;
+#pragma unroll
+                for (int i = 0; i < NKW; ++i) {
+                    if (wave + 4 * i < NKT) {
+                        const int e = coloff[i];
+                        const float bv = *reinterpret_cast<const float*>(smem + ((e & WL_ABS) ? (e & ~WL_ABS) : pb + e));
+#pragma unroll
+                        for (int ct = 0; ct < CTN; ++ct)
+                            acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ct], bv, acc[i][ct], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    float* slab = d.slabs + ((size_t)blockIdx.x * a.nchunks + chunk) * d.Cout * a.kextc;
+#pragma unroll
+    for (int i = 0; i < NKW; ++i) {
+        const int nkt = wave + 4 * i;
+        if (nkt >= NKT) continue;
+#pragma unroll
+        for (int ct = 0; ct < CTN; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = ct * 16 + lg * 4 + j;
+                if (co < d.Cout) slab[(size_t)co * a.kextc + nkt * 16 + li] = acc[i][ct][j];
+            }
+    }
+}
+
+template <typename T, int C8, int CO8, int KS>
+int launch_wlean(hipStream_t s, const WLeanArgs& a) {
+    using Cfg = WLeanCfg<T, C8, CO8, KS>;
+    if (Cfg::KEXT != a.kextc) return 0;                              // geometry disagrees with the generic planner
+    static bool attr_set = false;
+    if (!attr_set && Cfg::LDS > 60 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lean_kernel<T, C8, CO8, KS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
+        if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "wgrad_lean: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_lean_kernel<T, C8, CO8, KS>), dim3(a.d.nslabs, a.nchunks), dim3(256), Cfg::LDS, s, a);
+    MSAU_CHECK_LAUNCH("wgrad_lean_kernel");
+    return 1;
+}
+
+template <typename T, int KS>
+int wlean_dispatch(hipStream_t s, const WLeanArgs& a, int c8, int co8) {
+#define WL_CASE(C, O) if (c8 == C && co8 == O) return launch_wlean<T, C, O, KS>(s, a);
+    WL_CASE(1, 1) WL_CASE(1, 2) WL_CASE(2, 1) WL_CASE(2, 2) WL_CASE(2, 4) WL_CASE(4, 2) WL_CASE(4, 4) WL_CASE(8, 1)
+    WL_CASE(4, 8) WL_CASE(8, 4) WL_CASE(8, 8)
+#undef WL_CASE
+    return 0;
+}
+
+}  // namespace
+
+static const int kLeanShapes[][2] = {{1, 1}, {1, 2}, {2, 1}, {2, 2}, {2, 4}, {4, 2}, {4, 4}, {8, 1}, {4, 8}, {8, 4}, {8, 8}};
+
+int msau_wgrad_lean_applicable(int dtype, const msau_wgrad_desc* d, int cch) {
+    if (d->stride != 1 || d->dil != 1 || d->KH != d->KW || (d->KH != 1 && d->KH != 3)) return 0;
+    if (d->Hin != d->Hout || d->Win != d->Wout || d->pad_t != d->KH / 2 || d->pad_l != d->KW / 2) return 0;
+    const int esz = dtype == MSAU_F32 ? 4 : 2;
+    if ((int64_t)d->Hin * d->Win * (d->C1 > d->C2 ? d->C1 : d->C2) * esz >= (1ll << 31)) return 0;
+    if ((int64_t)d->Hout * d->Wout * d->Cout * esz >= (1ll << 31)) return 0;
+    const int tx = cdiv(d->Wout, 16), ty = cdiv(d->Hout, 16);
+    if ((int64_t)d->B * tx * ty >= (1 << 20) || tx >= 4096 || ty >= 4096) return 0;
+    for (auto& sh : kLeanShapes)
+        if (sh[0] == cch / 8 && sh[1] == d->Cout / 8 && cch % 8 == 0) return 1;
+    return 0;
+}
+
+// 1 = handled, 0 = not applicable (use the generic kernel), < 0 = error.  cch/nchunks/kextc are the generic geometry.
+int msau_wgrad_lean_try(hipStream_t s, int dtype, const msau_wgrad_desc* d, int cch, int nchunks, int kextc) {
+    if (!msau_wgrad_lean_applicable(dtype, d, cch)) return 0;
+    if (d->stride != 1 || d->dil != 1 || d->KH != d->KW || (d->KH != 1 && d->KH != 3)) return 0;
+    if (d->Hin != d->Hout || d->Win != d->Wout || d->pad_t != d->KH / 2 || d->pad_l != d->KW / 2) return 0;
+    const int esz = dtype == MSAU_F32 ? 4 : 2;
+    if ((int64_t)d->Hin * d->Win * (d->C1 > d->C2 ? d->C1 : d->C2) * esz >= (1ll << 31)) return 0;
+    if ((int64_t)d->Hout * d->Wout * d->Cout * esz >= (1ll << 31)) return 0;
+    WLeanArgs a;
+    a.d = *d;
+    a.kextc = kextc; a.nchunks = nchunks;
+    a.tiles_x = cdiv(d->Wout, 16); a.tiles_y = cdiv(d->Hout, 16);
+    a.ntiles = d->B * a.tiles_x * a.tiles_y;
+    if (a.ntiles >= (1 << 20) || a.tiles_x >= 4096 || a.tiles_y >= 4096) return 0;
+    a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
+    a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
+    if (dtype == MSAU_F32) return d->KH == 3 ? wlean_dispatch<float, 3>(s, a, cch / 8, d->Cout / 8) : wlean_dispatch<float, 1>(s, a, cch / 8, d->Cout / 8);
+    return d->KH == 3 ? wlean_dispatch<bf16_t, 3>(s, a, cch / 8, d->Cout / 8) : wlean_dispatch<bf16_t, 1>(s, a, cch / 8, d->Cout / 8);
+}

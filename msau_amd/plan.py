@@ -304,7 +304,10 @@ class ConvOp(Op):
             ctn = 4 if ctn == 3 else (8 if ctn > 4 else ctn)
             nkw = -(-(wg.kext // 16) // 4)
             nkw = 1 if nkw <= 1 else 2 if nkw <= 2 else 3 if nkw <= 3 else 5 if nkw <= 5 else 10
-            self.wkey = f"wgrad_kernel<{T},CT{ctn},NK{nkw}>"
+            if wg.lean:
+                self.wkey = f"wgrad_lean_kernel<{T},C{wg.cch},CO{w.Cout},K{w.KH}>"
+            else:
+                self.wkey = f"wgrad_kernel<{T},CT{ctn},NK{nkw}>"
             self.wbytes = (w.B * w.Hin * w.Win * (w.C1 + w.C2) * wg.nchunks // wg.nchunks + w.B * w.Hout * w.Wout * w.Cout) * esz \
                 + w.nslabs * wg.slab_bytes
             P.note_launch(self.wkey, self.wbytes, self.flops)
