@@ -49,8 +49,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(const LeanArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lg = lane >> 4;
     const int b = blockIdx.z, oy0 = blockIdx.y * 16, ox0 = blockIdx.x * 16;
-    constexpr int PAD = KS / 2;                                // SAME pad of an odd kernel
-    const int vy0 = oy0 - PAD, vx0 = ox0 - PAD;
+    const int vy0 = oy0 - d.pad_t, vx0 = ox0 - d.pad_l;       // forward: SAME pad; data gradient: (k-1) - pad
     const bool relu_in = d.flags & MSAU_CONV_RELU_IN;
 
     // ---- weights: registers (small) or LDS
@@ -238,12 +237,13 @@ int lean_cin(hipStream_t s, const LeanArgs& a, int cin8, bool dual, int CT) {
 // Returns 1 if a lean instance handled the launch, 0 if the caller must use the generic kernel,
 // < 0 on error.  `kchunk` / `nchunks` / `CT` come from the generic geometry (same packed image).
 int msau_conv_lean_applicable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
-    if (d->stride != 1 || d->ups != 1 || d->dil != 1 || d->KH != d->KW || (d->KH != 1 && d->KH != 3)) return 0;
+    if (d->stride != 1 || d->ups != 1 || d->dil != 1 || d->KH != d->KW || (d->KH != 1 && d->KH != 3 && d->KH != 4)) return 0;
     if (nchunks != (d->C2 ? 2 : 1)) return 0;                // one chunk per source (same packed image as conv.hip)
     if (d->Hin != d->Hout || d->Win != d->Wout) return 0;
-    if (d->pad_t != d->KH / 2 || d->pad_l != d->KW / 2) return 0;
+    if (d->pad_t < 0 || d->pad_l < 0 || d->pad_t >= d->KH || d->pad_l >= d->KW) return 0;
     if (CT > 2) return 0;
-    if ((int64_t)d->B * cdiv(d->Hout, 16) * cdiv(d->Wout, 16) < 512) return 0;
+    if (d->KH == 4 && ((d->C1 + d->C2) != 8 || d->C2)) return 0;           // only the 8-channel end conv / its data gradient
+    if ((int64_t)d->B * cdiv(d->Hout, 16) * cdiv(d->Wout, 16) < 256) return 0;
     const bool dual = d->C2 != 0;
     if (dual && d->C1 != d->C2) return 0;
     const int cin8 = (d->C1 + d->C2) / 8;
@@ -266,6 +266,7 @@ int msau_conv_lean_try(hipStream_t s, int dtype, const msau_conv_desc* d, int kc
     a.in_px1 = d->C1 * esz; a.in_px2 = d->C2 * esz;
     a.in_row1 = d->Win * a.in_px1; a.in_row2 = d->Win * a.in_px2;
     a.out_px = d->Cout * esz; a.out_row = d->Wout * a.out_px;
+    if (d->KH == 4) return dtype == MSAU_F32 ? lean_ct<float, 1, 4, false>(s, a, CT) : lean_ct<bf16_t, 1, 4, false>(s, a, CT);
     if (dtype == MSAU_F32) return d->KH == 3 ? lean_cin<float, 3>(s, a, cin8, dual, CT) : lean_cin<float, 1>(s, a, cin8, dual, CT);
     return d->KH == 3 ? lean_cin<bf16_t, 3>(s, a, cin8, dual, CT) : lean_cin<bf16_t, 1>(s, a, cin8, dual, CT);
 }

@@ -38,7 +38,6 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanArgs a) {
     using Cfg = WLeanCfg<T, C8, CO8, KS>;
     typedef typename Vec8<T>::type V8;
     constexpr int ESZ = Cfg::ESZ, TI = Cfg::TI, PSX = Cfg::PSX, PSG = Cfg::PSG, NKT = Cfg::NKT, NKW = Cfg::NKW, CTN = Cfg::CTN;
-    constexpr int PAD = KS / 2;
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* lds_x = smem;
     unsigned char* lds_g = smem + Cfg::X_BYTES;
@@ -93,7 +92,7 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanArgs a) {
         const int b = a.tiles_y > 1 ? __umulhi((unsigned)t1, a.mag_ty) : t1;
         const int tyi = t1 - b * a.tiles_y;
         const int oy0 = tyi * 16, ox0 = txi * 16;
-        const int vy0 = oy0 - PAD, vx0 = ox0 - PAD;
+        const int vy0 = oy0 - d.pad_t, vx0 = ox0 - d.pad_l;
         __syncthreads();
         {   // x halo tile
             constexpr int NITEMS = TI * TI * C8, NIT = (NITEMS + 255) / 256;
@@ -225,8 +224,9 @@ int wlean_dispatch(hipStream_t s, const WLeanArgs& a, int c8, int co8) {
 static const int kLeanShapes[][2] = {{1, 1}, {1, 2}, {2, 1}, {2, 2}, {2, 4}, {4, 2}, {4, 4}, {8, 1}, {4, 8}, {8, 4}, {8, 8}};
 
 int msau_wgrad_lean_applicable(int dtype, const msau_wgrad_desc* d, int cch) {
-    if (d->stride != 1 || d->dil != 1 || d->KH != d->KW || (d->KH != 1 && d->KH != 3)) return 0;
-    if (d->Hin != d->Hout || d->Win != d->Wout || d->pad_t != d->KH / 2 || d->pad_l != d->KW / 2) return 0;
+    if (d->stride != 1 || d->dil != 1 || d->KH != d->KW || (d->KH != 1 && d->KH != 3 && d->KH != 4)) return 0;
+    if (d->Hin != d->Hout || d->Win != d->Wout || d->pad_t < 0 || d->pad_l < 0 || d->pad_t >= d->KH || d->pad_l >= d->KW) return 0;
+    if (d->KH == 4 && !(cch == 8 && d->Cout == 8)) return 0;
     const int esz = dtype == MSAU_F32 ? 4 : 2;
     if ((int64_t)d->Hin * d->Win * (d->C1 > d->C2 ? d->C1 : d->C2) * esz >= (1ll << 31)) return 0;
     if ((int64_t)d->Hout * d->Wout * d->Cout * esz >= (1ll << 31)) return 0;
@@ -240,19 +240,14 @@ int msau_wgrad_lean_applicable(int dtype, const msau_wgrad_desc* d, int cch) {
 // 1 = handled, 0 = not applicable (use the generic kernel), < 0 = error.  cch/nchunks/kextc are the generic geometry.
 int msau_wgrad_lean_try(hipStream_t s, int dtype, const msau_wgrad_desc* d, int cch, int nchunks, int kextc) {
     if (!msau_wgrad_lean_applicable(dtype, d, cch)) return 0;
-    if (d->stride != 1 || d->dil != 1 || d->KH != d->KW || (d->KH != 1 && d->KH != 3)) return 0;
-    if (d->Hin != d->Hout || d->Win != d->Wout || d->pad_t != d->KH / 2 || d->pad_l != d->KW / 2) return 0;
-    const int esz = dtype == MSAU_F32 ? 4 : 2;
-    if ((int64_t)d->Hin * d->Win * (d->C1 > d->C2 ? d->C1 : d->C2) * esz >= (1ll << 31)) return 0;
-    if ((int64_t)d->Hout * d->Wout * d->Cout * esz >= (1ll << 31)) return 0;
     WLeanArgs a;
     a.d = *d;
     a.kextc = kextc; a.nchunks = nchunks;
     a.tiles_x = cdiv(d->Wout, 16); a.tiles_y = cdiv(d->Hout, 16);
     a.ntiles = d->B * a.tiles_x * a.tiles_y;
-    if (a.ntiles >= (1 << 20) || a.tiles_x >= 4096 || a.tiles_y >= 4096) return 0;
     a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
     a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
+    if (d->KH == 4) return dtype == MSAU_F32 ? launch_wlean<float, 1, 1, 4>(s, a) : launch_wlean<bf16_t, 1, 1, 4>(s, a);
     if (dtype == MSAU_F32) return d->KH == 3 ? wlean_dispatch<float, 3>(s, a, cch / 8, d->Cout / 8) : wlean_dispatch<float, 1>(s, a, cch / 8, d->Cout / 8);
     return d->KH == 3 ? wlean_dispatch<bf16_t, 3>(s, a, cch / 8, d->Cout / 8) : wlean_dispatch<bf16_t, 1>(s, a, cch / 8, d->Cout / 8);
 }
