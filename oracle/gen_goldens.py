@@ -177,7 +177,7 @@ def op_goldens():
     print("wrote ops", len(out), "arrays")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and os.environ.get("MSAU_GOLDEN_NET", "1") == "1":
     op_goldens()
     base = dict(n_class=5, scale_space_num=4, res_depth=2, featRoot=8, filter_size=3, pool_size=2, num_blocks=3)
     # G2: the hyper-parameters the reference instantiates (train_chargrid_funsd_msau.py:211-214), odd size
@@ -192,3 +192,84 @@ if __name__ == "__main__":
     net_golden("net_r3_s3_c8_21x35", dict(base, channels=8, res_depth=3, scale_space_num=3), 1, 21, 35, seed=15)
     # cfg 2 geometry checksum: 336x256x64, 3 stages, forward + loss + grads summaries
     net_golden("net_cfg2_336x256x64", dict(base, channels=64), 1, 336, 256, seed=16)
+
+
+# ---------------------------------------------------------------------------------------------
+# G3: chargrid pipeline goldens.  Synthetic FUNSD-format documents -> the reference's own
+# preprocessing + loader (modules it imports but never uses on this path are stubbed).
+# ---------------------------------------------------------------------------------------------
+def funsd_goldens():
+    import json, pickle, random, tempfile, types, shutil
+    for name in ("cv2", "skimage", "skimage.morphology", "tensorboardX", "sentence_transformers"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            if name == "skimage.morphology":
+                m.skeletonize = lambda *a, **k: None
+            if name == "sentence_transformers":
+                m.SentenceTransformer = lambda *a, **k: None
+            sys.modules[name] = m
+    with contextlib.redirect_stdout(io.StringIO()):
+        import funsd_preprocessing_word_level as RP          # reference
+        import data_generator_funsd_bert as RD               # reference
+    rng = random.Random(2024)
+    words_pool = ["Invoice", "No.", "12345", "Date:", "2019-03-07", "TOTAL", "$1,204.50", "Name", "J.", "Doe", "",
+                  "Qty", "7", "Address:", "42", "Elm", "St.", "fax", "(555)", "010-9999"]
+    labels_pool = ["question", "answer", "header", "other"]
+    out_dir = os.path.join(OUT, "funsd")
+    os.makedirs(os.path.join(out_dir, "train"), exist_ok=True)
+    os.makedirs(os.path.join(out_dir, "test"), exist_ok=True)
+
+    def make_doc(n_lines, seed):
+        r = random.Random(seed)
+        form, y = [], 30
+        for lid in range(n_lines):
+            x = r.randint(20, 200)
+            words, x0 = [], x
+            h = r.randint(14, 26)
+            for _ in range(r.randint(1, 4)):
+                t = r.choice(words_pool)
+                w = max(6, 9 * max(len(t), 1) + r.randint(-3, 6))
+                words.append({"box": [x0, y, x0 + w, y + h], "text": t})
+                x0 += w + r.randint(5, 14)
+            form.append({"box": [x, y, x0 - 5, y + h], "text": " ".join(w["text"] for w in words),
+                         "label": labels_pool[lid % 4] if lid < 4 else r.choice(labels_pool),
+                         "words": words, "linking": [], "id": lid})
+            y += h + r.randint(6, 30)
+        return {"form": form}
+
+    for split, seeds in (("train", (1, 2)), ("test", (3,))):
+        for s in seeds:
+            with open(os.path.join(out_dir, split, f"doc{s}.json"), "w") as fh:
+                json.dump(make_doc(6 + s, 100 + s), fh)
+    tmp = tempfile.mkdtemp()
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            train, inv = RP.get_preprocessed_list_word_msau(os.path.join(out_dir, "train"))
+            test, _ = RP.get_preprocessed_list_word_msau(os.path.join(out_dir, "test"), inv_dict_charset=inv)
+        res = {"charset": np.array(sorted(inv.keys()))}
+        for split, docs in (("train", train), ("test", test)):
+            docs.sort(key=lambda d: d["file_path"])
+            pickle.dump(docs, open(f"{split}.pkl", "wb"))
+        tr = RD.FUNSDCharGridDataLoaderBoxMaskBoxLabel("train.pkl")
+        te = RD.FUNSDCharGridDataLoaderBoxMaskBoxLabel("test.pkl", tr.labels)
+        res["labels_json"] = np.array(json.dumps(tr.labels))
+        for split, ds in (("train", tr), ("test", te)):
+            for i in range(len(ds)):
+                it = ds[i]
+                res[f"{split}{i}.mask"] = it["mask"].numpy().astype(np.uint8)
+                res[f"{split}{i}.label"] = it["label"].numpy().astype(np.uint8)
+                res[f"{split}{i}.nwords"] = len(it["ocr_values"])
+                res[f"{split}{i}.file"] = np.array(os.path.basename(ds.inp_list[i]["file_path"]))
+                res[f"{split}{i}.word_to_textline"] = np.array(ds.inp_list[i]["word_to_textline"])
+                res[f"{split}{i}.feat_sums"] = np.array([f.sum() for f in ds.inp_list[i]["charset_feature"]])
+        np.savez_compressed(os.path.join(out_dir, "chargrid.npz"), **res)
+        print("wrote funsd goldens", {k: v.shape for k, v in res.items() if k.endswith("mask")})
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp)
+
+
+if __name__ == "__main__" and os.environ.get("MSAU_GOLDEN_FUNSD", "1") == "1":
+    funsd_goldens()

@@ -171,3 +171,31 @@ def test_no_cpu_fallback():
     m = MSAUWrapper(13, 5, kw)
     with pytest.raises(RuntimeError):
         m(x)                                     # CPU tensor: refuse, do not fall back
+
+
+def test_train_script_end_to_end_on_synthetic_funsd(tmp_path, monkeypatch):
+    """funsd_preprocessing -> pickles -> loader -> train_chargrid_funsd_msau.train for 2 epochs (both loops):
+    the loss goes down and a reference-format checkpoint is written"""
+    import os, pickle, sys, types
+    from msau_amd.data.funsd import get_preprocessed_list_word_msau, FUNSDCharGridDataLoaderBoxMaskBoxLabel
+    import train_chargrid_funsd_msau as T
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "funsd")
+    monkeypatch.chdir(tmp_path)
+    train, inv = get_preprocessed_list_word_msau(os.path.join(G, "train"))
+    pickle.dump(train, open("train.pkl", "wb"))
+    ds = FUNSDCharGridDataLoaderBoxMaskBoxLabel("train.pkl")
+    items = [ds[i] for i in range(len(ds))]
+    for loop in ("engine", "reference"):
+        args = types.SimpleNamespace(loop=loop, lr=1e-3, clip=1.0, num_epochs=2, ckptdir=str(tmp_path / loop),
+                                     batch_size=1, bmname=None, dataset="invoice", method="GCN", hidden_dim=500,
+                                     output_dim=len(ds.labels) + 1)
+        m = MSAUWrapper(items[0]["mask"].shape[1], args.output_dim,
+                        dict(featRoot=8, scale_space_num=3, res_depth=2, final_act="softmax", dtype="fp32", seed=1)).cuda()
+        with torch.no_grad():
+            l0 = float(m.loss(*m(items[0]["mask"].cuda())[1:], items[0]["label"].long().cuda()))
+        T.train(items, m, args, val_dataset=items[:1], test_dataset=None, labels_map=ds.labels)
+        with torch.no_grad():
+            l1 = float(m.loss(*m(items[0]["mask"].cuda())[1:], items[0]["label"].long().cuda()))
+        assert l1 < l0, (loop, l0, l1)
+        ck = T.ckpt_filename(args.ckptdir, args, 0)
+        assert os.path.exists(ck) and set(torch.load(ck).keys()) == set(m.state_dict().keys())
