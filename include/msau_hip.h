@@ -250,6 +250,18 @@ int msau_clip_adam_step(void* stream, float* params, const float* grads, float* 
                         float* ws, int64_t n, float lr, float beta1, float beta2, float eps, float max_norm,
                         float grad_scale);
 
+/* ------------------------------------------------------------------------------------------
+ * Chargrid rasteriser (next row N1; data_generator_funsd_bert.py:149-186 get_box_mask_box_label_word).
+ * boxes: int32 [n][6] = {sample, y0, y1, x0, x1, value}, half-open, painted in order (later overwrites
+ * earlier), clipped to the grid.  owner: int32 [B][H][W] scratch (index of the last covering box, -1).
+ *   msau_raster_onehot : grid[b][y][x][c] = (c == value of the owning box); value < 0 paints zeros
+ *   msau_raster_labels : labels[b][y][x]  = value of the owning box, 0 where none
+ * ------------------------------------------------------------------------------------------ */
+int msau_raster_owner(void* stream, const int32_t* boxes, int n, int32_t* owner, int B, int H, int W);
+int msau_raster_onehot(void* stream, int dtype, const int32_t* boxes, const int32_t* owner, void* grid_nhwc,
+                       int B, int H, int W, int C, int Cs);
+int msau_raster_labels(void* stream, const int32_t* boxes, const int32_t* owner, int64_t* labels, int B, int H, int W);
+
 /* misc */
 int msau_fill_zero(void* stream, void* p, int64_t bytes);
 int msau_softmax_channels_nchw(void* stream, const float* logits, float* pred, int B, int C, int64_t hw);

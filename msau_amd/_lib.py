@@ -78,6 +78,9 @@ _SIGNATURES = {
     "msau_masked_ce": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, C.c_int, f32]),
     "msau_adam_ws_floats": (i64, [i64]),
     "msau_clip_adam_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32]),
+    "msau_raster_owner": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
+    "msau_raster_onehot": (C.c_int, [vp, C.c_int, vp, vp, vp] + [C.c_int] * 5),
+    "msau_raster_labels": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "msau_fill_zero": (C.c_int, [vp, vp, i64]),
     "msau_softmax_channels_nchw": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, i64]),
 }

@@ -1,0 +1,54 @@
+"""Device-side chargrid rasteriser: documents -> compact box lists (a few KB) -> one-hot NHWC
+grid + label mask painted by HIP kernels (msau_amd/csrc/raster.hip), bit-identical to the CPU painter
+`funsd.get_box_mask_box_label_word` (which is pinned to the reference)."""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from .funsd import chargrid_geometry, word_char_boxes
+
+
+def document_boxes(doc: dict, sample: int = 0) -> Tuple[np.ndarray, np.ndarray, int, int]:
+    """-> (char boxes [n,6], label boxes [m,6], H, W) for one preprocessed document.
+    char value = index of the character in the charset (argmax of its one-hot row), -1 if unknown
+    (an all-zero row: painting it clears whatever was underneath, as the reference does)."""
+    words, lines = doc["cells_word"], doc["cells"]
+    geo = chargrid_geometry(words)
+    chars = []
+    for wi, j, y0, y1, x0, x1 in word_char_boxes(words, geo):
+        row = doc["charset_feature"][wi][j]
+        v = int(np.argmax(row)) if row.any() else -1
+        chars.append((sample, y0, y1, x0, x1, v))
+    labs = []
+    for li, c in enumerate(lines):
+        x = int((c.x - geo["min_x"]) / geo["min_w"])
+        y = int((c.y - geo["min_y"]) / geo["min_h"])
+        w = max(int(c.w / geo["min_w"]), 1)
+        h = max(int(c.h / geo["min_h"]), 1)
+        labs.append((sample, y, y + h, x, x + w, int(doc["labels"][li]) + 1))
+    return (np.asarray(chars, np.int32).reshape(-1, 6), np.asarray(labs, np.int32).reshape(-1, 6), geo["H"], geo["W"])
+
+
+def rasterize(char_boxes: np.ndarray, label_boxes: np.ndarray, B: int, H: int, W: int, C: int,
+              dtype: str = "bf16", device="cuda") -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (grid [B,H,W,Cs] one-hot in `dtype` storage, labels int64 [B,H,W]) on `device`"""
+    dt = L.BF16 if dtype in ("bf16", "bfloat16") else L.F32
+    Cs = -(-C // 8) * 8
+    dev = torch.device(device)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    owner = torch.empty((B, H, W), dtype=torch.int32, device=dev)
+    grid = torch.empty((B, H, W, Cs), dtype=torch.bfloat16 if dt == L.BF16 else torch.float32, device=dev)
+    labels = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    for boxes, kind in ((char_boxes, "grid"), (label_boxes, "labels")):
+        bt = torch.from_numpy(np.ascontiguousarray(boxes, dtype=np.int32)).to(dev)
+        L.call("msau_raster_owner", s, bt.data_ptr() if len(boxes) else None, len(boxes), owner.data_ptr(), B, H, W)
+        if kind == "grid":
+            L.call("msau_raster_onehot", s, dt, bt.data_ptr(), owner.data_ptr(), grid.data_ptr(), B, H, W, C, Cs)
+        else:
+            L.call("msau_raster_labels", s, bt.data_ptr(), owner.data_ptr(), labels.data_ptr(), B, H, W)
+        torch.cuda.current_stream(dev).synchronize()          # `bt` must outlive the launches that read it
+    return grid, labels

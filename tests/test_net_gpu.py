@@ -197,5 +197,7 @@ def test_train_script_end_to_end_on_synthetic_funsd(tmp_path, monkeypatch):
         with torch.no_grad():
             l1 = float(m.loss(*m(items[0]["mask"].cuda())[1:], items[0]["label"].long().cuda()))
         assert l1 < l0, (loop, l0, l1)
-        ck = T.ckpt_filename(args.ckptdir, args, 0)
-        assert os.path.exists(ck) and set(torch.load(ck).keys()) == set(m.state_dict().keys())
+        # epoch 0 and the final dict checkpoint share one file name (the reference's own quirk,
+        # utils/io_utils.py:74-77: only epochs > 0 get a number): the final write wins
+        ck = torch.load(T.ckpt_filename(args.ckptdir, args, 0))
+        assert set(ck["model_state"].keys()) == set(m.state_dict().keys()) and ck["epoch"] == -1

@@ -290,3 +290,25 @@ def test_attention_mfma_bf16_vs_fp32_kernels(N, C):
     for nm, a, b in zip(("y", "stats", "df", "dg", "dh"), outs["mfma"], outs["ref"]):
         assert torch.isfinite(a).all(), nm
         assert rel_l2(a, b) < (1e-4 if nm == "stats" else 2e-2), (nm, rel_l2(a, b))
+
+
+def test_device_chargrid_rasteriser_matches_cpu_painter(tmp_path):
+    """N1: box lists painted on device == the CPU painter (bit exact), which is pinned to the reference"""
+    import os, pickle
+    from msau_amd.data import funsd as F
+    from msau_amd.data.raster import document_boxes, rasterize
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "funsd")
+    docs, inv = F.get_preprocessed_list_word_msau(os.path.join(G, "train"))
+    pickle.dump(docs, open(tmp_path / "t.pkl", "wb"))
+    ds = F.FUNSDCharGridDataLoaderBoxMaskBoxLabel(str(tmp_path / "t.pkl"), write_labels_file=False)
+    C = len(inv)
+    for i in range(len(ds)):
+        ref = ds[i]
+        cb, lb, H, W = document_boxes(ds.inp_list[i])
+        assert (H, W) == tuple(ref["label"].shape[1:])
+        for dtype in ("fp32", "bf16"):
+            grid, labels = rasterize(cb, lb, 1, H, W, C, dtype)
+            got = grid[..., :C].permute(0, 3, 1, 2).float().cpu()
+            assert torch.equal(got, ref["mask"]), (i, dtype)
+            assert float(grid[..., C:].abs().sum()) == 0.0
+            assert torch.equal(labels.cpu(), ref["label"].long())
