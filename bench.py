@@ -130,7 +130,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(os.environ.get("MSAU_DIST_BACKEND", "nccl"), device_id=dev)
 
     from msau_amd import _lib as L
     from msau_amd.model import MSAUWrapper, TrainEngine

@@ -1,0 +1,73 @@
+"""GPU, 2 ranks sharing cuda:0 over gloo (RCCL refuses two ranks on one device; the 8-GPU RCCL run is the
+driver's): the whole data-parallel TrainEngine -- HIP forward/backward per rank, bucketed all-reduce of the
+flat gradient, 1/world folded into clip+Adam -- must reproduce the single-process step on the global batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(scale_space_num=3, res_depth=2, featRoot=8, final_act="softmax", dtype="fp32", seed=21)
+
+
+def _data():
+    from oracle import msau_oracle as O
+    x, label = O.synthetic_batch(4, 13, 40, 36, 5, seed=5)
+    label[2] = 0                                   # a sample without labels
+    return x, label
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from msau_amd import MSAUWrapper, TrainEngine
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+      try:
+        torch.cuda.set_device(0)
+        m = MSAUWrapper(13, 5, KW).cuda()
+        eng = TrainEngine(m)
+        assert eng.world == world
+        x, label = _data()
+        lo = rank * 2
+        for _ in range(2):
+            loss = eng.step(x[lo:lo + 2].cuda(), label[lo:lo + 2].cuda())
+        torch.cuda.synchronize()
+        q.put((rank, float(loss), m.flat_parameters.cpu().numpy()))
+        dist.barrier()
+      except Exception as e:                                    # surface the worker's error in the parent
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_engine_equals_single_process_global_batch():
+    from msau_amd import MSAUWrapper, TrainEngine
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for g in got:
+        assert g[1] is not None, g[2]
+    got = [(r, l, torch.from_numpy(p)) for r, l, p in got]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m = MSAUWrapper(13, 5, KW).cuda()
+    eng = TrainEngine(m)
+    x, label = _data()
+    for _ in range(2):
+        loss = eng.step(x.cuda(), label.cuda())
+    ref = m.flat_parameters.cpu()
+    assert torch.equal(got[0][2], got[1][2])                               # replicas stay bit-identical
+    # two Adam steps of lr 1e-4 move a weight by <= 2e-4: the sharded run must agree to summation-order noise
+    assert float((got[0][2] - ref).abs().max()) < 2e-6
+    assert abs(0.5 * (got[0][1] + got[1][1]) - float(loss)) < 1e-5 * abs(float(loss))   # mean of local losses
