@@ -150,36 +150,43 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(const LeanArgs a) {
         if (co >= Cout) continue;
         f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
         if (d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + co);
+        // phase 1: issue every epilogue-operand load of the 4 rows back to back (one latency, not eight)
+        V4 e_ma[4], e_add[4], e_acc[4], e_mb[4];
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
             if (oyw + pt < d.Hout) {                               // scalar
+                const char* yp = y + (unsigned)(lane_out + ct * 4 * ESZ + pt * a.out_row);
+                if (flags & MSAU_CONV_MASK_A) e_ma[pt] = *reinterpret_cast<const V4*>(yp + delta_ma);
+                if (flags & MSAU_CONV_ADD) e_add[pt] = *reinterpret_cast<const V4*>(yp + delta_add);
+                if (flags & MSAU_CONV_ACCUM) e_acc[pt] = *reinterpret_cast<const V4*>(yp);
+                if (flags & MSAU_CONV_MASK_B) e_mb[pt] = *reinterpret_cast<const V4*>(yp + delta_mb);
+            }
+        }
+        // phase 2: combine and store
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            if (oyw + pt < d.Hout) {
                 char* yp = y + (unsigned)(lane_out + ct * 4 * ESZ + pt * a.out_row);
                 f32x4 v = acc[ct][pt] + bv;
-                if (flags & (MSAU_CONV_MASK_A | MSAU_CONV_ADD | MSAU_CONV_ACCUM | MSAU_CONV_RELU_OUT | MSAU_CONV_MASK_B)) {
-                    if (flags & MSAU_CONV_MASK_A) {
-                        V4 m = *reinterpret_cast<const V4*>(yp + delta_ma);
+                if (flags & MSAU_CONV_MASK_A) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : 0.f;
-                    }
-                    if (flags & MSAU_CONV_ADD) {
-                        V4 r = *reinterpret_cast<const V4*>(yp + delta_add);
+                    for (int j = 0; j < 4; ++j) v[j] = ((float)e_ma[pt][j] > 0.f) ? v[j] : 0.f;
+                }
+                if (flags & MSAU_CONV_ADD) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
-                    }
-                    if (flags & MSAU_CONV_ACCUM) {
-                        V4 r = *reinterpret_cast<const V4*>(yp);
+                    for (int j = 0; j < 4; ++j) v[j] += (float)e_add[pt][j];
+                }
+                if (flags & MSAU_CONV_ACCUM) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
-                    }
-                    if (flags & MSAU_CONV_RELU_OUT) {
+                    for (int j = 0; j < 4; ++j) v[j] += (float)e_acc[pt][j];
+                }
+                if (flags & MSAU_CONV_RELU_OUT) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                    }
-                    if (flags & MSAU_CONV_MASK_B) {
-                        V4 m = *reinterpret_cast<const V4*>(yp + delta_mb);
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                if (flags & MSAU_CONV_MASK_B) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : 0.f;
-                    }
+                    for (int j = 0; j < 4; ++j) v[j] = ((float)e_mb[pt][j] > 0.f) ? v[j] : 0.f;
                 }
                 V4 o;
 #pragma unroll

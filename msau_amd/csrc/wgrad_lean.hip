@@ -86,47 +86,73 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanArgs a) {
 #pragma unroll
         for (int ct = 0; ct < CTN; ++ct) acc[i][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    // software pipeline: the global loads of tile t+1 are issued (into registers) before the MFMA phase of
+    // tile t and written to LDS at the top of the next iteration -- a persistent workgroup has only
+    // 2 waves per SIMD, so without this every tile pays the full HBM latency.
+    constexpr int NITX = (TI * TI * C8 + 255) / 256, NITG = CO8;
+    constexpr bool PIPE = NITX + NITG <= 8;                      // beyond that the staging registers cost more than they hide
+    V8 xr[NITX], gr[NITG];
+    auto issue_loads = [&](int tile) {
         const int t1 = a.tiles_x > 1 ? __umulhi((unsigned)tile, a.mag_tx) : tile;
         const int txi = tile - t1 * a.tiles_x;
         const int b = a.tiles_y > 1 ? __umulhi((unsigned)t1, a.mag_ty) : t1;
         const int tyi = t1 - b * a.tiles_y;
         const int oy0 = tyi * 16, ox0 = txi * 16;
         const int vy0 = oy0 - d.pad_t, vx0 = ox0 - d.pad_l;
-        __syncthreads();
-        {   // x halo tile
-            constexpr int NITEMS = TI * TI * C8, NIT = (NITEMS + 255) / 256;
+        {
+            constexpr int NITEMS = TI * TI * C8;
             const char* base = xsrc + (long long)b * d.Hin * in_row + cb;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
+            for (int it = 0; it < NITX; ++it) {
                 const int idx = tid + it * 256;
+                xr[it] = zero8<T>();
                 if ((it + 1) * 256 <= NITEMS || idx < NITEMS) {
                     const int pix = idx / C8, cg = idx - pix * C8;
                     const int iy = pix / TI, ix = pix - iy * TI;
                     const int vy = vy0 + iy, vx = vx0 + ix;
-                    V8 v = zero8<T>();
-                    if ((unsigned)vy < (unsigned)d.Hin && (unsigned)vx < (unsigned)d.Win) {
-                        v = *reinterpret_cast<const V8*>(base + (unsigned)(vy * in_row + vx * in_px + cg * 8 * ESZ));
-                        if (relu_in) v = relu8<T>(v);
-                    }
-                    *reinterpret_cast<V8*>(lds_x + pix * PSX + cg * 8 * ESZ) = v;
+                    if ((unsigned)vy < (unsigned)d.Hin && (unsigned)vx < (unsigned)d.Win)
+                        xr[it] = *reinterpret_cast<const V8*>(base + (unsigned)(vy * in_row + vx * in_px + cg * 8 * ESZ));
                 }
             }
         }
-        {   // g tile: pixels outside the image contribute 0
-            constexpr int NITEMS = 256 * CO8, NIT = NITEMS / 256;
+        {
             const char* base = static_cast<const char*>(d.g) + (long long)b * d.Hout * g_row;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
+            for (int it = 0; it < NITG; ++it) {
                 const int idx = tid + it * 256;
                 const int m = idx / CO8, cg = idx - m * CO8;
                 const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-                V8 v = zero8<T>();
-                if (oy < d.Hout && ox < d.Wout) v = *reinterpret_cast<const V8*>(base + (unsigned)(oy * g_row + ox * g_px + cg * 8 * ESZ));
-                *reinterpret_cast<V8*>(lds_g + m * PSG + cg * 8 * ESZ) = v;
+                gr[it] = zero8<T>();                                 // pixels outside the image contribute 0
+                if (oy < d.Hout && ox < d.Wout) gr[it] = *reinterpret_cast<const V8*>(base + (unsigned)(oy * g_row + ox * g_px + cg * 8 * ESZ));
+            }
+        }
+    };
+    if (PIPE && (int)blockIdx.x < a.ntiles) issue_loads(blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        __syncthreads();
+        if (!PIPE) issue_loads(tile);
+        {
+            constexpr int NITEMS = TI * TI * C8;
+#pragma unroll
+            for (int it = 0; it < NITX; ++it) {
+                const int idx = tid + it * 256;
+                if ((it + 1) * 256 <= NITEMS || idx < NITEMS) {
+                    const int pix = idx / C8, cg = idx - pix * C8;
+                    V8 v = xr[it];
+                    if (relu_in) v = relu8<T>(v);
+                    *reinterpret_cast<V8*>(lds_x + pix * PSX + cg * 8 * ESZ) = v;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NITG; ++it) {
+                const int idx = tid + it * 256;
+                const int m = idx / CO8, cg = idx - m * CO8;
+                *reinterpret_cast<V8*>(lds_g + m * PSG + cg * 8 * ESZ) = gr[it];
             }
         }
         __syncthreads();
+        if (PIPE && tile + (int)gridDim.x < a.ntiles) issue_loads(tile + gridDim.x);
 
         if constexpr (sizeof(T) == 2) {
             const int q = li >> 2, p = li & 3;
