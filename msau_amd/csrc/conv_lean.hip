@@ -16,6 +16,8 @@ struct LeanArgs {
     int kchunk;                                  // packed K elements per weight row
     int in_px1, in_px2, in_row1, in_row2;        // bytes
     int out_px, out_row;                         // bytes
+    int tiles_x, tiles_y, ntiles;
+    unsigned mag_tx, mag_ty;                     // ceil(2^32 / tiles_x), ceil(2^32 / tiles_y)
 };
 
 template <typename T, int CIN8, int CT, int KS, bool DUAL>
@@ -48,11 +50,9 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(const LeanArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lg = lane >> 4;
-    const int b = blockIdx.z, oy0 = blockIdx.y * 16, ox0 = blockIdx.x * 16;
-    const int vy0 = oy0 - d.pad_t, vx0 = ox0 - d.pad_l;       // forward: SAME pad; data gradient: (k-1) - pad
     const bool relu_in = d.flags & MSAU_CONV_RELU_IN;
 
-    // ---- weights: registers (small) or LDS
+    // ---- weights: registers (small) or LDS, once per (persistent) workgroup
     const T* wp = static_cast<const T*>(d.wpack);
     V8 afr[Cfg::WREG ? CT : 1][Cfg::WREG ? NKS : 1];
     if constexpr (Cfg::WREG) {
@@ -70,35 +70,6 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(const LeanArgs a) {
         }
     }
 
-    // ---- stage the (16+KS-1)^2 halo tile; one source at a time so the base pointer stays scalar
-    auto stage = [&](const char* x, int in_row, int in_px, auto c8tag, int lds_cb) {
-        constexpr int C8 = decltype(c8tag)::value;            // 8-channel groups of this source
-        constexpr int NITEMS = Cfg::NPIX * C8;
-        constexpr int NIT = (NITEMS + 255) / 256;
-        const char* base = x + (long long)b * d.Hin * in_row;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * 256;
-            if ((it + 1) * 256 <= NITEMS || idx < NITEMS) {
-                const int pix = idx / C8, cg = idx - pix * C8;
-                const int iy = pix / TI, ix = pix - iy * TI;
-                const int vy = vy0 + iy, vx = vx0 + ix;
-                V8 v = zero8<T>();
-                if ((unsigned)vy < (unsigned)d.Hin && (unsigned)vx < (unsigned)d.Win) {
-                    v = *reinterpret_cast<const V8*>(base + (unsigned)(vy * in_row + vx * in_px + cg * 8 * ESZ));
-                    if (relu_in) v = relu8<T>(v);
-                }
-                *reinterpret_cast<V8*>(smem + pix * PS + lds_cb + cg * 8 * ESZ) = v;
-            }
-        }
-    };
-    if constexpr (DUAL) {
-        stage(static_cast<const char*>(d.x1), a.in_row1, a.in_px1, std::integral_constant<int, CIN8 / 2>{}, 0);
-        stage(static_cast<const char*>(d.x2), a.in_row2, a.in_px2, std::integral_constant<int, CIN8 / 2>{}, (CIN8 / 2) * 8 * ESZ);
-    } else {
-        stage(static_cast<const char*>(d.x1), a.in_row1, a.in_px1, std::integral_constant<int, CIN8>{}, 0);
-    }
-
     // ---- per-lane LDS offsets of the k-groups this lane feeds (lane group lg of every k-step)
     int koff[NKS];
 #pragma unroll
@@ -110,88 +81,146 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(const LeanArgs a) {
     }
     const unsigned char* pixp = smem + ((wave * 4) * TI + lr) * PS;
 
-    f32x4 acc[CT][4];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        const unsigned char* p = pixp + koff[ks];
-        V8 bfrag[4];
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt) bfrag[pt] = *reinterpret_cast<const V8*>(p + pt * TI * PS);
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            V8 af;
-            if constexpr (Cfg::WREG) af = afr[ct][ks];
-            else af = *reinterpret_cast<const V8*>(smem + Cfg::IN_BYTES + ((ks / NKSH) * (CT * 16) + ct * 16 + lr) * Cfg::WS +
-                                                   ((ks % NKSH) * 32 + lg * 8) * ESZ);
-#pragma unroll
-            for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = mma8(af, bfrag[pt], acc[ct][pt]);
-        }
-    }
-
-    // ---- epilogue: lane (pixel lr of row ty, q = lg) owns channels q*CT*4 + ct*4 + {0..3}
     const int flags = d.flags;
     const int Cout = d.Cout;
-    const int oyw = oy0 + wave * 4;
-    if (ox0 + lr >= d.Wout) return;
-    char* y = static_cast<char*>(d.y) + ((long long)(b * d.Hout + oyw)) * a.out_row + (long long)ox0 * a.out_px;
+    f32x4 bv[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        bv[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (d.bias && lg * (CT * 4) + ct * 4 < Cout) bv[ct] = *reinterpret_cast<const f32x4*>(d.bias + lg * (CT * 4) + ct * 4);
+    }
     const long long delta_add = static_cast<const char*>(d.add) - static_cast<const char*>(d.y);
     const long long delta_ma = static_cast<const char*>(d.mask_a) - static_cast<const char*>(d.y);
     const long long delta_mb = static_cast<const char*>(d.mask_b) - static_cast<const char*>(d.y);
     const int lane_out = lr * a.out_px + lg * (CT * 4) * ESZ;
+
+    // ---- staging: one source at a time so the base pointer stays scalar.  With few items per thread the
+    // loads of tile t+1 are issued into registers before the MFMAs of tile t (software pipeline).
+    constexpr int C8S = DUAL ? CIN8 / 2 : CIN8;                // 8-channel groups per source
+    constexpr int NITEMS = Cfg::NPIX * C8S;
+    constexpr int NIT = (NITEMS + 255) / 256;
+    constexpr int NSRC = DUAL ? 2 : 1;
+    constexpr bool PIPE = NIT * NSRC <= 6;
+    V8 pre[NSRC][NIT];
+    auto decode = [&](int tile, int& b, int& oy0, int& ox0) {
+        const int t1 = a.tiles_x > 1 ? __umulhi((unsigned)tile, a.mag_tx) : tile;
+        ox0 = (tile - t1 * a.tiles_x) * 16;
+        b = a.tiles_y > 1 ? __umulhi((unsigned)t1, a.mag_ty) : t1;
+        oy0 = (t1 - b * a.tiles_y) * 16;
+    };
+    auto issue_loads = [&](int tile) {
+        int b, oy0, ox0;
+        decode(tile, b, oy0, ox0);
+        const int vy0 = oy0 - d.pad_t, vx0 = ox0 - d.pad_l;    // forward: SAME pad; data gradient: (k-1) - pad
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        const int co = lg * (CT * 4) + ct * 4;
-        if (co >= Cout) continue;
-        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + co);
-        // phase 1: issue every epilogue-operand load of the 4 rows back to back (one latency, not eight)
-        V4 e_ma[4], e_add[4], e_acc[4], e_mb[4];
+        for (int sidx = 0; sidx < NSRC; ++sidx) {
+            const char* base = static_cast<const char*>(sidx ? d.x2 : d.x1) + (long long)b * d.Hin * (sidx ? a.in_row2 : a.in_row1);
+            const int in_row = sidx ? a.in_row2 : a.in_row1, in_px = sidx ? a.in_px2 : a.in_px1;
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
-            if (oyw + pt < d.Hout) {                               // scalar
-                const char* yp = y + (unsigned)(lane_out + ct * 4 * ESZ + pt * a.out_row);
-                if (flags & MSAU_CONV_MASK_A) e_ma[pt] = *reinterpret_cast<const V4*>(yp + delta_ma);
-                if (flags & MSAU_CONV_ADD) e_add[pt] = *reinterpret_cast<const V4*>(yp + delta_add);
-                if (flags & MSAU_CONV_ACCUM) e_acc[pt] = *reinterpret_cast<const V4*>(yp);
-                if (flags & MSAU_CONV_MASK_B) e_mb[pt] = *reinterpret_cast<const V4*>(yp + delta_mb);
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * 256;
+                pre[sidx][it] = zero8<T>();
+                if ((it + 1) * 256 <= NITEMS || idx < NITEMS) {
+                    const int pix = idx / C8S, cg = idx - pix * C8S;
+                    const int iy = pix / TI, ix = pix - iy * TI;
+                    const int vy = vy0 + iy, vx = vx0 + ix;
+                    if ((unsigned)vy < (unsigned)d.Hin && (unsigned)vx < (unsigned)d.Win)
+                        pre[sidx][it] = *reinterpret_cast<const V8*>(base + (unsigned)(vy * in_row + vx * in_px + cg * 8 * ESZ));
+                }
             }
         }
-        // phase 2: combine and store
+    };
+    auto write_lds = [&]() {
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
-            if (oyw + pt < d.Hout) {
-                char* yp = y + (unsigned)(lane_out + ct * 4 * ESZ + pt * a.out_row);
-                f32x4 v = acc[ct][pt] + bv;
-                if (flags & MSAU_CONV_MASK_A) {
+        for (int sidx = 0; sidx < NSRC; ++sidx)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = ((float)e_ma[pt][j] > 0.f) ? v[j] : 0.f;
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * 256;
+                if ((it + 1) * 256 <= NITEMS || idx < NITEMS) {
+                    const int pix = idx / C8S, cg = idx - pix * C8S;
+                    V8 v = pre[sidx][it];
+                    if (relu_in) v = relu8<T>(v);
+                    *reinterpret_cast<V8*>(smem + pix * PS + (sidx * C8S + cg) * 8 * ESZ) = v;
                 }
-                if (flags & MSAU_CONV_ADD) {
+            }
+    };
+    if (PIPE && (int)blockIdx.x < a.ntiles) issue_loads(blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        int b, oy0, ox0;
+        decode(tile, b, oy0, ox0);
+        __syncthreads();                                       // previous tile's fragment reads are done
+        if (!PIPE) issue_loads(tile);
+        write_lds();
+        __syncthreads();
+        if (PIPE && tile + (int)gridDim.x < a.ntiles) issue_loads(tile + gridDim.x);
+
+        f32x4 acc[CT][4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += (float)e_add[pt][j];
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const unsigned char* p = pixp + koff[ks];
+            V8 bfrag[4];
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) bfrag[pt] = *reinterpret_cast<const V8*>(p + pt * TI * PS);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                V8 af;
+                if constexpr (Cfg::WREG) af = afr[ct][ks];
+                else af = *reinterpret_cast<const V8*>(smem + Cfg::IN_BYTES + ((ks / NKSH) * (CT * 16) + ct * 16 + lr) * Cfg::WS +
+                                                       ((ks % NKSH) * 32 + lg * 8) * ESZ);
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = mma8(af, bfrag[pt], acc[ct][pt]);
+            }
+        }
+
+        // ---- epilogue: lane (pixel lr of row ty, q = lg) owns channels q*CT*4 + ct*4 + {0..3}
+        const int oyw = oy0 + wave * 4;
+        if (ox0 + lr < d.Wout) {
+            char* y = static_cast<char*>(d.y) + ((long long)(b * d.Hout + oyw)) * a.out_row + (long long)ox0 * a.out_px;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                if (lg * (CT * 4) + ct * 4 >= Cout) continue;
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) {
+                    if (oyw + pt < d.Hout) {                       // scalar
+                        char* yp = y + (unsigned)(lane_out + ct * 4 * ESZ + pt * a.out_row);
+                        f32x4 v = acc[ct][pt] + bv[ct];
+                        if (flags & (MSAU_CONV_MASK_A | MSAU_CONV_ADD | MSAU_CONV_ACCUM | MSAU_CONV_RELU_OUT | MSAU_CONV_MASK_B)) {
+                            if (flags & MSAU_CONV_MASK_A) {
+                                V4 m = *reinterpret_cast<const V4*>(yp + delta_ma);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : 0.f;
+                            }
+                            if (flags & MSAU_CONV_ADD) {
+                                V4 r = *reinterpret_cast<const V4*>(yp + delta_add);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                            }
+                            if (flags & MSAU_CONV_ACCUM) {
+                                V4 r = *reinterpret_cast<const V4*>(yp);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                            }
+                            if (flags & MSAU_CONV_RELU_OUT) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                            }
+                            if (flags & MSAU_CONV_MASK_B) {
+                                V4 m = *reinterpret_cast<const V4*>(yp + delta_mb);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : 0.f;
+                            }
+                        }
+                        V4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
+                        *reinterpret_cast<V4*>(yp) = o;
+                    }
                 }
-                if (flags & MSAU_CONV_ACCUM) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += (float)e_acc[pt][j];
-                }
-                if (flags & MSAU_CONV_RELU_OUT) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                }
-                if (flags & MSAU_CONV_MASK_B) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = ((float)e_mb[pt][j] > 0.f) ? v[j] : 0.f;
-                }
-                V4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
-                *reinterpret_cast<V4*>(yp) = o;
             }
         }
     }
@@ -207,8 +236,11 @@ int launch_lean(hipStream_t s, const LeanArgs& a) {
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_lean: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    dim3 grid(cdiv(a.d.Wout, 16), cdiv(a.d.Hout, 16), a.d.B);
-    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL>), grid, dim3(256), Cfg::LDS, s, a);
+    int per_cu = MSAU_LDS_LIMIT / (Cfg::LDS + 256);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+    int grid = 256 * per_cu;
+    if (grid > a.ntiles) grid = a.ntiles;
+    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL>), dim3(grid), dim3(256), Cfg::LDS, s, a);
     MSAU_CHECK_LAUNCH("conv_lean_kernel");
     return 1;
 }
@@ -273,6 +305,11 @@ int msau_conv_lean_try(hipStream_t s, int dtype, const msau_conv_desc* d, int kc
     a.in_px1 = d->C1 * esz; a.in_px2 = d->C2 * esz;
     a.in_row1 = d->Win * a.in_px1; a.in_row2 = d->Win * a.in_px2;
     a.out_px = d->Cout * esz; a.out_row = d->Wout * a.out_px;
+    a.tiles_x = cdiv(d->Wout, 16); a.tiles_y = cdiv(d->Hout, 16);
+    a.ntiles = d->B * a.tiles_x * a.tiles_y;
+    if (a.ntiles >= (1 << 20) || a.tiles_x >= 4096 || a.tiles_y >= 4096) return 0;
+    a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
+    a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
     if (d->KH == 4) return dtype == MSAU_F32 ? lean_ct<float, 1, 4, false>(s, a, CT) : lean_ct<bf16_t, 1, 4, false>(s, a, CT);
     if (dtype == MSAU_F32) return d->KH == 3 ? lean_cin<float, 3>(s, a, cin8, dual, CT) : lean_cin<float, 1>(s, a, cin8, dual, CT);
     return d->KH == 3 ? lean_cin<bf16_t, 3>(s, a, cin8, dual, CT) : lean_cin<bf16_t, 1>(s, a, cin8, dual, CT);
