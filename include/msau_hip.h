@@ -263,6 +263,8 @@ int msau_raster_onehot(void* stream, int dtype, const int32_t* boxes, const int3
 int msau_raster_labels(void* stream, const int32_t* boxes, const int32_t* owner, int64_t* labels, int B, int H, int W);
 
 /* misc */
+/* occupy the stream for ~microseconds (<= 200000) with a single sleeping wave: measurement aid only */
+int msau_spin(void* stream, int microseconds);
 int msau_fill_zero(void* stream, void* p, int64_t bytes);
 int msau_softmax_channels_nchw(void* stream, const float* logits, float* pred, int B, int C, int64_t hw);
 

@@ -81,6 +81,7 @@ _SIGNATURES = {
     "msau_raster_owner": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
     "msau_raster_onehot": (C.c_int, [vp, C.c_int, vp, vp, vp] + [C.c_int] * 5),
     "msau_raster_labels": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
+    "msau_spin": (C.c_int, [vp, C.c_int]),
     "msau_fill_zero": (C.c_int, [vp, vp, i64]),
     "msau_softmax_channels_nchw": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, i64]),
 }

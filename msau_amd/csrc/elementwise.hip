@@ -613,6 +613,21 @@ extern "C" int msau_clip_adam_step(void* stream, float* params, const float* gra
     return 0;
 }
 
+// Busy-wait kernel (one wave): keeps the stream occupied for ~`microseconds` so that launches issued behind
+// it queue up on the device; bench.py uses it to time kernels with HIP events without host launch gaps.
+__global__ void spin_kernel(long long cycles) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
+}
+
+extern "C" int msau_spin(void* stream, int microseconds) {
+    MSAU_CHECK_ARG(microseconds >= 0 && microseconds <= 200000, "spin: 0..200000 us");
+    // wall_clock64 ticks at 100 MHz on gfx950 (s_memrealtime)
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), (long long)microseconds * 100);
+    MSAU_CHECK_LAUNCH("spin_kernel");
+    return 0;
+}
+
 extern "C" int msau_fill_zero(void* stream, void* p, int64_t bytes) {
     MSAU_CHECK_ARG(p && bytes >= 0, "fill_zero: bad args");
     hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, static_cast<hipStream_t>(stream));

@@ -325,6 +325,10 @@ class TrainEngine:
         self.use_graph = use_graph
         self._graphs = {}
         self._static = {}
+        # Graph replays run on a dedicated non-default stream.  Replaying on the legacy NULL stream after the
+        # host had synchronised produced corrupted steps on ROCm 7.2 / gfx950 (nodes of consecutive launches
+        # overlapping; found 2026-10-03 with tools/loss_trace.py) -- never launch these graphs into stream 0.
+        self._gstream = torch.cuda.Stream(device=flat.device)
 
     # -- pieces (each is a fixed launch sequence on the current stream) --
     def _fwd_bwd(self, plan: Plan, x, labels):
@@ -356,30 +360,31 @@ class TrainEngine:
             self._optim()
             return loss
         key = (x.shape[0], x.shape[2], x.shape[3])
-        if key not in self._graphs:
-            sx, sl = x.clone(), labels.clone()
-            # warm up outside capture (hipFuncSetAttribute, lazy allocations)
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
+        cur = torch.cuda.current_stream()
+        gs = self._gstream
+        gs.wait_stream(cur)
+        with torch.cuda.stream(gs):
+            if key not in self._graphs:
+                sx, sl = x.clone(), labels.clone()
+                # warm up outside capture (hipFuncSetAttribute calls, lazy allocations)
                 self._fwd_bwd(plan, sx, sl)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                loss = self._fwd_bwd(plan, sx, sl)
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2):
-                self._optim()
-            self._graphs[key] = (g1, g2, loss)
-            self._static[key] = (sx, sl)
-        g1, g2, loss = self._graphs[key]
-        sx, sl = self._static[key]
-        sx.copy_(x, non_blocking=True)
-        sl.copy_(labels, non_blocking=True)
-        g1.replay()
-        self._allreduce()
-        g2.replay()
+                torch.cuda.synchronize()
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1, stream=gs):
+                    loss = self._fwd_bwd(plan, sx, sl)
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, stream=gs):
+                    self._optim()
+                self._graphs[key] = (g1, g2, loss)
+                self._static[key] = (sx, sl)
+            g1, g2, loss = self._graphs[key]
+            sx, sl = self._static[key]
+            sx.copy_(x, non_blocking=True)
+            sl.copy_(labels, non_blocking=True)
+            g1.replay()
+            self._allreduce()
+            g2.replay()
+        cur.wait_stream(gs)
         return loss
 
     @property

@@ -201,3 +201,25 @@ def test_train_script_end_to_end_on_synthetic_funsd(tmp_path, monkeypatch):
         # utils/io_utils.py:74-77: only epochs > 0 get a number): the final write wins
         ck = torch.load(T.ckpt_filename(args.ckptdir, args, 0))
         assert set(ck["model_state"].keys()) == set(m.state_dict().keys()) and ck["epoch"] == -1
+
+
+def test_graph_replay_after_host_sync_matches_eager_at_bench_size():
+    """regression (2026-10-03): replaying the step graphs on the legacy NULL stream right after a host
+    synchronisation corrupted the step at the bench configuration (B=16, 336x256x64, bf16) on ROCm 7.2;
+    TrainEngine now replays on its own stream.  Graph and eager must agree bit for bit."""
+    from oracle import msau_oracle as O
+    kw = dict(scale_space_num=4, res_depth=2, featRoot=8, final_act="softmax", num_blocks=3, dtype="bf16", seed=0)
+    x, label = O.synthetic_batch(16, 64, 336, 256, 5, seed=3)
+    x, label = x.cuda(), label.cuda()
+    res = []
+    for use_graph in (False, True):
+        m = MSAUWrapper(64, 5, kw).cuda()
+        eng = TrainEngine(m, use_graph=use_graph)
+        for i in range(3):
+            loss = eng.step(x, label)
+            if i == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        res.append((float(loss), float(eng.grad_norm), m.flat_parameters.clone()))
+    assert 0 < res[0][0] < 10
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and torch.equal(res[0][2], res[1][2])
