@@ -208,8 +208,17 @@ def main():
         ms, key, cnt, meta = next(r for r in rows if r[3])
         n_launch, alg_bytes, alg_flops = meta
         achieved = alg_bytes * nprof / (ms * 1e-3) / 1e9
+        traffic, traffic_note = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if key in tj:
+                traffic = tj[key]["hbm_bytes_per_launch"]
+                traffic_note = ("PMC (FETCH_SIZE x2 + WRITE_SIZE) of this kernel's plain forward launch, "
+                                f"{tj[key]['alg_bytes_of_measured_launch']} algorithmic bytes; collected offline by tools/pmc.sh")
+        except Exception:
+            pass
         roof = {"bound": "hbm", "kernel": key, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                 "launches_per_step": n_launch, "avg_launch_us": round(1e3 * ms / cnt, 2),
                 "alg_bytes_per_launch": round(alg_bytes / n_launch),
                 "share_of_step": round(ms / total_ms, 3),

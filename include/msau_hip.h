@@ -262,6 +262,31 @@ int msau_raster_onehot(void* stream, int dtype, const int32_t* boxes, const int3
                        int B, int H, int W, int C, int Cs);
 int msau_raster_labels(void* stream, const int32_t* boxes, const int32_t* owner, int64_t* labels, int B, int H, int W);
 
+/* ------------------------------------------------------------------------------------------
+ * Launch-sequence executor: one call enqueues a whole pre-built list of the launches above (the static
+ * plan of a forward or backward sweep), so the host cost per launch is a switch, not a Python/ctypes
+ * round trip.  `args` points to the msau_*_args / descriptor struct of the op's kind; all pointers
+ * inside must stay valid until the call returns (they are read at enqueue time only).
+ * ------------------------------------------------------------------------------------------ */
+enum {
+    MSAU_OP_CONV2D = 1,      /* args: msau_conv_desc          */
+    MSAU_OP_WGRAD = 2,       /* args: msau_wgrad_desc         */
+    MSAU_OP_LRN_FWD = 3,     /* args: msau_lrn_args           */
+    MSAU_OP_LRN_BWD = 4,     /* args: msau_lrn_args           */
+    MSAU_OP_POOL_FWD = 5,    /* args: msau_pool_args          */
+    MSAU_OP_POOL_BWD = 6,    /* args: msau_pool_args          */
+    MSAU_OP_ATTN_FWD = 7,    /* args: msau_attn_args          */
+    MSAU_OP_ATTN_BWD = 8,    /* args: msau_attn_args          */
+    MSAU_OP_CHANNEL_SUM = 9  /* args: msau_csum_args          */
+};
+typedef struct { int32_t kind; int32_t dtype; const void* args; } msau_op;
+typedef struct { const void* a; const void* dy; void* out; int64_t npix; int32_t C, Cs, n; float alpha, beta, k; } msau_lrn_args;
+typedef struct { const void* x_or_dy; void* y_or_dx; uint8_t* idx; const void* mask; int32_t B, H, W, Cs, accumulate; } msau_pool_args;
+typedef struct { const void* f; const void* g; const void* h; const void* x_or_dy; void* y; float* stats;
+                 void* df; void* dg; void* dh; float* ws; int32_t B, N, Ds, Cs; } msau_attn_args;
+typedef struct { const void* g; int64_t npix; int32_t Cs; float* partials; int32_t nblk; } msau_csum_args;
+int msau_run_ops(void* stream, const msau_op* ops, int n);
+
 /* misc */
 /* occupy the stream for ~microseconds (<= 200000) with a single sleeping wave: measurement aid only */
 int msau_spin(void* stream, int microseconds);

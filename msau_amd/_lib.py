@@ -53,6 +53,31 @@ class UnpackEntry(C.Structure):
                                    "cch", "nchunks", "accumulate")]
 
 
+class Op(C.Structure):
+    _fields_ = [("kind", i32), ("dtype", i32), ("args", vp)]
+
+
+class LrnArgs(C.Structure):
+    _fields_ = [("a", vp), ("dy", vp), ("out", vp), ("npix", i64), ("C", i32), ("Cs", i32), ("n", i32),
+                ("alpha", f32), ("beta", f32), ("k", f32)]
+
+
+class PoolArgs(C.Structure):
+    _fields_ = [("x_or_dy", vp), ("y_or_dx", vp), ("idx", vp), ("mask", vp)] + \
+               [(n, i32) for n in ("B", "H", "W", "Cs", "accumulate")]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [(n, vp) for n in ("f", "g", "h", "x_or_dy", "y", "stats", "df", "dg", "dh", "ws")] + \
+               [(n, i32) for n in ("B", "N", "Ds", "Cs")]
+
+
+class CsumArgs(C.Structure):
+    _fields_ = [("g", vp), ("npix", i64), ("Cs", i32), ("partials", vp), ("nblk", i32)]
+
+
+OP_CONV2D, OP_WGRAD, OP_LRN_FWD, OP_LRN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_CHANNEL_SUM = range(1, 10)
+
 _SIGNATURES = {
     "msau_last_error": (C.c_char_p, []),
     "msau_version": (C.c_int, []),
@@ -81,6 +106,7 @@ _SIGNATURES = {
     "msau_raster_owner": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
     "msau_raster_onehot": (C.c_int, [vp, C.c_int, vp, vp, vp] + [C.c_int] * 5),
     "msau_raster_labels": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
+    "msau_run_ops": (C.c_int, [vp, C.POINTER(Op), C.c_int]),
     "msau_spin": (C.c_int, [vp, C.c_int]),
     "msau_fill_zero": (C.c_int, [vp, vp, i64]),
     "msau_softmax_channels_nchw": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, i64]),

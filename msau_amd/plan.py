@@ -315,6 +315,20 @@ class ConvOp(Op):
     def fwd(self, s):
         L.call("msau_conv2d", s, self.plan.dtype, C.byref(self.fdesc), key=self.fkey)
 
+    def fwd_recs(self):
+        return [(L.OP_CONV2D, self.fdesc)]
+
+    def bwd_recs(self):
+        if self.wdesc is None:
+            return []
+        recs = [(L.OP_WGRAD, self.wdesc)]
+        if self.kind != "conv":
+            P = self.plan
+            self._csum = L.CsumArgs(_ptr(self.out.grad), self.out.npix, self.out.Cs, P.slab_ptr(self.csum_off), self.csum_blocks)
+            recs.append((L.OP_CHANNEL_SUM, self._csum))
+        recs += [(L.OP_CONV2D, dd) for dd in self.ddesc if dd is not None]
+        return recs
+
     def bwd_wgrad(self, s):
         """weight / bias gradient: reads out.grad and the saved inputs, writes only this op's slabs"""
         if self.wdesc is None:
@@ -346,6 +360,18 @@ class LrnOp(Op):
         self.slot = a.register() if a.needs_grad else None
         plan.ops.append(self)
 
+    def fwd_recs(self):
+        a, y = self.a, self.y
+        self._fa = L.LrnArgs(_ptr(a.data), None, _ptr(y.data), a.npix, a.C, a.Cs, a.C, 1e-4, 0.75, 1.0)
+        return [(L.OP_LRN_FWD, self._fa)]
+
+    def bwd_recs(self):
+        a, y = self.a, self.y
+        if y.grad is None or a.grad is None:
+            return []
+        self._ba = L.LrnArgs(_ptr(a.data), _ptr(y.grad), _ptr(a.grad), a.npix, a.C, a.Cs, a.C, 1e-4, 0.75, 1.0)
+        return [(L.OP_LRN_BWD, self._ba)]
+
     def fwd(self, s):
         a, y = self.a, self.y
         L.call("msau_lrn_fwd", s, self.plan.dtype, _ptr(a.data), _ptr(y.data), a.npix, a.C, a.Cs, a.C, 1e-4, 0.75, 1.0)
@@ -368,6 +394,20 @@ class PoolOp(Op):
         self.idx = torch.zeros((plan.B, y.H, y.W, y.Cs), dtype=torch.uint8, device=plan.device)
         self.slot = x.register() if x.needs_grad else None
         plan.ops.append(self)
+
+    def fwd_recs(self):
+        x, y = self.x, self.y
+        self._fa = L.PoolArgs(_ptr(x.data), _ptr(y.data), _ptr(self.idx), None, self.plan.B, x.H, x.W, x.Cs, 0)
+        return [(L.OP_POOL_FWD, self._fa)]
+
+    def bwd_recs(self):
+        x, y = self.x, self.y
+        if y.grad is None or x.grad is None:
+            return []
+        accum, maskb = x.slot_flags(self.slot)
+        self._ba = L.PoolArgs(_ptr(y.grad), _ptr(x.grad), _ptr(self.idx), _ptr(x.data) if maskb else None,
+                              self.plan.B, x.H, x.W, x.Cs, int(accum))
+        return [(L.OP_POOL_BWD, self._ba)]
 
     def fwd(self, s):
         x, y = self.x, self.y
@@ -394,6 +434,22 @@ class AttnCoreOp(Op):
             t.register()
         # the residual path (dx += dy) is folded into the h-projection's data gradient (ConvOp.bwd_add)
         plan.ops.append(self)
+
+    def _args(self, bwd):
+        return L.AttnArgs(_ptr(self.f.data), _ptr(self.g.data), _ptr(self.h.data),
+                          _ptr(self.y.grad) if bwd else _ptr(self.x.data), _ptr(self.y.data), _ptr(self.stats),
+                          _ptr(self.f.grad), _ptr(self.g.grad), _ptr(self.h.grad), _ptr(self.ws),
+                          self.plan.B, self.N, self.f.Cs, self.h.Cs)
+
+    def fwd_recs(self):
+        self._fa = self._args(False)
+        return [(L.OP_ATTN_FWD, self._fa)]
+
+    def bwd_recs(self):
+        if self.y.grad is None:
+            return []
+        self._ba = self._args(True)
+        return [(L.OP_ATTN_BWD, self._ba)]
 
     def fwd(self, s):
         L.call("msau_selfattn_fwd", s, self.plan.dtype, _ptr(self.f.data), _ptr(self.g.data), _ptr(self.h.data),
@@ -577,6 +633,8 @@ class Plan:
         for op in self.ops:
             if isinstance(op, ConvOp):
                 op.late_bind()
+        self._fwd_seq = self._make_seq([r for op in self.ops for r in op.fwd_recs()])
+        self._bwd_seq = self._make_seq([r for op in reversed(self.ops) for r in op.bwd_recs()]) if self.training else None
         self.pack_table = self._upload(self._pack_entries, L.PackEntry) if self._pack_entries else None
         self.unpack_table = self._upload(self._unpack_entries, L.UnpackEntry) if self._unpack_entries else None
         HW = self.H * self.W
@@ -588,6 +646,16 @@ class Plan:
             self.counts = torch.zeros((self.B,), dtype=torch.int32, device=self.device)
             self.ce_ws = torch.zeros((int(L.load().msau_ce_ws_floats(self.B * HW)),), dtype=torch.float32, device=self.device)
             self.loss_buf = torch.zeros((1,), dtype=torch.float32, device=self.device)
+
+    def _make_seq(self, recs):
+        """(kind, args struct) records -> (msau_op array, n); the structs are kept alive by the ops / this list"""
+        arr = (L.Op * max(len(recs), 1))()
+        for i, (kind, args) in enumerate(recs):
+            arr[i].kind, arr[i].dtype, arr[i].args = kind, self.dtype, C.addressof(args)
+        return arr, len(recs), recs
+
+    def _run_seq(self, seq, s):
+        L.call("msau_run_ops", s, seq[0], seq[1])
 
     def _upload(self, entries, ctype):
         n = len(entries)
@@ -617,8 +685,11 @@ class Plan:
         s = self._stream()
         self.pack(flat_params)
         self.load_input(x_nchw)
-        for op in self.ops:
-            op.fwd(s)
+        if L._profiler is None:
+            self._run_seq(self._fwd_seq, s)          # one C call enqueues the whole forward sweep
+        else:
+            for op in self.ops:
+                op.fwd(s)
         if export:
             self.export_logits()
         return self.out_logits, self.out_aux
@@ -666,7 +737,9 @@ class Plan:
         """Run the backward sweep (external gradients must already be in place) and write the
         flat fp32 parameter gradient."""
         s = self._stream()
-        if not self.overlap_wgrad:
+        if not self.overlap_wgrad and L._profiler is None:
+            self._run_seq(self._bwd_seq, s)          # one C call enqueues the whole backward sweep
+        elif not self.overlap_wgrad:
             for op in reversed(self.ops):
                 op.bwd(s)
         else:
