@@ -64,22 +64,23 @@ __global__ void pack_kernel(const float* __restrict__ params, unsigned char* __r
     }
 }
 
-// 256 threads = 16 consecutive K columns x 16 slab lanes: slab lane t sums slabs t, t+16, ... with
-// independent loads in flight, then the 16 partial sums are combined in a fixed order (reproducible).
+// 256 threads = 32 consecutive K columns (one 128-B line per slab) x 8 slab lanes: slab lane t sums slabs
+// t, t+8, ... with independent loads in flight, then the 8 partial sums are combined in a fixed order.
 __global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ slabs, float* __restrict__ grads,
                                                      const msau_unpack_entry* __restrict__ table) {
-    __shared__ float red[16][17];
+    constexpr int NC = 32, NS = 8;
+    __shared__ float red[NS][NC + 1];
     const msau_unpack_entry e = table[blockIdx.y];
     const int taps = e.KH * e.KW;
     const int kcols = e.nchunks * taps * e.cch;                 // stored K columns
-    const int kc16 = (kcols + 15) / 16;
+    const int kc16 = (kcols + NC - 1) / NC;
     const int rows_store = e.slab_elems / (e.kext * e.nchunks);
     const int ngroups = e.rows_real * kc16;                     // groups of 16 consecutive columns of one row
     const float* s0 = slabs + e.slab_off;
-    const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int col = threadIdx.x & (NC - 1), sl = threadIdx.x / NC;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int r = grp / kc16;
-        const int kk = (grp - r * kc16) * 16 + col;
+        const int kk = (grp - r * kc16) * NC + col;
         float sum = 0.f;
         int chunk = 0, k = 0, tap = 0, c = 0, kc = -1;
         if (kk < kcols) {
@@ -92,13 +93,13 @@ __global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ s
             const float* p = s0 + ((int64_t)chunk * rows_store + r) * e.kext + k;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
             int s = sl;
-            for (; s + 48 < e.nslabs; s += 64) {
+            for (; s + 3 * NS < e.nslabs; s += 4 * NS) {
                 a0 += p[(int64_t)s * e.slab_elems];
-                a1 += p[(int64_t)(s + 16) * e.slab_elems];
-                a2 += p[(int64_t)(s + 32) * e.slab_elems];
-                a3 += p[(int64_t)(s + 48) * e.slab_elems];
+                a1 += p[(int64_t)(s + NS) * e.slab_elems];
+                a2 += p[(int64_t)(s + 2 * NS) * e.slab_elems];
+                a3 += p[(int64_t)(s + 3 * NS) * e.slab_elems];
             }
-            for (; s < e.nslabs; s += 16) a0 += p[(int64_t)s * e.slab_elems];
+            for (; s < e.nslabs; s += NS) a0 += p[(int64_t)s * e.slab_elems];
             sum = (a0 + a1) + (a2 + a3);
         }
         __syncthreads();
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ s
         if (sl == 0 && kc >= 0) {
             float t = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) t += red[i][col];
+            for (int i = 0; i < NS; ++i) t += red[i][col];
             int ky = tap / e.KW, kx = tap - ky * e.KW;
             int i0 = e.row_is_dim0 ? r : kc;
             int i1 = e.row_is_dim0 ? kc : r;
@@ -117,18 +118,18 @@ __global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ s
     }
     if (e.b_off >= 0) {
         // bias gradient: the "ones" column of the wgrad slabs, or channel-sum partials; same 16 x 16 scheme
-        const int bgroups = (e.b_count + 15) / 16;
+        const int bgroups = (e.b_count + NC - 1) / NC;
         for (int grp = blockIdx.x; grp < bgroups; grp += gridDim.x) {
-            const int r = grp * 16 + col;
+            const int r = grp * NC + col;
             float a0 = 0.f, a1 = 0.f;
             if (r < e.b_count) {
                 const float* p = slabs + e.b_src_off + (int64_t)r * e.b_elem_stride;
                 int s = sl;
-                for (; s + 16 < e.b_nslabs; s += 32) {
+                for (; s + NS < e.b_nslabs; s += 2 * NS) {
                     a0 += p[(int64_t)s * e.b_slab_stride];
-                    a1 += p[(int64_t)(s + 16) * e.b_slab_stride];
+                    a1 += p[(int64_t)(s + NS) * e.b_slab_stride];
                 }
-                for (; s < e.b_nslabs; s += 16) a0 += p[(int64_t)s * e.b_slab_stride];
+                for (; s < e.b_nslabs; s += NS) a0 += p[(int64_t)s * e.b_slab_stride];
             }
             __syncthreads();
             red[sl][col] = a0 + a1;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ s
             if (sl == 0 && r < e.b_count) {
                 float t = 0.f;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) t += red[i][col];
+                for (int i = 0; i < NS; ++i) t += red[i][col];
                 float* dst = grads + e.b_off + r;
                 *dst = e.accumulate ? *dst + t : t;
             }
@@ -161,8 +162,8 @@ extern "C" int msau_pack_params(void* stream, const float* flat_params, void* pa
 extern "C" int msau_wgrad_reduce(void* stream, const float* slab_arena, float* flat_grads,
                                  const msau_unpack_entry* table_dev, int n_entries, int max_elems_per_entry) {
     MSAU_CHECK_ARG(slab_arena && flat_grads && table_dev && n_entries > 0, "wgrad_reduce: bad args");
-    int bx = cdiv(max_elems_per_entry, 16);
-    if (bx > 96) bx = 96;
+    int bx = cdiv(max_elems_per_entry, 32);
+    if (bx > 128) bx = 128;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(unpack_kernel, dim3(bx, n_entries), dim3(256), 0, static_cast<hipStream_t>(stream),
                        slab_arena, flat_grads, table_dev);

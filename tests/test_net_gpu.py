@@ -223,3 +223,38 @@ def test_graph_replay_after_host_sync_matches_eager_at_bench_size():
         res.append((float(loss), float(eng.grad_norm), m.flat_parameters.clone()))
     assert 0 < res[0][0] < 10
     assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and torch.equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("tag,channels,stages,H,W,dense", [
+    ("cfg1", 32, 1, 128, 128, False),        # BASELINE configs[0]: 1-stage 128x128x32, batch 2
+    ("cfg4", 768, 2, 336, 256, True),        # configs[3]: BERT-embedding chargrid 336x256x768, 2 stages
+    ("cfg5-geometry", 64, 3, 512, 384, False),   # configs[4] geometry with plain residual blocks (box conv: unpinned)
+])
+def test_baseline_configs_full_size_vs_oracle(tag, channels, stages, H, W, dense):
+    """every BASELINE configuration at its full spatial / channel size: HIP fp32 forward + loss + gradient norm
+    against the CPU oracle on the same seeded input (the oracle finishes these in seconds)"""
+    from oracle import msau_oracle as O
+    B = 2 if tag == "cfg1" else 1
+    cfg = dict(O.DEFAULT_CFG, channels=channels, num_blocks=stages)
+    sd = O.init_params(cfg, seed=31)
+    x, label = O.synthetic_batch(B, channels, H, W, 5, seed=32, dense=dense)
+    kw = dict(scale_space_num=4, res_depth=2, featRoot=8, final_act="softmax", num_blocks=stages, dtype="fp32")
+    m = MSAUWrapper(channels, 5, kw)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lr, ar = O.msau_forward(leaves, x, cfg)
+    with torch.no_grad():
+        _, logits, aux = m(x.cuda())
+    assert rel_err(logits.cpu(), lr.detach()) < 2e-4, tag
+    if stages == 1:
+        assert aux is None and ar is None
+        return
+    assert rel_err(aux.cpu(), ar.detach()) < 2e-4
+    ref_loss = O.msau_loss(lr, ar, label)
+    ref_loss.backward()
+    gn_ref = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in leaves.values() if p.grad is not None)))
+    eng = TrainEngine(m)
+    loss = eng.step(x.cuda(), label.cuda())
+    assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
+    assert abs(float(eng.grad_norm) - gn_ref) < 2e-3 * gn_ref
