@@ -239,6 +239,11 @@ int64_t msau_ce_ws_floats(int64_t npix_total);
 int msau_masked_ce(void* stream, int dtype, const void* logits, const int64_t* labels, const int32_t* counts,
                    void* dlogits, float* loss_accum, float* ws, int B, int64_t hw, int C, int Cs, float scale);
 
+/* plain cross entropy over EVERY pixel (label 0 is a class), as model/training/cost.py:35-65 `UNetLoss`:
+ *   loss += scale * sum_p -log softmax(logits_p)[label_p] ; dlogits = scale * (softmax - onehot)           */
+int msau_softmax_ce(void* stream, int dtype, const void* logits, const int64_t* labels, void* dlogits,
+                    float* loss_accum, float* ws, int B, int64_t hw, int C, int Cs, float scale);
+
 /* ------------------------------------------------------------------------------------------
  * Global-norm clip + Adam on flat fp32 buffers (train_chargrid_funsd_msau.py:24-26,58-59).
  * state (device, 8 floats): [0]=step count, [1]=grad norm (after grad_scale), [2]=clip coef,

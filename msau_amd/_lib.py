@@ -101,6 +101,7 @@ _SIGNATURES = {
     "msau_label_counts": (C.c_int, [vp, vp, vp, C.c_int, i64]),
     "msau_ce_ws_floats": (i64, [i64]),
     "msau_masked_ce": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, C.c_int, f32]),
+    "msau_softmax_ce": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, C.c_int, f32]),
     "msau_adam_ws_floats": (i64, [i64]),
     "msau_clip_adam_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32]),
     "msau_raster_owner": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]),

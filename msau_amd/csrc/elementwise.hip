@@ -319,7 +319,7 @@ __global__ void label_count_kernel(const int64_t* __restrict__ labels, int32_t* 
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(&counts[b], local);            // integer: order-independent
 }
 
-template <typename T>
+template <typename T, bool ALL>
 __global__ void masked_ce_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels,
                                  const int32_t* __restrict__ counts, T* __restrict__ dlogits, float* __restrict__ partials,
                                  int B, int64_t hw, int C, int Cs, float scale) {
@@ -329,8 +329,8 @@ __global__ void masked_ce_kernel(const T* __restrict__ logits, const int64_t* __
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
         const int b = (int)(p / hw);
         const int64_t lab = labels[p];
-        const bool on = lab != 0 && lab < C;
-        const float w = on ? scale / (float)max(counts[b], 1) : 0.f;
+        const bool on = ALL ? (lab >= 0 && lab < C) : (lab != 0 && lab < C);
+        const float w = on ? (ALL ? scale : scale / (float)max(counts[b], 1)) : 0.f;
         float x[16];
         float mx = -INFINITY;
         for (int c0 = 0; c0 < Cs && c0 < 16; c0 += 8) {
@@ -575,9 +575,24 @@ extern "C" int msau_masked_ce(void* stream, int dtype, const void* logits, const
     hipStream_t s = static_cast<hipStream_t>(stream);
     int nb = ce_blocks((int64_t)B * hw);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(masked_ce_kernel<float>, dim3(nb), dim3(kThreads), 0, s, static_cast<const float*>(logits), labels, counts, static_cast<float*>(dlogits), ws, B, hw, C, Cs, scale),
-               hipLaunchKernelGGL(masked_ce_kernel<bf16_t>, dim3(nb), dim3(kThreads), 0, s, static_cast<const bf16_t*>(logits), labels, counts, static_cast<bf16_t*>(dlogits), ws, B, hw, C, Cs, scale));
+               hipLaunchKernelGGL((masked_ce_kernel<float, false>), dim3(nb), dim3(kThreads), 0, s, static_cast<const float*>(logits), labels, counts, static_cast<float*>(dlogits), ws, B, hw, C, Cs, scale),
+               hipLaunchKernelGGL((masked_ce_kernel<bf16_t, false>), dim3(nb), dim3(kThreads), 0, s, static_cast<const bf16_t*>(logits), labels, counts, static_cast<bf16_t*>(dlogits), ws, B, hw, C, Cs, scale));
     MSAU_CHECK_LAUNCH("masked_ce");
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(64), 0, s, ws, nb, loss_accum);
+    MSAU_CHECK_LAUNCH("ordered_sum");
+    return 0;
+}
+
+extern "C" int msau_softmax_ce(void* stream, int dtype, const void* logits, const int64_t* labels, void* dlogits,
+                               float* loss_accum, float* ws, int B, int64_t hw, int C, int Cs, float scale) {
+    MSAU_CHECK_ARG(logits && labels && dlogits && loss_accum && ws, "softmax_ce: null pointer");
+    MSAU_CHECK_ARG(B > 0 && hw > 0 && C > 0 && C <= Cs && Cs % 8 == 0 && Cs <= 16, "softmax_ce: bad dims (n_class <= 16)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int nb = ce_blocks((int64_t)B * hw);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((masked_ce_kernel<float, true>), dim3(nb), dim3(kThreads), 0, s, static_cast<const float*>(logits), labels, nullptr, static_cast<float*>(dlogits), ws, B, hw, C, Cs, scale),
+               hipLaunchKernelGGL((masked_ce_kernel<bf16_t, true>), dim3(nb), dim3(kThreads), 0, s, static_cast<const bf16_t*>(logits), labels, nullptr, static_cast<bf16_t*>(dlogits), ws, B, hw, C, Cs, scale));
+    MSAU_CHECK_LAUNCH("softmax_ce");
     hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(64), 0, s, ws, nb, loss_accum);
     MSAU_CHECK_LAUNCH("ordered_sum");
     return 0;

@@ -258,3 +258,52 @@ def test_baseline_configs_full_size_vs_oracle(tag, channels, stages, H, W, dense
     loss = eng.step(x.cuda(), label.cuda())
     assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
     assert abs(float(eng.grad_norm) - gn_ref) < 2e-3 * gn_ref
+
+
+def test_unet_loss_and_trainer_api(tmp_path):
+    """N3: UNetLoss (0.5 final + 0.5 aux plain CE on one-hot targets, acc over non-zero target pixels) against
+    torch's CE, and the Trainer loop (lr schedule, save policy) on a tiny in-memory data provider"""
+    import torch.nn.functional as F
+    from msau_amd.training import Trainer, UNetLoss
+    torch.manual_seed(0)
+    B, C, H, W = 2, 5, 9, 11
+    lg = torch.randn(B, C, H, W, device="cuda", requires_grad=True)
+    ax = torch.randn(B, C, H, W, device="cuda", requires_grad=True)
+    t = torch.randint(0, C, (B, H, W), device="cuda")
+    onehot = F.one_hot(t, C).permute(0, 3, 1, 2).float()
+    acc, loss, final = UNetLoss({})(lg, onehot, {"aux_logits": ax, "aux_tgt": onehot})
+    loss.backward()
+    lr_, ar_ = lg.detach().clone().requires_grad_(True), ax.detach().clone().requires_grad_(True)
+    ref = 0.5 * F.cross_entropy(lr_, t) + 0.5 * F.cross_entropy(ar_, t)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 and abs(float(final) - float(F.cross_entropy(lr_, t))) < 1e-5
+    assert rel_err(lg.grad.cpu(), lr_.grad.cpu()) < 1e-5 and rel_err(ax.grad.cpu(), ar_.grad.cpu()) < 1e-5
+    nz = t != 0
+    assert abs(acc - float((lg.argmax(1)[nz] == t[nz]).float().mean())) < 1e-6
+
+    class Provider:
+        batchsize_tr, size_val = 1, 1
+        def __init__(self):
+            g = torch.Generator().manual_seed(1)
+            self.x = torch.randn(1, 8, 24, 20, generator=g)
+            lab = torch.randint(0, 5, (1, 24, 20), generator=g)
+            self.t = F.one_hot(lab, 5).permute(0, 3, 1, 2).float()
+            self.stopped = self.restarts = 0
+        def next_data(self, split):
+            return self.x, self.t, self.t
+        def restart_val_runner(self):
+            self.restarts += 1
+        def stop_all(self):
+            self.stopped += 1
+
+    net = MSAUWrapper(8, 5, dict(scale_space_num=3, res_depth=2, featRoot=8, final_act="softmax", seed=2)).cuda()
+    tr = Trainer(net, opt_kwargs={"optimizer": "adam", "learning_rate": 1e-3})
+    prov = Provider()
+    with torch.no_grad():
+        l0 = float(tr._loss(*tr._batch(prov, "val"))[1])
+    out = tr.train(prov, str(tmp_path), batch_steps_per_epoch=4, epochs=2)
+    with torch.no_grad():
+        l1 = float(tr._loss(*tr._batch(prov, "val"))[1])
+    assert l1 < l0 and prov.stopped == 1 and prov.restarts == 2
+    assert abs(tr.adjust_lr(25) - 1e-3 * 0.95 ** 2) < 1e-12
+    assert out == str(tmp_path / "model") and (tmp_path / "model1").exists()
