@@ -291,6 +291,12 @@ typedef struct { const void* f; const void* g; const void* h; const void* x_or_d
                  void* df; void* dg; void* dh; float* ws; int32_t B, N, Ds, Cs; } msau_attn_args;
 typedef struct { const void* g; int64_t npix; int32_t Cs; float* partials; int32_t nblk; } msau_csum_args;
 int msau_run_ops(void* stream, const msau_op* ops, int n);
+/* As msau_run_ops, but ops whose kind carries MSAU_OP_SIDE are enqueued on `side_stream` after everything
+ * enqueued so far on `stream` (event fork); `stream` waits for `side_stream` at the end (join).  Used for
+ * the weight gradients: they depend on a finished output gradient and feed nothing but the final slab
+ * reduction, so they run beside the data-gradient chain. */
+#define MSAU_OP_SIDE 0x100
+int msau_run_ops_overlap(void* stream, void* side_stream, const msau_op* ops, int n);
 
 /* misc */
 /* occupy the stream for ~microseconds (<= 200000) with a single sleeping wave: measurement aid only */

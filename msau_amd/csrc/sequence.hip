@@ -3,10 +3,67 @@
 // step is then a handful of C calls instead of ~450 Python -> ctypes round trips.
 #include "msau_common.h"
 
+#include <vector>
+
+static int run_one(void* stream, const msau_op& o, int i);
+
 extern "C" int msau_run_ops(void* stream, const msau_op* ops, int n) {
     MSAU_CHECK_ARG(ops || n == 0, "run_ops: null list");
     for (int i = 0; i < n; ++i) {
-        const msau_op& o = ops[i];
+        int rc = run_one(stream, ops[i], i);
+        if (rc) return rc;              // msau_last_error() holds the failing launch's message
+    }
+    return 0;
+}
+
+extern "C" int msau_run_ops_overlap(void* stream, void* side_stream, const msau_op* ops, int n) {
+    MSAU_CHECK_ARG((ops || n == 0) && side_stream && side_stream != stream, "run_ops_overlap: bad args");
+    static thread_local std::vector<hipEvent_t> pool;          // timing-disabled events, reused across calls
+    hipStream_t ms = static_cast<hipStream_t>(stream), ss = static_cast<hipStream_t>(side_stream);
+    size_t used = 0;
+    auto next_event = [&](hipEvent_t* ev) -> int {
+        if (used == pool.size()) {
+            hipEvent_t e;
+            hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            if (err != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "run_ops_overlap: event: %s", hipGetErrorString(err));
+            pool.push_back(e);
+        }
+        *ev = pool[used++];
+        return 0;
+    };
+    bool main_dirty = true, any_side = false;                   // main has work the side stream has not waited for yet
+    for (int i = 0; i < n; ++i) {
+        msau_op o = ops[i];
+        const bool side = o.kind & MSAU_OP_SIDE;
+        o.kind &= ~MSAU_OP_SIDE;
+        if (side) {
+            if (main_dirty) {
+                hipEvent_t ev;
+                int rc = next_event(&ev);
+                if (rc) return rc;
+                if (hipEventRecord(ev, ms) != hipSuccess || hipStreamWaitEvent(ss, ev, 0) != hipSuccess)
+                    return msau_set_error(MSAU_ERR_HIP, "run_ops_overlap: fork failed");
+                main_dirty = false;
+            }
+            any_side = true;
+        } else {
+            main_dirty = true;
+        }
+        int rc = run_one(side ? side_stream : stream, o, i);
+        if (rc) return rc;
+    }
+    if (any_side) {
+        hipEvent_t ev;
+        int rc = next_event(&ev);
+        if (rc) return rc;
+        if (hipEventRecord(ev, ss) != hipSuccess || hipStreamWaitEvent(ms, ev, 0) != hipSuccess)
+            return msau_set_error(MSAU_ERR_HIP, "run_ops_overlap: join failed");
+    }
+    return 0;
+}
+
+static int run_one(void* stream, const msau_op& o, int i) {
+    {
         int rc;
         switch (o.kind) {
             case MSAU_OP_CONV2D: rc = msau_conv2d(stream, o.dtype, static_cast<const msau_conv_desc*>(o.args)); break;
@@ -49,7 +106,6 @@ extern "C" int msau_run_ops(void* stream, const msau_op* ops, int n) {
             }
             default: return msau_set_error(MSAU_ERR_ARG, "run_ops: op %d has unknown kind %d", i, o.kind);
         }
-        if (rc) return rc;              // msau_last_error() holds the failing launch's message
+        return rc;
     }
-    return 0;
 }

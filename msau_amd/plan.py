@@ -322,11 +322,12 @@ class ConvOp(Op):
     def bwd_recs(self):
         if self.wdesc is None:
             return []
-        recs = [(L.OP_WGRAD, self.wdesc)]
+        side = L.OP_SIDE if self.plan.overlap_wgrad else 0     # weight gradients run beside the data-gradient chain
+        recs = [(L.OP_WGRAD | side, self.wdesc)]
         if self.kind != "conv":
             P = self.plan
             self._csum = L.CsumArgs(_ptr(self.out.grad), self.out.npix, self.out.Cs, P.slab_ptr(self.csum_off), self.csum_blocks)
-            recs.append((L.OP_CHANNEL_SUM, self._csum))
+            recs.append((L.OP_CHANNEL_SUM | side, self._csum))
         recs += [(L.OP_CONV2D, dd) for dd in self.ddesc if dd is not None]
         return recs
 
@@ -479,10 +480,12 @@ class Plan:
         self._pack_max = 1
         self._unpack_max = 1
         self.launch_meta: Dict[str, Tuple[int, float, float]] = {}
-        # measured 2026-10-03: running the wgrads beside the dgrad chain is 4 % SLOWER (6.76 vs 6.50 ms/step): both
-        # chains are instruction-issue bound and only steal issue slots from each other.  Off by default.
-        self.overlap_wgrad = bool(cfg.get("overlap_wgrad", False)) and str(device).startswith("cuda")
+        # The weight gradients form no dependency chain (each reads a finished out.grad and writes its own slabs),
+        # so they run on a side stream beside the data-gradient chain.  Measured 2026-10-03 with the lean kernels:
+        # 5.76 -> 5.20 ms/step (with the first, generic kernels it was 4 % slower: both chains were issue-bound).
+        self.overlap_wgrad = bool(cfg.get("overlap_wgrad", True)) and str(device).startswith("cuda")
         self._side = None
+        self.overlap_max_pix = int(cfg.get("overlap_max_pix", 1 << 62))     # only layers this small go to the side stream
         self.x_in = Act(self, "input", H, W, cfg["channels"], needs_grad=bool(cfg.get("input_grad", False)))
         self.logits: Optional[Act] = None
         self.aux: Optional[Act] = None
@@ -738,30 +741,15 @@ class Plan:
         """Run the backward sweep (external gradients must already be in place) and write the
         flat fp32 parameter gradient."""
         s = self._stream()
-        if not self.overlap_wgrad and L._profiler is None:
-            self._run_seq(self._bwd_seq, s)          # one C call enqueues the whole backward sweep
-        elif not self.overlap_wgrad:
+        if L._profiler is not None:
             for op in reversed(self.ops):
                 op.bwd(s)
+        elif not self.overlap_wgrad:
+            self._run_seq(self._bwd_seq, s)          # one C call enqueues the whole backward sweep
         else:
-            # The weight gradients form no dependency chain (each reads a finished out.grad and writes its own
-            # slabs), so they run on a side stream beside the data-gradient chain: two instruction-bound
-            # kernels share the CUs, and the many small launches hide each other's tails and launch gaps.
-            main = torch.cuda.current_stream()
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.device)
-            side = self._side
-            for op in reversed(self.ops):
-                if isinstance(op, ConvOp) and op.wdesc is not None:
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    side.wait_event(ev)
-                    with torch.cuda.stream(side):
-                        op.bwd_wgrad(side.cuda_stream)
-                    op.bwd_dgrad(s)
-                else:
-                    op.bwd(s)
-            main.wait_stream(side)
+            L.call("msau_run_ops_overlap", s, self._side.cuda_stream, self._bwd_seq[0], self._bwd_seq[1])
         if self.unpack_table is not None:
             L.call("msau_wgrad_reduce", s, self.slab_arena.data_ptr(), flat_grads.data_ptr(), self.unpack_table.data_ptr(),
                    len(self._unpack_entries), self._unpack_max)
