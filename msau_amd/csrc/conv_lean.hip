@@ -20,10 +20,10 @@ struct LeanArgs {
     unsigned mag_tx, mag_ty;                     // ceil(2^32 / tiles_x), ceil(2^32 / tiles_y)
 };
 
-template <typename T, int CIN8, int CT, int KS, bool DUAL>
+template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1>
 struct LeanCfg {
     static constexpr int ESZ = (int)sizeof(T);
-    static constexpr int TI = 16 + KS - 1;
+    static constexpr int TI = 16 + (KS - 1) * DIL;
     static constexpr int PSRAW = CIN8 * 8 * ESZ;
     static constexpr int PS = ((PSRAW / 16) % 2 == 0) ? PSRAW + 16 : PSRAW;
     static constexpr int NPIX = TI * TI;
@@ -39,9 +39,9 @@ struct LeanCfg {
     static constexpr int LDS = IN_BYTES + (WREG ? 0 : NCH * CT * 16 * WS);
 };
 
-template <typename T, int CIN8, int CT, int KS, bool DUAL>
+template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1>
 __global__ __launch_bounds__(256) void conv_lean_kernel(const LeanArgs a) {
-    using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL>;
+    using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL>;
     typedef typename Vec8<T>::type V8;
     typedef typename Vec4<T>::type V4;
     constexpr int ESZ = Cfg::ESZ, TI = Cfg::TI, PS = Cfg::PS, NKS = Cfg::NKS, NG = Cfg::NG, NKSH = Cfg::NKSH, C8H = Cfg::C8H;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(const LeanArgs a) {
         const int G = (ks % NKSH) * 4 + lg;                    // k-group inside chunk ks / NKSH
         const int tap = G / C8H, cg = G - tap * C8H;
         const int ky = tap / KS, kx = tap - ky * KS;
-        koff[ks] = G < NG ? (ky * TI + kx) * PS + ((ks / NKSH) * C8H + cg) * 8 * ESZ : 0;
+        koff[ks] = G < NG ? (ky * DIL * TI + kx * DIL) * PS + ((ks / NKSH) * C8H + cg) * 8 * ESZ : 0;
     }
     const unsigned char* pixp = smem + ((wave * 4) * TI + lr) * PS;
 
@@ -226,12 +226,12 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(const LeanArgs a) {
     }
 }
 
-template <typename T, int CIN8, int CT, int KS, bool DUAL>
+template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1>
 int launch_lean(hipStream_t s, const LeanArgs& a) {
-    using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL>;
+    using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL>;
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS > 60 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<T, CIN8, CT, KS, DUAL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_lean: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -240,7 +240,7 @@ int launch_lean(hipStream_t s, const LeanArgs& a) {
     per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
     int grid = 256 * per_cu;
     if (grid > a.ntiles) grid = a.ntiles;
-    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL>), dim3(grid), dim3(256), Cfg::LDS, s, a);
+    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL>), dim3(grid), dim3(256), Cfg::LDS, s, a);
     MSAU_CHECK_LAUNCH("conv_lean_kernel");
     return 1;
 }
@@ -249,6 +249,9 @@ template <typename T, int CIN8, int KS, bool DUAL>
 int lean_ct(hipStream_t s, const LeanArgs& a, int CT) {
     if (CT == 1) return launch_lean<T, CIN8, 1, KS, DUAL>(s, a);
     if (CT == 2) return launch_lean<T, CIN8, 2, KS, DUAL>(s, a);
+    if constexpr (CIN8 >= 4 && KS != 4) {
+        if (CT == 4) return launch_lean<T, CIN8, 4, KS, DUAL>(s, a);
+    }
     return 0;
 }
 
@@ -267,8 +270,18 @@ int lean_cin(hipStream_t s, const LeanArgs& a, int cin8, bool dual, int CT) {
         case 2: return lean_ct<T, 2, KS, true>(s, a, CT);
         case 4: return lean_ct<T, 4, KS, true>(s, a, CT);
         case 8: return lean_ct<T, 8, KS, true>(s, a, CT);
+        case 16: if constexpr (KS == 1) return lean_ct<T, 16, KS, true>(s, a, CT); else return 0;
         default: return 0;
     }
+}
+
+// dilated 3x3 (the level-entry convs of the encoder and their data gradients): single source only
+template <typename T, int DIL>
+int lean_dil(hipStream_t s, const LeanArgs& a, int cin8, int CT) {
+#define LD_CASE(C8, CTV) if (cin8 == C8 && CT == CTV) return launch_lean<T, C8, CTV, 3, false, DIL>(s, a);
+    LD_CASE(1, 1) LD_CASE(2, 1) LD_CASE(2, 2) LD_CASE(4, 1) LD_CASE(4, 2) LD_CASE(4, 4) LD_CASE(8, 2)
+#undef LD_CASE
+    return 0;
 }
 
 }  // namespace
@@ -276,20 +289,26 @@ int lean_cin(hipStream_t s, const LeanArgs& a, int cin8, bool dual, int CT) {
 // Returns 1 if a lean instance handled the launch, 0 if the caller must use the generic kernel,
 // < 0 on error.  `kchunk` / `nchunks` / `CT` come from the generic geometry (same packed image).
 int msau_conv_lean_applicable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
-    if (d->stride != 1 || d->ups != 1 || d->dil != 1 || d->KH != d->KW || (d->KH != 1 && d->KH != 3 && d->KH != 4)) return 0;
+    if (d->stride != 1 || d->ups != 1 || d->KH != d->KW || (d->KH != 1 && d->KH != 3 && d->KH != 4)) return 0;
+    if (d->dil != 1) {
+        if (d->KH != 3 || d->C2 || (d->dil != 2 && d->dil != 4 && d->dil != 8)) return 0;
+        const int c8 = d->C1 / 8;
+        const bool ok = (c8 == 1 && CT == 1) || (c8 == 2 && CT <= 2) || (c8 == 4 && (CT == 1 || CT == 2 || CT == 4)) || (c8 == 8 && CT == 2);
+        if (!ok) return 0;
+    }
     if (nchunks != (d->C2 ? 2 : 1)) return 0;                // one chunk per source (same packed image as conv.hip)
     if (d->Hin != d->Hout || d->Win != d->Wout) return 0;
-    if (d->pad_t < 0 || d->pad_l < 0 || d->pad_t >= d->KH || d->pad_l >= d->KW) return 0;
-    if (CT > 2) return 0;
+    if (d->pad_t < 0 || d->pad_l < 0 || d->pad_t > (d->KH - 1) * d->dil || d->pad_l > (d->KW - 1) * d->dil) return 0;
+    if (CT > 4 || (CT == 4 && (d->C1 + d->C2) < 32)) return 0;
     if (d->KH == 4 && ((d->C1 + d->C2) != 8 || d->C2)) return 0;           // only the 8-channel end conv / its data gradient
-    if ((int64_t)d->B * cdiv(d->Hout, 16) * cdiv(d->Wout, 16) < 256) return 0;
+    if ((int64_t)d->B * cdiv(d->Hout, 16) * cdiv(d->Wout, 16) < 64) return 0;
     const bool dual = d->C2 != 0;
     if (dual && d->C1 != d->C2) return 0;
     const int cin8 = (d->C1 + d->C2) / 8;
     const int esz = dtype == MSAU_F32 ? 4 : 2;
     if ((int64_t)d->Hin * d->Win * (d->C1 > d->C2 ? d->C1 : d->C2) * esz >= (1ll << 31)) return 0;   // 32-bit lane offsets
     if ((int64_t)d->Wout * d->Cout * esz * 20 >= (1ll << 31)) return 0;
-    if (cin8 != 1 && cin8 != 2 && cin8 != 4 && cin8 != 8) return 0;
+    if (cin8 != 1 && cin8 != 2 && cin8 != 4 && cin8 != 8 && !(cin8 == 16 && dual && d->KH == 1)) return 0;
     if (dual && cin8 < 2) return 0;
     return 1;
 }
@@ -310,6 +329,9 @@ int msau_conv_lean_try(hipStream_t s, int dtype, const msau_conv_desc* d, int kc
     if (a.ntiles >= (1 << 20) || a.tiles_x >= 4096 || a.tiles_y >= 4096) return 0;
     a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
     a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
+    if (d->dil == 2) return dtype == MSAU_F32 ? lean_dil<float, 2>(s, a, cin8, CT) : lean_dil<bf16_t, 2>(s, a, cin8, CT);
+    if (d->dil == 4) return dtype == MSAU_F32 ? lean_dil<float, 4>(s, a, cin8, CT) : lean_dil<bf16_t, 4>(s, a, cin8, CT);
+    if (d->dil == 8) return dtype == MSAU_F32 ? lean_dil<float, 8>(s, a, cin8, CT) : lean_dil<bf16_t, 8>(s, a, cin8, CT);
     if (d->KH == 4) return dtype == MSAU_F32 ? lean_ct<float, 1, 4, false>(s, a, CT) : lean_ct<bf16_t, 1, 4, false>(s, a, CT);
     if (dtype == MSAU_F32) return d->KH == 3 ? lean_cin<float, 3>(s, a, cin8, dual, CT) : lean_cin<float, 1>(s, a, cin8, dual, CT);
     return d->KH == 3 ? lean_cin<bf16_t, 3>(s, a, cin8, dual, CT) : lean_cin<bf16_t, 1>(s, a, cin8, dual, CT);
