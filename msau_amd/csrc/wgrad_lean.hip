@@ -17,10 +17,10 @@ struct WLeanArgs {
 
 typedef __attribute__((address_space(3))) bf16x4* lds_v4;
 
-template <typename T, int C8, int CO8, int KS>
+template <typename T, int C8, int CO8, int KS, int DIL = 1, int STRIDE = 1>
 struct WLeanCfg {
     static constexpr int ESZ = (int)sizeof(T);
-    static constexpr int TI = 16 + KS - 1;
+    static constexpr int TI = 15 * STRIDE + (KS - 1) * DIL + 1;
     static constexpr int PSX = ((C8 * 8 * ESZ / 16) % 2 == 0) ? C8 * 8 * ESZ + 16 : C8 * 8 * ESZ;
     static constexpr int PSG = ((CO8 * 8 * ESZ / 16) % 2 == 0) ? CO8 * 8 * ESZ + 16 : CO8 * 8 * ESZ;
     static constexpr int KREAL = KS * KS * C8 * 8;
@@ -33,9 +33,9 @@ struct WLeanCfg {
     static constexpr int LDS = X_BYTES + G_BYTES + 64;
 };
 
-template <typename T, int C8, int CO8, int KS>
+template <typename T, int C8, int CO8, int KS, int DIL = 1, int STRIDE = 1>
 __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanArgs a) {
-    using Cfg = WLeanCfg<T, C8, CO8, KS>;
+    using Cfg = WLeanCfg<T, C8, CO8, KS, DIL, STRIDE>;
     typedef typename Vec8<T>::type V8;
     constexpr int ESZ = Cfg::ESZ, TI = Cfg::TI, PSX = Cfg::PSX, PSG = Cfg::PSG, NKT = Cfg::NKT, NKW = Cfg::NKW, CTN = Cfg::CTN;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanArgs a) {
         if (k < Cfg::KREAL) {
             const int tap = k / (C8 * 8), c = k - tap * (C8 * 8);
             const int ky = tap / KS, kx = tap - ky * KS;
-            off = (ky * TI + kx) * PSX + c * ESZ;
+            off = (ky * DIL * TI + kx * DIL) * PSX + c * ESZ;
         } else if (k == Cfg::KREAL) off = WL_ABS | ONES;
         else off = WL_ABS | (ONES + 4 * ESZ);
         if (sizeof(T) == 4) off += (li & 3) * 4;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanArgs a) {
         const int b = a.tiles_y > 1 ? __umulhi((unsigned)t1, a.mag_ty) : t1;
         const int tyi = t1 - b * a.tiles_y;
         const int oy0 = tyi * 16, ox0 = txi * 16;
-        const int vy0 = oy0 - d.pad_t, vx0 = ox0 - d.pad_l;
+        const int vy0 = oy0 * STRIDE - d.pad_t, vx0 = ox0 * STRIDE - d.pad_l;
         {
             constexpr int NITEMS = TI * TI * C8;
             const char* base = xsrc + (long long)b * d.Hin * in_row + cb;
@@ -168,13 +168,13 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanArgs a) {
                     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(ga + 4 * PSG + ct * 32));
                     afrag[ct] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
-                const int pb0 = (row * TI + col) * PSX;
+                const int pb0 = (row * STRIDE * TI + col * STRIDE) * PSX;
 #pragma unroll
                 for (int i = 0; i < NKW; ++i) {
                     if (wave + 4 * i < NKT) {                          // wave-uniform
                         const int e = coloff[i];
                         const int o0 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + e;
-                        const int o1 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + 4 * PSX + e;
+                        const int o1 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + 4 * STRIDE * PSX + e;
                         bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o0));
                         bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o1));
                         bf16x8 bfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanArgs a) {
                 float afrag[CTN];
 #pragma unroll
                 for (int ct = 0; ct < CTN; ++ct) afrag[ct] = *reinterpret_cast<const float*>(lds_g + m * PSG + (ct * 16 + li) * 4);
-                const int pb = ((m >> 4) * TI + (m & 15)) * PSX;
+                const int pb = ((m >> 4) * STRIDE * TI + (m & 15) * STRIDE) * PSX;
 #pragma unroll
                 for (int i = 0; i < NKW; ++i) {
                     if (wave + 4 * i < NKT) {
@@ -220,18 +220,18 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanArgs a) {
     }
 }
 
-template <typename T, int C8, int CO8, int KS>
+template <typename T, int C8, int CO8, int KS, int DIL = 1, int STRIDE = 1>
 int launch_wlean(hipStream_t s, const WLeanArgs& a) {
-    using Cfg = WLeanCfg<T, C8, CO8, KS>;
+    using Cfg = WLeanCfg<T, C8, CO8, KS, DIL, STRIDE>;
     if (Cfg::KEXT != a.kextc) return 0;                              // geometry disagrees with the generic planner
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS > 60 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lean_kernel<T, C8, CO8, KS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lean_kernel<T, C8, CO8, KS, DIL, STRIDE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "wgrad_lean: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_lean_kernel<T, C8, CO8, KS>), dim3(a.d.nslabs, a.nchunks), dim3(256), Cfg::LDS, s, a);
+    hipLaunchKernelGGL((wgrad_lean_kernel<T, C8, CO8, KS, DIL, STRIDE>), dim3(a.d.nslabs, a.nchunks), dim3(256), Cfg::LDS, s, a);
     MSAU_CHECK_LAUNCH("wgrad_lean_kernel");
     return 1;
 }
@@ -245,19 +245,49 @@ int wlean_dispatch(hipStream_t s, const WLeanArgs& a, int c8, int co8) {
     return 0;
 }
 
+// dilated 3x3 (encoder level-entry convs) and the stride-2 form (transposed-conv weight gradient, roles swapped)
+template <typename T>
+int wlean_special(hipStream_t s, const WLeanArgs& a, int c8, int co8, int dil, int stride) {
+    if (stride == 2 && dil == 1) {
+        if (c8 == 1 && co8 == 2) return launch_wlean<T, 1, 2, 3, 1, 2>(s, a);
+        if (c8 == 2 && co8 == 4) return launch_wlean<T, 2, 4, 3, 1, 2>(s, a);
+        if (c8 == 4 && co8 == 8) return launch_wlean<T, 4, 8, 3, 1, 2>(s, a);
+        return 0;
+    }
+    if (stride == 1) {
+        if (dil == 2 && c8 == 1 && co8 == 2) return launch_wlean<T, 1, 2, 3, 2, 1>(s, a);
+        if (dil == 4 && c8 == 2 && co8 == 4) return launch_wlean<T, 2, 4, 3, 4, 1>(s, a);
+        if (dil == 8 && c8 == 4 && co8 == 8) return launch_wlean<T, 4, 8, 3, 8, 1>(s, a);
+    }
+    return 0;
+}
+
+static bool wlean_special_shape(int c8, int co8, int dil, int stride) {
+    if (stride == 2 && dil == 1) return (c8 == 1 && co8 == 2) || (c8 == 2 && co8 == 4) || (c8 == 4 && co8 == 8);
+    if (stride == 1) return (dil == 2 && c8 == 1 && co8 == 2) || (dil == 4 && c8 == 2 && co8 == 4) || (dil == 8 && c8 == 4 && co8 == 8);
+    return false;
+}
+
 }  // namespace
 
 static const int kLeanShapes[][2] = {{1, 1}, {1, 2}, {2, 1}, {2, 2}, {2, 4}, {4, 2}, {4, 4}, {8, 1}, {4, 8}, {8, 4}, {8, 8}};
 
 int msau_wgrad_lean_applicable(int dtype, const msau_wgrad_desc* d, int cch) {
-    if (d->stride != 1 || d->dil != 1 || d->KH != d->KW || (d->KH != 1 && d->KH != 3 && d->KH != 4)) return 0;
-    if (d->Hin != d->Hout || d->Win != d->Wout || d->pad_t < 0 || d->pad_l < 0 || d->pad_t >= d->KH || d->pad_l >= d->KW) return 0;
+    if (d->KH != d->KW || (d->KH != 1 && d->KH != 3 && d->KH != 4)) return 0;
+    const bool special = d->stride != 1 || d->dil != 1;
+    if (special) {
+        if (d->KH != 3 || d->C2 || cch != d->C1 || !wlean_special_shape(cch / 8, d->Cout / 8, d->dil, d->stride)) return 0;
+        if (d->pad_t != d->dil || d->pad_l != d->dil) return 0;
+    } else {
+        if (d->Hin != d->Hout || d->Win != d->Wout || d->pad_t < 0 || d->pad_l < 0 || d->pad_t >= d->KH || d->pad_l >= d->KW) return 0;
+    }
     if (d->KH == 4 && !(cch == 8 && d->Cout == 8)) return 0;
     const int esz = dtype == MSAU_F32 ? 4 : 2;
     if ((int64_t)d->Hin * d->Win * (d->C1 > d->C2 ? d->C1 : d->C2) * esz >= (1ll << 31)) return 0;
     if ((int64_t)d->Hout * d->Wout * d->Cout * esz >= (1ll << 31)) return 0;
     const int tx = cdiv(d->Wout, 16), ty = cdiv(d->Hout, 16);
     if ((int64_t)d->B * tx * ty >= (1 << 20) || tx >= 4096 || ty >= 4096) return 0;
+    if (special) return 1;
     for (auto& sh : kLeanShapes)
         if (sh[0] == cch / 8 && sh[1] == d->Cout / 8 && cch % 8 == 0) return 1;
     return 0;
@@ -273,6 +303,9 @@ int msau_wgrad_lean_try(hipStream_t s, int dtype, const msau_wgrad_desc* d, int 
     a.ntiles = d->B * a.tiles_x * a.tiles_y;
     a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
     a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
+    if (d->stride != 1 || d->dil != 1)
+        return dtype == MSAU_F32 ? wlean_special<float>(s, a, cch / 8, d->Cout / 8, d->dil, d->stride)
+                                 : wlean_special<bf16_t>(s, a, cch / 8, d->Cout / 8, d->dil, d->stride);
     if (d->KH == 4) return dtype == MSAU_F32 ? launch_wlean<float, 1, 1, 4>(s, a) : launch_wlean<bf16_t, 1, 1, 4>(s, a);
     if (dtype == MSAU_F32) return d->KH == 3 ? wlean_dispatch<float, 3>(s, a, cch / 8, d->Cout / 8) : wlean_dispatch<float, 1>(s, a, cch / 8, d->Cout / 8);
     return d->KH == 3 ? wlean_dispatch<bf16_t, 3>(s, a, cch / 8, d->Cout / 8) : wlean_dispatch<bf16_t, 1>(s, a, cch / 8, d->Cout / 8);
