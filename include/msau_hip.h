@@ -282,7 +282,8 @@ enum {
     MSAU_OP_POOL_BWD = 6,    /* args: msau_pool_args          */
     MSAU_OP_ATTN_FWD = 7,    /* args: msau_attn_args          */
     MSAU_OP_ATTN_BWD = 8,    /* args: msau_attn_args          */
-    MSAU_OP_CHANNEL_SUM = 9  /* args: msau_csum_args          */
+    MSAU_OP_CHANNEL_SUM = 9, /* args: msau_csum_args          */
+    MSAU_OP_WGRAD_REDUCE = 10 /* args: msau_reduce_args       */
 };
 typedef struct { int32_t kind; int32_t dtype; const void* args; } msau_op;
 typedef struct { const void* a; const void* dy; void* out; int64_t npix; int32_t C, Cs, n; float alpha, beta, k; } msau_lrn_args;
@@ -290,13 +291,14 @@ typedef struct { const void* x_or_dy; void* y_or_dx; uint8_t* idx; const void* m
 typedef struct { const void* f; const void* g; const void* h; const void* x_or_dy; void* y; float* stats;
                  void* df; void* dg; void* dh; float* ws; int32_t B, N, Ds, Cs; } msau_attn_args;
 typedef struct { const void* g; int64_t npix; int32_t Cs; float* partials; int32_t nblk; } msau_csum_args;
+typedef struct { const float* slab_arena; float* flat_grads; const msau_unpack_entry* table_dev; int32_t n_entries, max_elems; } msau_reduce_args;
 int msau_run_ops(void* stream, const msau_op* ops, int n);
 /* As msau_run_ops, but ops whose kind carries MSAU_OP_SIDE are enqueued on `side_stream` after everything
  * enqueued so far on `stream` (event fork); `stream` waits for `side_stream` at the end (join).  Used for
  * the weight gradients: they depend on a finished output gradient and feed nothing but the final slab
  * reduction, so they run beside the data-gradient chain. */
 #define MSAU_OP_SIDE 0x100
-int msau_run_ops_overlap(void* stream, void* side_stream, const msau_op* ops, int n);
+int msau_run_ops_overlap(void* stream, void* side_stream, const msau_op* ops, int n, int join);   /* join=0: leave the side stream running */
 
 /* misc */
 /* occupy the stream for ~microseconds (<= 200000) with a single sleeping wave: measurement aid only */

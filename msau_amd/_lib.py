@@ -76,7 +76,12 @@ class CsumArgs(C.Structure):
     _fields_ = [("g", vp), ("npix", i64), ("Cs", i32), ("partials", vp), ("nblk", i32)]
 
 
+class ReduceArgs(C.Structure):
+    _fields_ = [("slab_arena", vp), ("flat_grads", vp), ("table_dev", vp), ("n_entries", i32), ("max_elems", i32)]
+
+
 OP_SIDE = 0x100
+OP_WGRAD_REDUCE = 10
 OP_CONV2D, OP_WGRAD, OP_LRN_FWD, OP_LRN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_CHANNEL_SUM = range(1, 10)
 
 _SIGNATURES = {
@@ -109,7 +114,7 @@ _SIGNATURES = {
     "msau_raster_onehot": (C.c_int, [vp, C.c_int, vp, vp, vp] + [C.c_int] * 5),
     "msau_raster_labels": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "msau_run_ops": (C.c_int, [vp, C.POINTER(Op), C.c_int]),
-    "msau_run_ops_overlap": (C.c_int, [vp, vp, C.POINTER(Op), C.c_int]),
+    "msau_run_ops_overlap": (C.c_int, [vp, vp, C.POINTER(Op), C.c_int, C.c_int]),
     "msau_spin": (C.c_int, [vp, C.c_int]),
     "msau_fill_zero": (C.c_int, [vp, vp, i64]),
     "msau_softmax_channels_nchw": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, i64]),

@@ -16,7 +16,7 @@ extern "C" int msau_run_ops(void* stream, const msau_op* ops, int n) {
     return 0;
 }
 
-extern "C" int msau_run_ops_overlap(void* stream, void* side_stream, const msau_op* ops, int n) {
+extern "C" int msau_run_ops_overlap(void* stream, void* side_stream, const msau_op* ops, int n, int join) {
     MSAU_CHECK_ARG((ops || n == 0) && side_stream && side_stream != stream, "run_ops_overlap: bad args");
     static thread_local std::vector<hipEvent_t> pool;          // timing-disabled events, reused across calls
     hipStream_t ms = static_cast<hipStream_t>(stream), ss = static_cast<hipStream_t>(side_stream);
@@ -52,7 +52,7 @@ extern "C" int msau_run_ops_overlap(void* stream, void* side_stream, const msau_
         int rc = run_one(side ? side_stream : stream, o, i);
         if (rc) return rc;
     }
-    if (any_side) {
+    if (any_side && join) {
         hipEvent_t ev;
         int rc = next_event(&ev);
         if (rc) return rc;
@@ -102,6 +102,11 @@ static int run_one(void* stream, const msau_op& o, int i) {
             case MSAU_OP_CHANNEL_SUM: {
                 const msau_csum_args* a = static_cast<const msau_csum_args*>(o.args);
                 rc = msau_channel_sum(stream, o.dtype, a->g, a->npix, a->Cs, a->partials, a->nblk);
+                break;
+            }
+            case MSAU_OP_WGRAD_REDUCE: {
+                const msau_reduce_args* a = static_cast<const msau_reduce_args*>(o.args);
+                rc = msau_wgrad_reduce(stream, a->slab_arena, a->flat_grads, a->table_dev, a->n_entries, a->max_elems);
                 break;
             }
             default: return msau_set_error(MSAU_ERR_ARG, "run_ops: op %d has unknown kind %d", i, o.kind);

@@ -54,14 +54,14 @@ class GradSync:
     def grad_scale(self) -> float:
         return 1.0 / self.world
 
-    def start(self, i: int):
-        """Issue bucket i (call when the gradients in its range are final on the current stream)."""
+    def start(self, i: int, after=None):
+        """Issue bucket i.  Its gradients must be final on stream `after` (default: the current stream)."""
         if self.world == 1:
             return
         lo, hi = self.buckets[i]
         view = self.flat[lo:hi]
         if self._side is not None:
-            self._side.wait_stream(torch.cuda.current_stream())
+            self._side.wait_stream(after if after is not None else torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
                 self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:

@@ -334,7 +334,15 @@ class TrainEngine:
     def _fwd_bwd(self, plan: Plan, x, labels):
         plan.forward(self.model._flat, x, export=False)
         loss = plan.loss_grads(labels)
-        plan.backward(self.flat_grad)
+        if self.world > 1 and not self.use_graph:
+            # bucket i of GradSync = [end convs, last stage, ..., stage 0]; a stage's bucket is reduced over RCCL as
+            # soon as that stage's slab reduction is enqueued, while the earlier stages' backward still runs
+            nb = self.model.num_blocks
+            plan.backward(self.flat_grad, on_stage_done=lambda b, side: self.sync.start(nb - b, after=side))
+            self._ar_started = True
+        else:
+            plan.backward(self.flat_grad)
+            self._ar_started = False
         return loss
 
     def _optim(self):
@@ -346,7 +354,10 @@ class TrainEngine:
 
     def _allreduce(self):
         if self.world > 1:
-            self.sync.start_all()
+            if getattr(self, "_ar_started", False):
+                self.sync.start(0)                       # the end-conv tail: final once every stage is done
+            else:
+                self.sync.start_all()
             self.sync.finish()
 
     def step(self, x: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:

@@ -111,6 +111,7 @@ class ConvOp(Op):
         self.slots = []
         for x in (x1, x2):
             self.slots.append(x.register() if (x is not None and x.needs_grad) else None)
+        self.stage = plan._cur_stage
         plan.ops.append(self)
 
     # ---- helpers -------------------------------------------------------------------------
@@ -264,7 +265,7 @@ class ConvOp(Op):
             self.csum_off = P.alloc_slab(self.csum_blocks * out.Cs)
             u.b_src_off, u.b_slab_stride, u.b_elem_stride, u.b_nslabs = self.csum_off, out.Cs, 1, self.csum_blocks
             u.b_count = out.C
-        P.add_unpack_entry(u, rows_real * wg.nchunks * taps * wg.cch)
+        P.add_unpack_entry(u, rows_real * wg.nchunks * taps * wg.cch, self.stage)
 
     def late_bind(self):
         P = self.plan
@@ -360,6 +361,7 @@ class LrnOp(Op):
     def __init__(self, plan, name, a: Act, y: Act):
         self.plan, self.name, self.a, self.y = plan, name, a, y
         self.slot = a.register() if a.needs_grad else None
+        self.stage = plan._cur_stage
         plan.ops.append(self)
 
     def fwd_recs(self):
@@ -395,6 +397,7 @@ class PoolOp(Op):
         assert y.H == (x.H + 1) // 2 and y.W == (x.W + 1) // 2 and y.Cs == x.Cs
         self.idx = torch.zeros((plan.B, y.H, y.W, y.Cs), dtype=torch.uint8, device=plan.device)
         self.slot = x.register() if x.needs_grad else None
+        self.stage = plan._cur_stage
         plan.ops.append(self)
 
     def fwd_recs(self):
@@ -435,6 +438,7 @@ class AttnCoreOp(Op):
         for t in (f, g, h):
             t.register()
         # the residual path (dx += dy) is folded into the h-projection's data gradient (ConvOp.bwd_add)
+        self.stage = plan._cur_stage
         plan.ops.append(self)
 
     def _args(self, bwd):
@@ -477,9 +481,11 @@ class Plan:
         self._slab_elems = 0
         self._pack_entries: List[L.PackEntry] = []
         self._unpack_entries: List[L.UnpackEntry] = []
+        self._unpack_stage: List[int] = []
         self._pack_max = 1
         self._unpack_max = 1
         self.launch_meta: Dict[str, Tuple[int, float, float]] = {}
+        self._cur_stage = 0
         # The weight gradients form no dependency chain (each reads a finished out.grad and writes its own slabs),
         # so they run on a side stream beside the data-gradient chain.  Measured 2026-10-03 with the lean kernels:
         # 5.76 -> 5.20 ms/step (with the first, generic kernels it was 4 % slower: both chains were issue-bound).
@@ -510,8 +516,9 @@ class Plan:
         self._pack_entries.append(e)
         self._pack_max = max(self._pack_max, int(nelems))
 
-    def add_unpack_entry(self, e, nelems):
+    def add_unpack_entry(self, e, nelems, stage=0):
         self._unpack_entries.append(e)
+        self._unpack_stage.append(stage)
         self._unpack_max = max(self._unpack_max, int(nelems))
 
     def note_launch(self, key: str, nbytes: float, flops: float):
@@ -549,6 +556,7 @@ class Plan:
         prev_dw = prev_up = None
         self.stage_logits: List[Act] = []
         for b in range(nb):
+            self._cur_stage = b
             coupled, last = b > 0, b == nb - 1
             pd = f"msau_net.blocks.{b}.downsamplingblock"
             pu = f"msau_net.blocks.{b}.upsamplingblock"
@@ -638,9 +646,27 @@ class Plan:
             if isinstance(op, ConvOp):
                 op.late_bind()
         self._fwd_seq = self._make_seq([r for op in self.ops for r in op.fwd_recs()])
-        self._bwd_seq = self._make_seq([r for op in reversed(self.ops) for r in op.bwd_recs()]) if self.training else None
         self.pack_table = self._upload(self._pack_entries, L.PackEntry) if self._pack_entries else None
         self.unpack_table = self._upload(self._unpack_entries, L.UnpackEntry) if self._unpack_entries else None
+        self._bwd_seq, self._bwd_segs, self._reduce_args = None, [], []
+        if self.training:
+            # backward = stages in reverse; after a stage's last op its slabs are reduced into the flat gradient
+            # (on the side stream, behind that stage's weight gradients) while the next stage's backward runs
+            recs = []
+            stages = sorted({op.stage for op in self.ops}, reverse=True)
+            esz = C.sizeof(L.UnpackEntry)
+            for b in stages:
+                start = len(recs)
+                recs += [r for op in reversed(self.ops) if op.stage == b for r in op.bwd_recs()]
+                idx = [i for i, st in enumerate(self._unpack_stage) if st == b]
+                if idx:
+                    assert idx == list(range(idx[0], idx[-1] + 1)), "unpack entries of a stage must be contiguous"
+                    ra = L.ReduceArgs(self.slab_arena.data_ptr(), None, self.unpack_table.data_ptr() + idx[0] * esz,
+                                      len(idx), self._unpack_max)
+                    self._reduce_args.append(ra)
+                    recs.append((L.OP_WGRAD_REDUCE | (L.OP_SIDE if self.overlap_wgrad else 0), ra))
+                self._bwd_segs.append((b, start, len(recs) - start))
+            self._bwd_seq = self._make_seq(recs)
         HW = self.H * self.W
         lg = self.logits
         self.out_logits = torch.zeros((self.B, lg.C, lg.H, lg.W), dtype=torch.float32, device=self.device)
@@ -737,22 +763,39 @@ class Plan:
                    1.0 / self.B)
         return self.loss_buf
 
-    def backward(self, flat_grads: torch.Tensor):
-        """Run the backward sweep (external gradients must already be in place) and write the
-        flat fp32 parameter gradient."""
+    def backward(self, flat_grads: torch.Tensor, on_stage_done=None):
+        """Run the backward sweep (external gradients must already be in place) and write the flat fp32
+        parameter gradient.  `on_stage_done(stage, side_stream)` is called after each stage's launches are
+        enqueued (its slab reduction is the last thing on `side_stream`): the data-parallel engine starts that
+        stage's all-reduce bucket there."""
         s = self._stream()
-        if L._profiler is not None:
+        if L._profiler is not None:                      # per-launch timing path (bench roofline pass)
             for op in reversed(self.ops):
                 op.bwd(s)
-        elif not self.overlap_wgrad:
-            self._run_seq(self._bwd_seq, s)          # one C call enqueues the whole backward sweep
-        else:
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
-            L.call("msau_run_ops_overlap", s, self._side.cuda_stream, self._bwd_seq[0], self._bwd_seq[1])
-        if self.unpack_table is not None:
-            L.call("msau_wgrad_reduce", s, self.slab_arena.data_ptr(), flat_grads.data_ptr(), self.unpack_table.data_ptr(),
-                   len(self._unpack_entries), self._unpack_max)
+            if self.unpack_table is not None:
+                L.call("msau_wgrad_reduce", s, self.slab_arena.data_ptr(), flat_grads.data_ptr(), self.unpack_table.data_ptr(),
+                       len(self._unpack_entries), self._unpack_max)
+            return
+        for ra in self._reduce_args:
+            ra.flat_grads = flat_grads.data_ptr()
+        arr, n, _ = self._bwd_seq
+        if not self.overlap_wgrad:
+            L.call("msau_run_ops", s, arr, n)
+            if on_stage_done is not None:
+                for b, _, _ in self._bwd_segs:
+                    on_stage_done(b, torch.cuda.current_stream())
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side.cuda_stream
+        if on_stage_done is None:
+            L.call("msau_run_ops_overlap", s, side, arr, n, 1)
+            return
+        for i, (b, start, cnt) in enumerate(self._bwd_segs):
+            last = i == len(self._bwd_segs) - 1
+            seg = C.cast(C.byref(arr, start * C.sizeof(L.Op)), C.POINTER(L.Op))
+            L.call("msau_run_ops_overlap", s, side, seg, cnt, 1 if last else 0)
+            on_stage_done(b, self._side)
 
     def input_grad_nchw(self) -> torch.Tensor:
         """d(loss)/d(input) as NCHW fp32 (only with cfg['input_grad'], used by the op-level tests)."""
