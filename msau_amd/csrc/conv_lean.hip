@@ -8,6 +8,7 @@
 // one VGPR plus immediates, and small weight sets live in registers.  Same arithmetic, same packed
 // weight image, same epilogue contract as conv.hip (include/msau_hip.h).
 #include "msau_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -18,15 +19,18 @@ struct LeanArgs {
     int out_px, out_row;                         // bytes
     int tiles_x, tiles_y, ntiles;
     unsigned mag_tx, mag_ty;                     // ceil(2^32 / tiles_x), ceil(2^32 / tiles_y)
+    int per_xcd;                                 // tiles per XCD chunk (0: plain grid-stride tile order)
 };
 
-template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1>
+template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1>
 struct LeanCfg {
     static constexpr int ESZ = (int)sizeof(T);
-    static constexpr int TI = 16 + (KS - 1) * DIL;
+    static constexpr int TI = 16 + (KS - 1) * DIL;            // input tile rows
+    static constexpr int TIW = 16 * WGW + (KS - 1) * DIL;     // input tile columns (output tile = 16 x 16*WGW)
+    static constexpr int NT = 256 * WGW;                      // threads per workgroup
     static constexpr int PSRAW = CIN8 * 8 * ESZ;
     static constexpr int PS = ((PSRAW / 16) % 2 == 0) ? PSRAW + 16 : PSRAW;
-    static constexpr int NPIX = TI * TI;
+    static constexpr int NPIX = TI * TIW;
     // the packed image is chunk-major and a chunk never straddles the two sources: dual = 2 chunks
     static constexpr int NCH = DUAL ? 2 : 1;
     static constexpr int C8H = CIN8 / NCH;                    // 8-channel groups per chunk
@@ -39,16 +43,18 @@ struct LeanCfg {
     static constexpr int LDS = IN_BYTES + (WREG ? 0 : NCH * CT * 16 * WS);
 };
 
-template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1>
-__global__ __launch_bounds__(256) void conv_lean_kernel(const LeanArgs a) {
-    using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL>;
+template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1>
+__global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) {
+    using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL, WGW>;
+    constexpr int NT = Cfg::NT;
     typedef typename Vec8<T>::type V8;
     typedef typename Vec4<T>::type V4;
-    constexpr int ESZ = Cfg::ESZ, TI = Cfg::TI, PS = Cfg::PS, NKS = Cfg::NKS, NG = Cfg::NG, NKSH = Cfg::NKSH, C8H = Cfg::C8H;
+    constexpr int ESZ = Cfg::ESZ, TI = Cfg::TIW, PS = Cfg::PS, NKS = Cfg::NKS, NG = Cfg::NG, NKSH = Cfg::NKSH, C8H = Cfg::C8H;
     extern __shared__ __align__(16) unsigned char smem[];
     const msau_conv_desc& d = a.d;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all & 3, cwt = wave_all >> 2;       // 4 row groups x WGW column tiles
     const int lr = lane & 15, lg = lane >> 4;
     const bool relu_in = d.flags & MSAU_CONV_RELU_IN;
 
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(const LeanArgs a) {
     } else {
         unsigned char* lds_w = smem + Cfg::IN_BYTES;
         constexpr int WG8 = NKSH * 4;                          // 8-element groups per (chunk, row)
-        for (int idx = tid; idx < Cfg::NCH * CT * 16 * WG8; idx += 256) {
+        for (int idx = tid; idx < Cfg::NCH * CT * 16 * WG8; idx += NT) {
             int r = idx / WG8, g8 = idx - r * WG8;             // r = chunk * rows + row: the packed image order
             *reinterpret_cast<V8*>(lds_w + r * Cfg::WS + g8 * 8 * ESZ) = load8<T>(wp + (size_t)r * a.kchunk + g8 * 8);
         }
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(const LeanArgs a) {
         const int ky = tap / KS, kx = tap - ky * KS;
         koff[ks] = G < NG ? (ky * DIL * TI + kx * DIL) * PS + ((ks / NKSH) * C8H + cg) * 8 * ESZ : 0;
     }
-    const unsigned char* pixp = smem + ((wave * 4) * TI + lr) * PS;
+    const unsigned char* pixp = smem + ((wave * 4) * TI + cwt * 16 + lr) * PS;
 
     const int flags = d.flags;
     const int Cout = d.Cout;
@@ -92,19 +98,19 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(const LeanArgs a) {
     const long long delta_add = static_cast<const char*>(d.add) - static_cast<const char*>(d.y);
     const long long delta_ma = static_cast<const char*>(d.mask_a) - static_cast<const char*>(d.y);
     const long long delta_mb = static_cast<const char*>(d.mask_b) - static_cast<const char*>(d.y);
-    const int lane_out = lr * a.out_px + lg * (CT * 4) * ESZ;
+    const int lane_out = (cwt * 16 + lr) * a.out_px + lg * (CT * 4) * ESZ;
 
     // ---- staging: one source at a time so the base pointer stays scalar.  With few items per thread the
     // loads of tile t+1 are issued into registers before the MFMAs of tile t (software pipeline).
     constexpr int C8S = DUAL ? CIN8 / 2 : CIN8;                // 8-channel groups per source
     constexpr int NITEMS = Cfg::NPIX * C8S;
-    constexpr int NIT = (NITEMS + 255) / 256;
+    constexpr int NIT = (NITEMS + NT - 1) / NT;
     constexpr int NSRC = DUAL ? 2 : 1;
     constexpr bool PIPE = NIT * NSRC <= 6;
     V8 pre[NSRC][NIT];
     auto decode = [&](int tile, int& b, int& oy0, int& ox0) {
         const int t1 = a.tiles_x > 1 ? __umulhi((unsigned)tile, a.mag_tx) : tile;
-        ox0 = (tile - t1 * a.tiles_x) * 16;
+        ox0 = (tile - t1 * a.tiles_x) * (16 * WGW);
         b = a.tiles_y > 1 ? __umulhi((unsigned)t1, a.mag_ty) : t1;
         oy0 = (t1 - b * a.tiles_y) * 16;
     };
@@ -118,9 +124,9 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(const LeanArgs a) {
             const int in_row = sidx ? a.in_row2 : a.in_row1, in_px = sidx ? a.in_px2 : a.in_px1;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int idx = tid + it * 256;
+                const int idx = tid + it * NT;
                 pre[sidx][it] = zero8<T>();
-                if ((it + 1) * 256 <= NITEMS || idx < NITEMS) {
+                if ((it + 1) * NT <= NITEMS || idx < NITEMS) {
                     const int pix = idx / C8S, cg = idx - pix * C8S;
                     const int iy = pix / TI, ix = pix - iy * TI;
                     const int vy = vy0 + iy, vx = vx0 + ix;
@@ -135,8 +141,8 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(const LeanArgs a) {
         for (int sidx = 0; sidx < NSRC; ++sidx)
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int idx = tid + it * 256;
-                if ((it + 1) * 256 <= NITEMS || idx < NITEMS) {
+                const int idx = tid + it * NT;
+                if ((it + 1) * NT <= NITEMS || idx < NITEMS) {
                     const int pix = idx / C8S, cg = idx - pix * C8S;
                     V8 v = pre[sidx][it];
                     if (relu_in) v = relu8<T>(v);
@@ -144,16 +150,25 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(const LeanArgs a) {
                 }
             }
     };
-    if (PIPE && (int)blockIdx.x < a.ntiles) issue_loads(blockIdx.x);
+    // Workgroup i is dispatched to XCD i % 8 and every XCD has its own L2: give each XCD one contiguous run of tiles
+    // so that the halo rows and columns neighbouring tiles share are L2 hits instead of second HBM reads.
+    int tile0 = blockIdx.x, tend = a.ntiles, tstep = gridDim.x;
+    if (a.per_xcd) {
+        const int xcd = blockIdx.x & 7;
+        tile0 = xcd * a.per_xcd + (blockIdx.x >> 3);
+        tend = min(a.ntiles, (xcd + 1) * a.per_xcd);
+        tstep = gridDim.x >> 3;
+    }
+    if (PIPE && tile0 < tend) issue_loads(tile0);
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (int tile = tile0; tile < tend; tile += tstep) {
         int b, oy0, ox0;
         decode(tile, b, oy0, ox0);
         __syncthreads();                                       // previous tile's fragment reads are done
         if (!PIPE) issue_loads(tile);
         write_lds();
         __syncthreads();
-        if (PIPE && tile + (int)gridDim.x < a.ntiles) issue_loads(tile + gridDim.x);
+        if (PIPE && tile + tstep < tend) issue_loads(tile + tstep);
 
         f32x4 acc[CT][4];
 #pragma unroll
@@ -179,7 +194,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(const LeanArgs a) {
 
         // ---- epilogue: lane (pixel lr of row ty, q = lg) owns channels q*CT*4 + ct*4 + {0..3}
         const int oyw = oy0 + wave * 4;
-        if (ox0 + lr < d.Wout) {
+        if (ox0 + cwt * 16 + lr < d.Wout) {
             char* y = static_cast<char*>(d.y) + ((long long)(b * d.Hout + oyw)) * a.out_row + (long long)ox0 * a.out_px;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
@@ -226,27 +241,43 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(const LeanArgs a) {
     }
 }
 
-template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1>
-int launch_lean(hipStream_t s, const LeanArgs& a) {
-    using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL>;
+template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1>
+int launch_lean(hipStream_t s, const LeanArgs& a0) {
+    using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL, WGW>;
+    LeanArgs a = a0;
+    a.tiles_x = cdiv(a.d.Wout, 16 * WGW);
+    a.ntiles = a.d.B * a.tiles_x * a.tiles_y;
+    a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS > 60 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_lean: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
     int per_cu = MSAU_LDS_LIMIT / (Cfg::LDS + 256);
-    per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 8 / WGW ? 8 / WGW : per_cu);
     int grid = 256 * per_cu;
     if (grid > a.ntiles) grid = a.ntiles;
-    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL>), dim3(grid), dim3(256), Cfg::LDS, s, a);
+    static const bool xcd_off = std::getenv("MSAU_XCD") && std::getenv("MSAU_XCD")[0] == '0';
+    a.per_xcd = 0;
+    if (!xcd_off && grid >= 64) {
+        grid &= ~7;
+        a.per_xcd = cdiv(a.ntiles, 8);
+    }
+    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW>), dim3(grid), dim3(256 * WGW), Cfg::LDS, s, a);
     MSAU_CHECK_LAUNCH("conv_lean_kernel");
     return 1;
 }
 
 template <typename T, int CIN8, int KS, bool DUAL>
 int lean_ct(hipStream_t s, const LeanArgs& a, int CT) {
+    if constexpr (sizeof(T) == 2 && (CIN8 == 1 || (DUAL && CIN8 == 2)) && KS == 3) {
+        // 16 x 32 output tile per 512-thread workgroup for the 8/16-channel layers: same work per wave, but a halo
+        // row is 544 B (5-6 lines for 4.25 of payload) instead of 288 B (4 lines for 2.25)
+        if (CT == 1 && a.d.Wout >= 64 && (int64_t)a.d.B * a.tiles_y * cdiv(a.d.Wout, 32) >= 512)
+            return launch_lean<T, CIN8, 1, KS, DUAL, 1, 2>(s, a);
+    }
     if (CT == 1) return launch_lean<T, CIN8, 1, KS, DUAL>(s, a);
     if (CT == 2) return launch_lean<T, CIN8, 2, KS, DUAL>(s, a);
     if constexpr (CIN8 >= 4 && KS != 4) {
