@@ -226,6 +226,13 @@ def main():
                 "whole_step": {"alg_GB": round(sum(m[1] for m in plan.launch_meta.values()) / 1e9, 3),
                                "alg_TFLOP": round(sum(m[2] for m in plan.launch_meta.values()) / 1e12, 4),
                                "hbm_frac": round(sum(m[1] for m in plan.launch_meta.values()) * value / (world * args.batch) / 1e9 / HBM_PEAK_GBS, 4)}}
+        if (args.height, args.width, args.channels, args.stages) == (336, 256, 64, 3):
+            # SURVEY.md 8(d) compulsory-traffic model of the whole step (tools/roofline.py re-derives it)
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+            import roofline as RF
+            ach = RF.achieved(RF.CONFIGS["cfg2"], value / world, 2 if args.dtype == "bf16" else 4)
+            roof["whole_step"]["compulsory_hbm_frac"] = round(ach["hbm_frac"], 4)
+            roof["whole_step"]["compulsory_mfma_frac"] = round(ach["mfma_frac"], 4)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -124,3 +124,27 @@ def test_compute_without_gpu_raises_not_falls_back():
     m = MSAUWrapper(13, 5, dict(scale_space_num=3, res_depth=2, featRoot=8, final_act="softmax"))
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 13, 16, 16))
+
+
+def test_roofline_tool_known_answers():
+    """tools/roofline.py re-derives SURVEY.md 8(d)'s per-tile work from the architecture; these are its known answers."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("roofline", os.path.join(os.path.dirname(__file__), "..", "tools", "roofline.py"))
+    RF = importlib.util.module_from_spec(spec)
+    import sys
+    sys.modules["roofline"] = RF
+    spec.loader.exec_module(RF)
+    w = RF.work(RF.CONFIGS["cfg2"])
+    assert (w["convs"], w["deconvs"], w["params"]) == (98, 9, 636167)
+    assert round(w["conv_fwd_flops"] / 1e9, 3) == 8.434
+    assert round(w["attn_live_flops"] / 1e9, 3) == 0.520
+    assert round(w["first_conv_flops"] / 1e9, 3) == 0.793
+    assert round(w["train_flops"] / 1e9, 2) == 26.07
+    assert round(w["act_elems"] / 1e6, 2) == 76.75 and round(w["bytes_train"] / 1e6) == 460
+    assert w["bound"] == "hbm"
+    w1, w4 = RF.work(RF.CONFIGS["cfg1"]), RF.work(RF.CONFIGS["cfg4"])
+    assert round(w1["train_flops"] / 1e9, 2) == 1.52 and round(w1["act_elems"] / 1e6, 2) == 4.04
+    assert round(w4["train_flops"] / 1e9, 2) == 34.87 and round(w4["act_elems"] / 1e6, 1) == 110.9
+    # the parameter count of the walk agrees with the model's own table
+    cfg = dict(channels=64, n_class=5, featRoot=8, scale_space_num=4, res_depth=2, filter_size=3, num_blocks=3)
+    assert sum(int(np.prod(s)) for s in param_shapes(cfg).values()) == w["params"]
