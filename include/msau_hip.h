@@ -62,7 +62,13 @@ enum {
     MSAU_CONV_ADD      = 4,
     MSAU_CONV_ACCUM    = 8,
     MSAU_CONV_MASK_A   = 16,
-    MSAU_CONV_MASK_B   = 32
+    MSAU_CONV_MASK_B   = 32,
+    MSAU_CONV_HEAD     = 64     /* inference head (kv_model.py:305-313): besides y, write softmax over the Cout real
+                                   channels of the (storage-rounded) result to head_probs (fp32 [B][Hout][Wout][Cout],
+                                   dense) and the index of its first maximum to head_argmax (uint8 [B][Hout][Wout]).
+                                   Forward convs with Cout <= 16 and no other epilogue flag; see
+                                   msau_conv2d_launch_info: info[7] != 0 when the launch can take the flag, otherwise
+                                   run msau_softmax_argmax_nhwc on y. */
 };
 
 typedef struct {
@@ -82,6 +88,10 @@ typedef struct {
     const void* mask_a;
     const void* mask_b;
     void* y;
+    float* head_probs;          /* MSAU_CONV_HEAD only: fp32 [B][Hout][Wout][head_classes]          */
+    uint8_t* head_argmax;       /* MSAU_CONV_HEAD only: uint8 [B][Hout][Wout]                       */
+    int32_t head_classes;       /* MSAU_CONV_HEAD only: real classes (<= Cout, <= 16)               */
+    int32_t reserved;
 } msau_conv_desc;
 
 /* Geometry of the packed weight image the conv kernel expects for a given layer.
@@ -101,7 +111,8 @@ int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d);
 /* which template instance msau_conv2d launches for this descriptor (for profiling / roofline):
  * info[0] = CT (16-row output-channel tiles), info[1] = PT (pixel tiles per wave: tile = 4*PT x 16),
  * info[2] = dynamic LDS bytes, info[3] = workgroups, info[4] = channel chunk, info[5] = chunks,
- * info[6] = 1 if a compile-time-specialised "lean" instance (conv_lean.hip) takes the launch, info[7] = 0 */
+ * info[6] = 1 if a compile-time-specialised "lean" instance (conv_lean.hip) takes the launch,
+ * info[7] = 1 if that instance implements MSAU_CONV_HEAD for this descriptor */
 int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info8);
 
 /* ------------------------------------------------------------------------------------------
@@ -305,6 +316,18 @@ int msau_run_ops_overlap(void* stream, void* side_stream, const msau_op* ops, in
 int msau_spin(void* stream, int microseconds);
 int msau_fill_zero(void* stream, void* p, int64_t bytes);
 int msau_softmax_channels_nchw(void* stream, const float* logits, float* pred, int B, int C, int64_t hw);
+
+/* ------------------------------------------------------------------------------------------
+ * Inference head and input painter (next row N2; inference/kv_model.py:274-276,305-313).
+ *   msau_softmax_argmax_nhwc : probs[p][c] = softmax_c(logits[p][0..C)), argmax[p] = first maximum of probs[p];
+ *                              logits [npix][Cs] in `dtype` storage, probs fp32 [npix][C] dense, argmax uint8 [npix]
+ *                              (the stand-alone form of MSAU_CONV_HEAD, bit-identical to it; any C <= 255)
+ *   msau_onehot_ids          : grid[p][c] = (c == ids[p]) for c < C, 0 for C <= c < Cs -- to_categorical() of the
+ *                              character-id mask (generic_util.py:97-98) written straight into the NHWC input
+ * ------------------------------------------------------------------------------------------ */
+int msau_softmax_argmax_nhwc(void* stream, int dtype, const void* logits, float* probs, uint8_t* argmax,
+                             int64_t npix, int C, int Cs);
+int msau_onehot_ids(void* stream, int dtype, const int32_t* ids, void* grid_nhwc, int64_t npix, int C, int Cs);
 
 #ifdef __cplusplus
 }

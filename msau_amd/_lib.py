@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MSAU_HIP_LIB", os.path.join(HERE, "libmsau_hip.so"))
 
 F32, BF16 = 0, 1
 
-CONV_RELU_IN, CONV_RELU_OUT, CONV_ADD, CONV_ACCUM, CONV_MASK_A, CONV_MASK_B = 1, 2, 4, 8, 16, 32
+CONV_RELU_IN, CONV_RELU_OUT, CONV_ADD, CONV_ACCUM, CONV_MASK_A, CONV_MASK_B, CONV_HEAD = 1, 2, 4, 8, 16, 32, 64
 
 i32, i64, vp, f32 = C.c_int32, C.c_int64, C.c_void_p, C.c_float
 
@@ -21,7 +21,8 @@ i32, i64, vp, f32 = C.c_int32, C.c_int64, C.c_void_p, C.c_float
 class ConvDesc(C.Structure):
     _fields_ = [(n, i32) for n in ("B", "Hin", "Win", "Hout", "Wout", "C1", "C2", "Cout", "KH", "KW", "dil",
                                    "pad_t", "pad_l", "stride", "ups", "flags")] + \
-               [(n, vp) for n in ("x1", "x2", "wpack", "bias", "add", "mask_a", "mask_b", "y")]
+               [(n, vp) for n in ("x1", "x2", "wpack", "bias", "add", "mask_a", "mask_b", "y", "head_probs", "head_argmax")] + \
+               [("head_classes", i32), ("reserved", i32)]
 
 
 class ConvPackGeom(C.Structure):
@@ -118,6 +119,8 @@ _SIGNATURES = {
     "msau_spin": (C.c_int, [vp, C.c_int]),
     "msau_fill_zero": (C.c_int, [vp, vp, i64]),
     "msau_softmax_channels_nchw": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, i64]),
+    "msau_softmax_argmax_nhwc": (C.c_int, [vp, C.c_int, vp, vp, vp, i64, C.c_int, C.c_int]),
+    "msau_onehot_ids": (C.c_int, [vp, C.c_int, vp, vp, i64, C.c_int, C.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -282,6 +282,7 @@ static int conv_plan(int dtype, const msau_conv_desc* d, ConvGeom* gout, TileGeo
 // conv_lean.hip: compile-time-specialised instances for the hot layer shapes
 int msau_conv_lean_applicable(int dtype, const msau_conv_desc* d, int nchunks, int CT);
 int msau_conv_lean_try(hipStream_t s, int dtype, const msau_conv_desc* d, int kchunk, int nchunks, int CT);
+int msau_conv_lean_head_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT);
 
 extern "C" int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info) {
     MSAU_CHECK_ARG(d && info, "conv2d_launch_info: null pointer");
@@ -290,7 +291,7 @@ extern "C" int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32
     if (rc) return rc;
     info[0] = g.CT; info[1] = PT; info[2] = t.total; info[3] = (int32_t)nb; info[4] = g.cch; info[5] = g.nchunks;
     info[6] = msau_conv_lean_applicable(dtype, d, g.nchunks, g.CT);
-    info[7] = 0;
+    info[7] = msau_conv_lean_head_capable(dtype, d, g.nchunks, g.CT);
     return 0;
 }
 
@@ -320,6 +321,13 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
     ConvGeom g; TileGeom t; int PT; int64_t nb;
     int rc = conv_plan(dtype, d, &g, &t, &PT, &nb);
     if (rc) return rc;
+    if (d->flags & MSAU_CONV_HEAD) {
+        MSAU_CHECK_ARG(d->head_probs && d->head_argmax && d->head_classes > 0 && d->head_classes <= 16 &&
+                       d->head_classes <= d->Cout && d->flags == MSAU_CONV_HEAD, "conv2d: bad HEAD arguments");
+        if (!msau_conv_lean_head_capable(dtype, d, g.nchunks, g.CT))
+            return msau_set_error(MSAU_ERR_ARG, "conv2d: MSAU_CONV_HEAD is not implemented for this launch (see "
+                                  "msau_conv2d_launch_info info[7]); run msau_softmax_argmax_nhwc on y instead");
+    }
     rc = msau_conv_lean_try(static_cast<hipStream_t>(stream), dtype, d, g.kchunk, g.nchunks, g.CT);
     if (rc != 0) return rc < 0 ? rc : 0;
     ConvArgs a;

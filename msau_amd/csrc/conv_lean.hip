@@ -238,6 +238,37 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
                 }
             }
         }
+        // ---- inference head on the end conv (MSAU_CONV_HEAD): the 16 channel rows of a pixel sit in the four lanes
+        // (lr, q = 0..3); every lane gathers them, runs the shared softmax / first-max routine and writes its own
+        // channels.  Outside the divergent store guards above so that all lanes take part in the shuffles.
+        if constexpr (KS == 4 && CT == 1 && !DUAL) {
+            if (flags & MSAU_CONV_HEAD) {
+                const int ncls = d.head_classes;
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) {
+                    const f32x4 v = acc[0][pt] + bv[0];
+                    float all[16];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float mine = (float)(T)v[j];                 // the storage-rounded logit, as written to y
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) all[q * 4 + j] = __shfl(mine, q * 16 + lr);
+                    }
+                    const int best = msau_head_softmax(all, ncls);
+                    if (oyw + pt < d.Hout && ox0 + lr < d.Wout) {
+                        const long long pix = ((long long)b * d.Hout + oyw + pt) * d.Wout + ox0 + lr;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float pr = all[j];
+#pragma unroll
+                            for (int q = 1; q < 4; ++q) pr = lg == q ? all[q * 4 + j] : pr;
+                            if (lg * 4 + j < ncls) d.head_probs[pix * ncls + lg * 4 + j] = pr;
+                        }
+                        if (lg == 0) d.head_argmax[pix] = (unsigned char)best;
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -342,6 +373,11 @@ int msau_conv_lean_applicable(int dtype, const msau_conv_desc* d, int nchunks, i
     if (cin8 != 1 && cin8 != 2 && cin8 != 4 && cin8 != 8 && !(cin8 == 16 && dual && d->KH == 1)) return 0;
     if (dual && cin8 < 2) return 0;
     return 1;
+}
+
+// 1 if the lean instance that takes this launch implements MSAU_CONV_HEAD (the 4x4 end conv, one 16-row tile)
+int msau_conv_lean_head_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
+    return msau_conv_lean_applicable(dtype, d, nchunks, CT) && d->KH == 4 && CT == 1 && d->dil == 1;
 }
 
 int msau_conv_lean_try(hipStream_t s, int dtype, const msau_conv_desc* d, int kchunk, int nchunks, int CT) {

@@ -274,7 +274,7 @@ __global__ void pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint
 #pragma unroll
         for (int j = 0; j < 8; ++j) { o[j] = (T)best[j]; packed |= (uint64_t)bi[j] << (8 * j); }
         store8<T>(y + i * 8, o);
-        *reinterpret_cast<uint64_t*>(idx + i * 8) = packed;
+        if (idx) *reinterpret_cast<uint64_t*>(idx + i * 8) = packed;      // forward-only plans keep no indices
     }
 }
 
@@ -467,6 +467,44 @@ __global__ void softmax_nchw_kernel(const float* __restrict__ logits, float* __r
     }
 }
 
+// softmax + first-maximum index over the C real channels of NHWC logits, any C <= 255.  Operation for operation
+// msau_head_softmax() of msau_common.h (max, sum and product in channel order, __expf), which the conv epilogue
+// (MSAU_CONV_HEAD) uses for C <= 16: the two produce identical bits.
+template <typename T>
+__global__ void softmax_argmax_nhwc_kernel(const T* __restrict__ logits, float* __restrict__ probs,
+                                           uint8_t* __restrict__ amax, int64_t npix, int C, int Cs) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        const T* l = logits + p * Cs;
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, (float)l[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += __expf((float)l[c] - mx);
+        const float inv = 1.f / se;
+        int best = 0;
+        float bp = -1.f;
+        for (int c = 0; c < C; ++c) {
+            const float pr = __expf((float)l[c] - mx) * inv;
+            probs[p * C + c] = pr;
+            if (pr > bp) { bp = pr; best = c; }
+        }
+        amax[p] = (uint8_t)best;
+    }
+}
+
+template <typename T>
+__global__ void onehot_ids_kernel(const int32_t* __restrict__ ids, T* __restrict__ grid, int64_t npix, int C, int Cs) {
+    const int cgs = Cs >> 3;
+    const int64_t total = npix * cgs;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % cgs);
+        const int id = ids[i / cgs];
+        typename Vec8<T>::type o = zero8<T>();
+        const int j = id - cg * 8;
+        if (id >= 0 && id < C && j >= 0 && j < 8) o[j] = (T)1.0f;
+        store8<T>(grid + i * 8, o);
+    }
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16)                          \
@@ -530,7 +568,7 @@ extern "C" int msau_lrn_bwd(void* stream, int dtype, const void* a, const void* 
 }
 
 extern "C" int msau_maxpool2x2_fwd(void* stream, int dtype, const void* x, void* y, uint8_t* idx, int B, int H, int W, int Cs) {
-    MSAU_CHECK_ARG(x && y && idx && B > 0 && H > 0 && W > 0 && Cs % 8 == 0, "maxpool_fwd: bad args");
+    MSAU_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && Cs % 8 == 0, "maxpool_fwd: bad args");
     hipStream_t s = static_cast<hipStream_t>(stream);
     int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     int grid = grid_for((int64_t)B * Ho * Wo * (Cs / 8));
@@ -655,5 +693,26 @@ extern "C" int msau_softmax_channels_nchw(void* stream, const float* logits, flo
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(softmax_nchw_kernel, dim3(grid_for((int64_t)B * hw)), dim3(kThreads), 0, s, logits, pred, B, C, hw);
     MSAU_CHECK_LAUNCH("softmax_nchw");
+    return 0;
+}
+
+extern "C" int msau_softmax_argmax_nhwc(void* stream, int dtype, const void* logits, float* probs, uint8_t* argmax,
+                                        int64_t npix, int C, int Cs) {
+    MSAU_CHECK_ARG(logits && probs && argmax && npix > 0 && C > 0 && C <= 255 && C <= Cs, "softmax_argmax: bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(softmax_argmax_nhwc_kernel<float>, dim3(grid_for(npix)), dim3(kThreads), 0, s, static_cast<const float*>(logits), probs, argmax, npix, C, Cs),
+               hipLaunchKernelGGL(softmax_argmax_nhwc_kernel<bf16_t>, dim3(grid_for(npix)), dim3(kThreads), 0, s, static_cast<const bf16_t*>(logits), probs, argmax, npix, C, Cs));
+    MSAU_CHECK_LAUNCH("softmax_argmax_nhwc");
+    return 0;
+}
+
+extern "C" int msau_onehot_ids(void* stream, int dtype, const int32_t* ids, void* grid, int64_t npix, int C, int Cs) {
+    MSAU_CHECK_ARG(ids && grid && npix > 0 && C > 0 && Cs % 8 == 0 && C <= Cs, "onehot_ids: bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(onehot_ids_kernel<float>, dim3(grid_for(npix * (Cs / 8))), dim3(kThreads), 0, s, ids, static_cast<float*>(grid), npix, C, Cs),
+               hipLaunchKernelGGL(onehot_ids_kernel<bf16_t>, dim3(grid_for(npix * (Cs / 8))), dim3(kThreads), 0, s, ids, static_cast<bf16_t*>(grid), npix, C, Cs));
+    MSAU_CHECK_LAUNCH("onehot_ids");
     return 0;
 }

@@ -81,6 +81,27 @@ template <typename T> __device__ __forceinline__ void store4(T* p, typename Vec4
 //   f32 : eight v_mfma_f32_16x16x4_f32; instruction j takes element j of each lane's group, so the
 //         4 k-slots of instruction j are k = 8*(l>>4) + j for the 4 lane groups -- A and B agree,
 //         which is all the MFMA needs.  Exact fp32 products and sums.
+// Inference head (MSAU_CONV_HEAD / msau_softmax_argmax_nhwc): v[0..C) logits -> probabilities in place, returns the
+// index of the first maximum probability (np.argmax of the softmax output, kv_model.py:168).  Same operation order
+// as softmax_nchw_kernel so that the head and MSAUWrapper.forward's `pred` agree bit for bit.
+__device__ __forceinline__ int msau_head_softmax(float (&v)[16], int C) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) if (c < C) mx = fmaxf(mx, v[c]);
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) if (c < C) se += __expf(v[c] - mx);
+    const float inv = 1.f / se;
+    int best = 0;
+    float bp = -1.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) if (c < C) {
+        v[c] = __expf(v[c] - mx) * inv;
+        if (v[c] > bp) { bp = v[c]; best = c; }
+    }
+    return best;
+}
+
 __device__ __forceinline__ f32x4 mma8(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }

@@ -187,6 +187,9 @@ class MSAUWrapper(nn.Module):
         self.cfg = dict(channels=channels, n_class=n_class, scale_space_num=self.scale_space_num,
                         res_depth=self.res_depth, featRoot=self.featRoot, filter_size=self.filter_size,
                         pool_size=self.pool_size, num_blocks=self.num_blocks)
+        for opt in ("reuse_activations", "overlap_wgrad", "overlap_max_pix"):      # execution options of the plan
+            if opt in kw:
+                self.cfg[opt] = kw[opt]
 
         shapes = param_shapes(self.cfg)
         self._poff: Dict[str, int] = {}
@@ -246,15 +249,18 @@ class MSAUWrapper(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("MSAUWrapper runs on an MI355X through libmsau_hip.so; input must be a CUDA/HIP tensor "
                                "(there is no CPU fallback)")
-        if self._flat.device != x.device:
-            raise RuntimeError(f"model is on {self._flat.device}, input on {x.device}")
         B, C, H, W = x.shape
         if C != self.channels:
             raise ValueError(f"expected {self.channels} input channels, got {C}")
+        return self._plan_for_shape(B, H, W, x.device, training)
+
+    def _plan_for_shape(self, B: int, H: int, W: int, device, training: bool) -> Plan:
+        if self._flat.device != device:
+            raise RuntimeError(f"model is on {self._flat.device}, input on {device}")
         key = (B, H, W, training)
         plan = self._plans.get(key)
         if plan is None:
-            plan = Plan(self.cfg, B, H, W, self._dtype, x.device, self._poff, self._pshape, training=training)
+            plan = Plan(self.cfg, B, H, W, self._dtype, device, self._poff, self._pshape, training=training)
             self._plans[key] = plan
             while len(self._plans) > self.max_cached_plans:
                 self._plans.popitem(last=False)
@@ -283,6 +289,37 @@ class MSAUWrapper(nn.Module):
         else:
             pred = logits
         return pred, logits, aux
+
+    @torch.no_grad()
+    def predict_nhwc(self, inp: Optional[torch.Tensor] = None, ids: Optional[torch.Tensor] = None):
+        """Forward-only path for `KVModel.predict` (inference/kv_model.py:305-313): one of
+          inp float [B,C,H,W]   -- the dense grid the reference builds with to_categorical, or
+          ids int   [B,H,W]     -- the character-id mask itself; the one-hot grid is painted on the device
+        -> (pred fp32 [B,H,W,n_class] = softmax over classes, already in the NHWC order `_extract_value` wants,
+            argmax uint8 [B,H,W] = np.argmax(pred, -1)).
+        No activations are kept (buffers are reused by liveness) and softmax + argmax run in the last conv's epilogue.
+        The returned tensors are the plan's buffers: copy them before the next call if they must survive it."""
+        if (inp is None) == (ids is None):
+            raise ValueError("give exactly one of inp / ids")
+        if self.final_act != "softmax":
+            raise ValueError("predict_nhwc is the softmax head; final_act is %r" % (self.final_act,))
+        if self.n_class > 255:
+            raise ValueError("the argmax map is uint8: at most 255 classes")
+        if ids is not None:
+            if ids.dim() != 3:
+                raise ValueError("ids must be [B,H,W]")
+            ids = ids.to(device=self._flat.device, dtype=torch.int32).contiguous()
+            B, H, W = ids.shape
+            ref = ids
+        else:
+            inp = inp.contiguous().float()
+            B, C, H, W = inp.shape
+            ref = inp
+        if not ref.is_cuda:
+            raise RuntimeError("MSAUWrapper runs on an MI355X through libmsau_hip.so; input must be a CUDA/HIP tensor "
+                               "(there is no CPU fallback)")
+        plan = self._plan_for(inp, False) if ids is None else self._plan_for_shape(B, H, W, ref.device, False)
+        return plan.predict(self._flat, x_nchw=inp, ids=ids)
 
     def save(self, path):
         torch.save(self.state_dict(), path)

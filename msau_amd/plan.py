@@ -48,7 +48,8 @@ class Act:
         self.Cs = _ru(C, 8)
         self.relu_out = relu_out
         self.needs_grad = needs_grad and plan.training
-        self.data = torch.zeros((plan.B, H, W, self.Cs), dtype=plan.tdtype, device=plan.device)
+        # forward-only plans get their buffers from Plan._assign_buffers (liveness-based reuse), after the graph is known
+        self.data = None if plan.reuse else torch.zeros((plan.B, H, W, self.Cs), dtype=plan.tdtype, device=plan.device)
         self.grad: Optional[torch.Tensor] = None
         self.n_contrib = 0
         plan.acts.append(self)
@@ -74,6 +75,12 @@ class Act:
 class Op:
     name = "op"
 
+    def reads(self) -> List["Act"]:
+        return []
+
+    def writes(self) -> List["Act"]:
+        return []
+
     def finalize(self):
         pass
 
@@ -91,8 +98,9 @@ class ConvOp(Op):
 
     def __init__(self, plan: "Plan", name: str, x1: Act, x2: Optional[Act], wname: str, bname: str, out: Act,
                  k: int, dil: int = 1, relu_in: bool = False, relu_out: bool = False,
-                 fwd_add: Optional[Act] = None, kind: str = "conv"):
+                 fwd_add: Optional[Act] = None, kind: str = "conv", head: bool = False):
         self.plan, self.name, self.x1, self.x2, self.out = plan, name, x1, x2, out
+        self.head = head            # forward-only: also emit softmax probabilities + argmax (MSAU_CONV_HEAD)
         self.wname, self.bname, self.k, self.dil, self.kind = wname, bname, k, dil, kind
         self.relu_in, self.relu_out, self.fwd_add = relu_in, relu_out, fwd_add
         self.bwd_add: Optional[Act] = None
@@ -113,6 +121,12 @@ class ConvOp(Op):
             self.slots.append(x.register() if (x is not None and x.needs_grad) else None)
         self.stage = plan._cur_stage
         plan.ops.append(self)
+
+    def reads(self):
+        return [t for t in (self.x1, self.x2, self.fwd_add) if t is not None]
+
+    def writes(self):
+        return [self.out]
 
     # ---- helpers -------------------------------------------------------------------------
     def _geom(self, C1, C2, Cout, dil, stride, ups):
@@ -184,6 +198,15 @@ class ConvOp(Op):
         d.wpack, d.bias = P.pack_ptr(self.w_off), P.pack_ptr(self.b_off)
         d.add = _ptr(self.fwd_add.data) if self.fwd_add is not None else None
         d.y = _ptr(out.data)
+        if self.head:
+            # softmax + argmax in the end conv's epilogue when the instance taking the launch implements it,
+            # otherwise Plan.predict runs the stand-alone kernel on the stored logits (same arithmetic)
+            d.head_probs, d.head_argmax, d.head_classes = _ptr(P.head_probs), _ptr(P.head_argmax), out.C
+            info = (L.i32 * 8)()
+            L.call("msau_conv2d_launch_info", P.dtype, C.byref(d), info)
+            P.head_fused = bool(info[7]) and d.flags == 0 and out.C <= 16
+            if P.head_fused:
+                d.flags = L.CONV_HEAD
         self.fdesc = d
         self.ddesc = [None, None]
         self.wdesc = None
@@ -364,6 +387,12 @@ class LrnOp(Op):
         self.stage = plan._cur_stage
         plan.ops.append(self)
 
+    def reads(self):
+        return [self.a]
+
+    def writes(self):
+        return [self.y]
+
     def fwd_recs(self):
         a, y = self.a, self.y
         self._fa = L.LrnArgs(_ptr(a.data), None, _ptr(y.data), a.npix, a.C, a.Cs, a.C, 1e-4, 0.75, 1.0)
@@ -395,10 +424,16 @@ class PoolOp(Op):
     def __init__(self, plan, name, x: Act, y: Act):
         self.plan, self.name, self.x, self.y = plan, name, x, y
         assert y.H == (x.H + 1) // 2 and y.W == (x.W + 1) // 2 and y.Cs == x.Cs
-        self.idx = torch.zeros((plan.B, y.H, y.W, y.Cs), dtype=torch.uint8, device=plan.device)
+        self.idx = torch.zeros((plan.B, y.H, y.W, y.Cs), dtype=torch.uint8, device=plan.device) if plan.training else None
         self.slot = x.register() if x.needs_grad else None
         self.stage = plan._cur_stage
         plan.ops.append(self)
+
+    def reads(self):
+        return [self.x]
+
+    def writes(self):
+        return [self.y]
 
     def fwd_recs(self):
         x, y = self.x, self.y
@@ -441,6 +476,12 @@ class AttnCoreOp(Op):
         self.stage = plan._cur_stage
         plan.ops.append(self)
 
+    def reads(self):
+        return [self.f, self.g, self.h, self.x]
+
+    def writes(self):
+        return [self.y]
+
     def _args(self, bwd):
         return L.AttnArgs(_ptr(self.f.data), _ptr(self.g.data), _ptr(self.h.data),
                           _ptr(self.y.grad) if bwd else _ptr(self.x.data), _ptr(self.y.data), _ptr(self.stats),
@@ -475,6 +516,10 @@ class Plan:
         self.cfg, self.B, self.H, self.W, self.dtype, self.device = cfg, B, H, W, dtype, device
         self.tdtype = torch.float32 if dtype == L.F32 else torch.bfloat16
         self.poff, self.pshape, self.training = poff, pshape, training
+        # forward-only plans keep no activation beyond its last reader: buffers are handed out by liveness
+        self.reuse = (not training) and bool(cfg.get("reuse_activations", True))
+        self.head_probs = self.head_argmax = None
+        self.head_fused = False
         self.acts: List[Act] = []
         self.ops: List[Op] = []
         self._pack_bytes = 0
@@ -619,7 +664,8 @@ class Plan:
                 cur = x2
             logits = Act(self, f"s{b}.logits", self.H, self.W, ncls)
             ConvOp(self, f"s{b}.end", cur, None, f"msau_net.end_convs.{b}.custom_conv.weight",
-                   f"msau_net.end_convs.{b}.custom_conv.bias", logits, 4)          # model.py:390, 375-376
+                   f"msau_net.end_convs.{b}.custom_conv.bias", logits, 4,          # model.py:390, 375-376
+                   head=(not self.training and b == nb - 1 and ncls <= 255))
             self.stage_logits.append(logits)
             inp, prev_dw, prev_up = logits, dw, up
         self.logits = self.stage_logits[-1]
@@ -632,7 +678,13 @@ class Plan:
             for t in (self.logits, self.aux):
                 if t is not None:
                     self.ext_slot[t.name] = t.register()
-        # ---- allocate gradients, pack images, descriptors
+        # ---- allocate activations (forward-only), gradients, pack images, descriptors
+        if self.reuse:
+            self._assign_buffers()
+        if not self.training and self.logits.C <= 255:
+            lg = self.logits
+            self.head_probs = torch.zeros((self.B, lg.H, lg.W, lg.C), dtype=torch.float32, device=self.device)
+            self.head_argmax = torch.zeros((self.B, lg.H, lg.W), dtype=torch.uint8, device=self.device)
         for a in self.acts:
             a.alloc_grad()
         for op in self.ops:
@@ -677,6 +729,45 @@ class Plan:
             self.ce_ws = torch.zeros((int(L.load().msau_ce_ws_floats(self.B * HW)),), dtype=torch.float32, device=self.device)
             self.loss_buf = torch.zeros((1,), dtype=torch.float32, device=self.device)
 
+    def _assign_buffers(self):
+        """Forward-only: give every activation a buffer that is free from its producer to its last reader.  Buffers are
+        pooled by exact byte size (the sizes repeat per level), a producer never gets a buffer one of its own inputs
+        still occupies, and the tensors read after the sweep (all stage logits: aux + final) are never released."""
+        last_read: Dict[int, int] = {}
+        for i, op in enumerate(self.ops):
+            for t in op.reads():
+                last_read[id(t)] = i
+        keep = {id(t) for t in getattr(self, "stage_logits", [])} | {id(t) for t in (self.logits, self.aux) if t is not None}
+        free: Dict[int, List[torch.Tensor]] = {}
+        self.buffers: List[torch.Tensor] = []
+
+        def take(a: Act):
+            n = self.B * a.H * a.W * a.Cs
+            pool = free.setdefault(n, [])
+            if pool:
+                buf = pool.pop()
+            else:
+                buf = torch.zeros((n,), dtype=self.tdtype, device=self.device)
+                self.buffers.append(buf)
+            a.data = buf.view(self.B, a.H, a.W, a.Cs)
+            a._buf = buf
+
+        def release(a: Act):
+            if id(a) not in keep and a.data is not None:
+                free[a._buf.numel()].append(a._buf)
+
+        take(self.x_in)
+        for i, op in enumerate(self.ops):
+            for t in op.writes():
+                if t.data is None:
+                    take(t)
+            for t in set(op.reads()) | set(op.writes()):
+                if last_read.get(id(t), -1) <= i and (t in op.reads() or id(t) not in last_read):
+                    release(t)
+        for a in self.acts:                       # anything no op touches (custom builders)
+            if a.data is None:
+                take(a)
+
     def _make_seq(self, recs):
         """(kind, args struct) records -> (msau_op array, n); the structs are kept alive by the ops / this list"""
         arr = (L.Op * max(len(recs), 1))()
@@ -710,6 +801,30 @@ class Plan:
             (self.B, self.cfg["channels"], self.H, self.W), (x_nchw.shape, x_nchw.dtype)
         a = self.x_in
         L.call("msau_nchw_to_nhwc", self._stream(), self.dtype, x_nchw.data_ptr(), a.data.data_ptr(), self.B, a.C, a.Cs, self.H, self.W)
+
+    def load_ids(self, ids: torch.Tensor):
+        """Paint the one-hot input from a character-id mask int32 [B,H,W] (to_categorical, generic_util.py:97-98):
+        H*W*4 bytes cross PCIe instead of the dense H*W*C float grid."""
+        assert ids.dtype == torch.int32 and ids.is_contiguous() and tuple(ids.shape) == (self.B, self.H, self.W), (ids.shape, ids.dtype)
+        a = self.x_in
+        L.call("msau_onehot_ids", self._stream(), self.dtype, ids.data_ptr(), a.data.data_ptr(), a.npix, a.C, a.Cs)
+
+    def predict(self, flat_params: torch.Tensor, x_nchw: Optional[torch.Tensor] = None, ids: Optional[torch.Tensor] = None):
+        """Forward-only sweep ending in the inference head -> (probs fp32 [B,H,W,n_class], argmax uint8 [B,H,W]),
+        the NHWC layout `KVModel._extract_value` consumes (kv_model.py:305-313).  The buffers are the plan's own."""
+        assert not self.training and self.head_probs is not None
+        s = self._stream()
+        self.pack(flat_params)
+        if ids is not None:
+            self.load_ids(ids)
+        else:
+            self.load_input(x_nchw)
+        self._run_seq(self._fwd_seq, s)
+        if not self.head_fused:
+            lg = self.logits
+            L.call("msau_softmax_argmax_nhwc", s, self.dtype, lg.data.data_ptr(), self.head_probs.data_ptr(),
+                   self.head_argmax.data_ptr(), lg.npix, lg.C, lg.Cs)
+        return self.head_probs, self.head_argmax
 
     def forward(self, flat_params: torch.Tensor, x_nchw: torch.Tensor, export: bool = True):
         s = self._stream()

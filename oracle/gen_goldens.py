@@ -273,3 +273,160 @@ def funsd_goldens():
 
 if __name__ == "__main__" and os.environ.get("MSAU_GOLDEN_FUNSD", "1") == "1":
     funsd_goldens()
+
+
+# ---------------------------------------------------------------------------------------------
+# G5: inference-side goldens.  Synthetic layout+OCR JSON -> the reference's own
+# KVModel._generate_masks_from_label / _extract_value / post_process_kv / read_json_gt /
+# sort_box_reading_order / morph helpers, plus the reference network's NHWC prediction for the
+# painted one-hot input (weights from seeds, as in the net goldens).  cv2 / skimage are only
+# used by the reference's drawing code and are stubbed.
+# ---------------------------------------------------------------------------------------------
+def kv_goldens():
+    import copy, json, random, types, warnings
+    warnings.simplefilter("ignore")
+    for name in ("cv2", "skimage", "skimage.morphology"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            if name == "skimage.morphology":
+                m.skeletonize = lambda *a, **k: None
+            sys.modules[name] = m
+    with contextlib.redirect_stdout(io.StringIO()):
+        from inference import kv_model as RK                 # reference
+        from inference import generic_util as RG             # reference
+        from inference import morph_util as RM               # reference
+    out_dir = os.path.join(OUT, "kv")
+    os.makedirs(out_dir, exist_ok=True)
+    charset = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0:-./#"
+    with open(os.path.join(out_dir, "charset.txt"), "w") as fh:
+        fh.write(charset)
+    n_class = 17
+    words = ["Bank", "of", "Elm", "Branch:", "North-7", "Acct", "No.", "00123-4567", "Type", "Savings", "Name", "J. Doe",
+             "KANA", "ジョン", "Inst.", "First Union", "", "Ref#", "2019/03/07", "x"]
+
+    def make_doc(seed, n_lines):
+        r = random.Random(seed)
+        lines, y = [], r.randint(40, 120)
+        for i in range(n_lines):
+            h = r.randint(18, 34)
+            x = r.randint(30, 400)
+            for _ in range(r.randint(1, 3)):                 # several cells on the same row
+                text = " ".join(r.choice(words) for _ in range(r.randint(1, 3))).strip()
+                w = max(10, int(h * 0.55 * max(len(text), 1)) + r.randint(-4, 8))
+                value = r.choice([0, 0, 1, 2, 3, 4, 4, 5, 6, 9, 10, 10, 11, 12])
+                lines.append({"box": [x, y, x + w, y + h], "text": text, "type": r.choice([0, 1, 2]), "value": value})
+                x += w + r.randint(12, 60)
+            y += h + r.randint(4, 26)
+        return {"img_shape": [y + 60, 1200], "lines": lines}
+
+    res, meta = {}, {}
+    rk = RK.KVModel()
+    rk.charset = " " + "$" + charset
+    rk.tok_to_id = {t: i for i, t in enumerate(rk.charset)}
+    rk.id_to_tok = {i: t for t, i in rk.tok_to_id.items()}
+    rk.n_token = len(rk.tok_to_id)
+    rk.n_class = n_class
+    meta["n_token"], meta["n_class"] = rk.n_token, n_class
+
+    def jsonable(o):
+        if isinstance(o, (np.integer,)):
+            return int(o)
+        if isinstance(o, (np.floating,)):
+            return float(o)
+        if isinstance(o, (list, tuple)):
+            return [jsonable(v) for v in o]
+        if isinstance(o, dict):
+            return {str(k): jsonable(v) for k, v in o.items()}
+        return o
+
+    for di, (seed, n_lines) in enumerate(((11, 7), (12, 12), (13, 4))):
+        doc = make_doc(seed, n_lines)
+        path = os.path.join(out_dir, f"layout{di}.json")
+        with open(path, "w") as fh:
+            json.dump(doc, fh, ensure_ascii=False)
+        inp, line_mask, char_mask, lines, scale, bg_pad, bbox = rk._generate_masks_from_label(path)
+        res[f"d{di}.input_mask"], res[f"d{di}.line_mask"], res[f"d{di}.char_mask"] = inp, line_mask, char_mask
+        m = {"scale": float(scale), "bg_pad": int(bg_pad), "bbox": [int(v) for v in bbox], "lines": jsonable(lines)}
+        # a plausible class map: every line votes for class value+1 over (part of) its box; some lines are split
+        # between two classes, some classes get several blobs, everything else is background; then noise
+        r = np.random.RandomState(seed)
+        H, W = inp.shape
+        score = r.rand(H, W, n_class).astype(np.float32) * 0.6
+        score[:, :, 0] += 1.0
+        for li, l in enumerate(lines):
+            x1, y1, x2, y2 = l["box"]
+            c = doc["lines"][li]["value"] + 1 if doc["lines"][li]["value"] > 0 else 0
+            if c < 2:
+                continue
+            if r.rand() < 0.35 and x2 - x1 > 8:              # shared line: second half goes to the next class
+                xm = (x1 + x2) // 2
+                score[y1:y2, x1:xm, c] += 2.0
+                score[y1:y2, xm:x2, min(c + 1, n_class - 1)] += 2.0
+            else:
+                score[y1:y2, x1:x2, c] += 2.0
+            if r.rand() < 0.3:                                 # a stray blob of the same class elsewhere
+                yy, xx = r.randint(0, max(1, H - 3)), r.randint(0, max(1, W - 6))
+                score[yy:yy + 3, xx:xx + 6, c] += 2.5
+        e = np.exp(score - score.max(-1, keepdims=True))
+        pred = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+        res[f"d{di}.pred"] = pred.astype(np.float16)          # the test feeds exactly these (fp16-rounded) values
+        pred_in = res[f"d{di}.pred"].astype(np.float32)
+        values, new_mask = rk._extract_value(line_mask, char_mask, copy.deepcopy(lines), pred_in, n_class)
+        m["values"] = jsonable(values)
+        res[f"d{di}.kept"] = new_mask[:, :, 1:].astype(np.uint8)
+        res[f"d{di}.kept0"] = new_mask[:, :, 0].astype(np.float32)
+        m["kv"] = jsonable(RK.post_process_kv(values))
+        gt = RG.read_json_gt(path, scale=scale, offset=(bbox[0] - bg_pad, bbox[1] - bg_pad))
+        m["gt"] = jsonable(gt)
+        meta[f"d{di}"] = m
+
+    # reading order / morphology on random inputs
+    r = random.Random(5)
+    ro = []
+    for _ in range(6):
+        cells = []
+        for i in range(r.randint(1, 9)):
+            x, y, w, h = r.randint(0, 300), r.randint(0, 200), r.randint(5, 120), r.randint(5, 40)
+            cells.append({"box": [x, y, x + w, y + h], "tag": i})
+        order = [c["tag"] for c in RG.sort_box_reading_order(copy.deepcopy(cells))]
+        ro.append({"cells": cells, "order": order})
+    meta["reading_order"] = ro
+    rs = np.random.RandomState(9)
+    for i, (shape, p) in enumerate((((23, 31), 0.35), ((8, 50), 0.6), ((40, 7), 0.2))):
+        mk = rs.rand(*shape) < p
+        res[f"morph{i}.in"] = mk
+        res[f"morph{i}.closing13"] = RM.r_closing(mk, (1, 3))
+        res[f"morph{i}.opening22"] = RM.r_opening(mk, (2, 2))
+        lab, objs = RM.connected_components(mk)
+        res[f"morph{i}.labels"] = lab.astype(np.int32)
+        res[f"morph{i}.objects"] = np.array([[o[0].start, o[0].stop, o[1].start, o[1].stop] for o in objs], np.int32)
+    boxes = [[rs.randint(0, 50), rs.randint(0, 50)] for _ in range(12)]
+    boxes = [[x, y, x + rs.randint(1, 40), y + rs.randint(1, 40)] for x, y in boxes]
+    meta["boxes"] = boxes
+    meta["filter_overlap"] = jsonable(RM.filter_overlap_boxes(copy.deepcopy(boxes), return_indices=True))
+    meta["filter_overlap_bigger"] = jsonable(RM.filter_overlap_boxes_bigger(copy.deepcopy(boxes), intersect_thres=0.5, return_indices=True))
+    meta["iou"] = [[float(RM.IoU(a, b)) for b in boxes[:4]] for a in boxes[:4]]
+    meta["intersect_area"] = [[float(RM.intersect_area(a, b)) for b in boxes[:4]] for a in boxes[:4]]
+
+    # the reference network on the painted input of doc 0 (kv_model.py:274-279,305-309), weights from seeds
+    cfg = dict(channels=rk.n_token, n_class=n_class, featRoot=8, scale_space_num=4, res_depth=2, filter_size=3,
+               pool_size=2, num_blocks=3)
+    sd = O.init_params(cfg, 77)
+    net = build_ref(cfg)
+    net.load_state_dict(sd)
+    net.eval()
+    inp = res["d0.input_mask"]
+    batch_x = torch.from_numpy(np.expand_dims(RG.to_categorical(inp, rk.n_token), 0)).transpose(1, -1).transpose(2, 3).float()
+    with torch.set_grad_enabled(False):
+        a_pred, _, _ = net(batch_x)
+        a_pred = torch.transpose(a_pred, 1, -1).transpose(1, 2).numpy()
+    res["net.pred_nhwc"] = a_pred[0]
+    meta["net"] = {"cfg": cfg, "seed": 77, "weights_checksum": checksum(sd)}
+    np.savez_compressed(os.path.join(out_dir, "kv.npz"), **res)
+    with open(os.path.join(out_dir, "kv.json"), "w") as fh:
+        json.dump(meta, fh, ensure_ascii=False, indent=1)
+    print("wrote kv goldens", {k: v.shape for k, v in res.items() if k.endswith("input_mask")}, a_pred.shape)
+
+
+if __name__ == "__main__" and os.environ.get("MSAU_GOLDEN_KV", "1") == "1":
+    kv_goldens()
