@@ -129,9 +129,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or os.environ.get("MSAU_FORCE_DIST") == "1":       # the latter: RCCL rehearsal on one GPU (msau_amd/dp.py)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(os.environ.get("MSAU_DIST_BACKEND", "nccl"), device_id=dev)
 
     from msau_amd import _lib as L
@@ -251,7 +254,7 @@ def main():
                           "graph": bool(args.graph), "loss": round(loss_val, 5)},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or os.environ.get("MSAU_FORCE_DIST") == "1":
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -13,6 +13,7 @@ so that  mean_r(grad loss_r)  ==  grad of the same expression over the global ba
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -42,13 +43,19 @@ class GradSync:
         self.flat = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # MSAU_FORCE_DIST=1 keeps the exchange step in the sequence at world size 1 (an identity all-reduce): a
+        # rehearsal of the RCCL path -- side stream, per-stage buckets, joins -- on a one-GPU box
+        self.active = self.world > 1 or (os.environ.get("MSAU_FORCE_DIST") == "1" and dist.is_available() and dist.is_initialized())
         n = flat_grad.numel()
         self.buckets = list(buckets) if buckets else [(0, n)]
         covered = sorted(self.buckets)
         assert covered[0][0] == 0 and covered[-1][1] == n and all(a[1] == b[0] for a, b in zip(covered, covered[1:])), \
             "buckets must tile the flat buffer"
         self._pending = []
-        self._side = torch.cuda.Stream() if flat_grad.is_cuda else None
+        self._side = None
+        if flat_grad.is_cuda:
+            from . import _lib
+            self._side = _lib.concurrent_stream(flat_grad.device, index=1)      # overlaps with the compute stream
 
     @property
     def grad_scale(self) -> float:
@@ -56,7 +63,7 @@ class GradSync:
 
     def start(self, i: int, after=None):
         """Issue bucket i.  Its gradients must be final on stream `after` (default: the current stream)."""
-        if self.world == 1:
+        if not self.active:
             return
         lo, hi = self.buckets[i]
         view = self.flat[lo:hi]

@@ -291,14 +291,16 @@ class MSAUWrapper(nn.Module):
         return pred, logits, aux
 
     @torch.no_grad()
-    def predict_nhwc(self, inp: Optional[torch.Tensor] = None, ids: Optional[torch.Tensor] = None):
+    def predict_nhwc(self, inp: Optional[torch.Tensor] = None, ids: Optional[torch.Tensor] = None, graph: bool = False):
         """Forward-only path for `KVModel.predict` (inference/kv_model.py:305-313): one of
           inp float [B,C,H,W]   -- the dense grid the reference builds with to_categorical, or
           ids int   [B,H,W]     -- the character-id mask itself; the one-hot grid is painted on the device
         -> (pred fp32 [B,H,W,n_class] = softmax over classes, already in the NHWC order `_extract_value` wants,
             argmax uint8 [B,H,W] = np.argmax(pred, -1)).
         No activations are kept (buffers are reused by liveness) and softmax + argmax run in the last conv's epilogue.
-        The returned tensors are the plan's buffers: copy them before the next call if they must survive it."""
+        The returned tensors are the plan's buffers: copy them before the next call if they must survive it.
+        graph=True replays the sweep as a HIP graph (captured per shape on first use, on a dedicated stream): at
+        batch 1 the ~120 launches are host-bound and the replay is what sets the latency."""
         if (inp is None) == (ids is None):
             raise ValueError("give exactly one of inp / ids")
         if self.final_act != "softmax":
@@ -319,7 +321,29 @@ class MSAUWrapper(nn.Module):
             raise RuntimeError("MSAUWrapper runs on an MI355X through libmsau_hip.so; input must be a CUDA/HIP tensor "
                                "(there is no CPU fallback)")
         plan = self._plan_for(inp, False) if ids is None else self._plan_for_shape(B, H, W, ref.device, False)
-        return plan.predict(self._flat, x_nchw=inp, ids=ids)
+        if not graph:
+            return plan.predict(self._flat, x_nchw=inp, ids=ids)
+        kind = "ids" if ids is not None else "dense"
+        if getattr(self, "_pstream", None) is None:
+            self._pstream = torch.cuda.Stream(device=ref.device)      # never replay into the NULL stream (see TrainEngine)
+        cur, gs = torch.cuda.current_stream(), self._pstream
+        gs.wait_stream(cur)
+        with torch.cuda.stream(gs):
+            cache = plan.__dict__.setdefault("_pgraphs", {})
+            if kind not in cache:
+                static = ref.clone()
+                kw = dict(ids=static) if ids is not None else dict(x_nchw=static)
+                plan.predict(self._flat, **kw)                        # warm-up outside capture
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=gs):
+                    plan.predict(self._flat, **kw)
+                cache[kind] = (g, static)
+            g, static = cache[kind]
+            static.copy_(ref, non_blocking=True)
+            g.replay()
+        cur.wait_stream(gs)
+        return plan.head_probs, plan.head_argmax
 
     def save(self, path):
         torch.save(self.state_dict(), path)
@@ -371,7 +395,7 @@ class TrainEngine:
     def _fwd_bwd(self, plan: Plan, x, labels):
         plan.forward(self.model._flat, x, export=False)
         loss = plan.loss_grads(labels)
-        if self.world > 1 and not self.use_graph:
+        if self.sync.active and not self.use_graph:
             # bucket i of GradSync = [end convs, last stage, ..., stage 0]; a stage's bucket is reduced over RCCL as
             # soon as that stage's slab reduction is enqueued, while the earlier stages' backward still runs
             nb = self.model.num_blocks
@@ -390,7 +414,7 @@ class TrainEngine:
                self.adam_ws.data_ptr(), n, self.lr, b1, b2, self.eps, self.max_norm, 1.0 / self.world)
 
     def _allreduce(self):
-        if self.world > 1:
+        if self.sync.active:
             if getattr(self, "_ar_started", False):
                 self.sync.start(0)                       # the end-conv tail: final once every stage is done
             else:

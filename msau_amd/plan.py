@@ -901,7 +901,7 @@ class Plan:
                     on_stage_done(b, torch.cuda.current_stream())
             return
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = L.concurrent_stream(self.device)      # a stream that demonstrably overlaps with this one
         side = self._side.cuda_stream
         if on_stage_done is None:
             L.call("msau_run_ops_overlap", s, side, arr, n, 1)

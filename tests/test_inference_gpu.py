@@ -113,6 +113,15 @@ def test_predict_from_ids_equals_dense_input():
     pa, aa = pa.clone(), aa.clone()
     pb, ab = m.predict_nhwc(inp=dense.cuda())
     assert torch.equal(pa, pb) and torch.equal(aa, ab)
+    # HIP-graph replay of the same sweep: same bits, also after the input changes and after a host sync
+    pg, ag = m.predict_nhwc(ids=ids.cuda(), graph=True)
+    assert torch.equal(pg, pa) and torch.equal(ag, aa)
+    ids2 = torch.randint(0, cfg["channels"], (2, 64, 48), dtype=torch.int32).cuda()
+    want, _ = m.predict_nhwc(ids=ids2)
+    want = want.clone()
+    torch.cuda.synchronize()
+    got, _ = m.predict_nhwc(ids=ids2, graph=True)
+    assert torch.equal(got, want)
     with pytest.raises(ValueError):
         m.predict_nhwc()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
