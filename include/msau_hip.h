@@ -310,6 +310,15 @@ int msau_run_ops(void* stream, const msau_op* ops, int n);
  * reduction, so they run beside the data-gradient chain. */
 #define MSAU_OP_SIDE 0x100
 int msau_run_ops_overlap(void* stream, void* side_stream, const msau_op* ops, int n, int join);   /* join=0: leave the side stream running */
+/* Ops whose kind carries MSAU_OP_PROBE are bracketed by a pair of timing HIP events on the stream they are launched
+ * on, inside the normal sequence (concurrent side-stream work included): the in-situ duration bench.py's roofline
+ * object quotes.  msau_probe_read synchronises on the recorded events, writes up to `cap` durations in microseconds
+ * in launch order, stores the count in *n and clears the list. */
+#define MSAU_OP_PROBE 0x200
+int msau_probe_read(float* us, int cap, int* n);
+/* cost of an event pair with nothing between its two records, averaged over `reps` pairs on `stream` (microseconds):
+ * the part of a probed duration that is the probe itself */
+int msau_probe_overhead(void* stream, int reps, float* us);
 
 /* misc */
 /* occupy the stream for ~microseconds (<= 200000) with a single sleeping wave: measurement aid only */

@@ -82,6 +82,7 @@ class ReduceArgs(C.Structure):
 
 
 OP_SIDE = 0x100
+OP_PROBE = 0x200
 OP_WGRAD_REDUCE = 10
 OP_CONV2D, OP_WGRAD, OP_LRN_FWD, OP_LRN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_CHANNEL_SUM = range(1, 10)
 
@@ -119,6 +120,8 @@ _SIGNATURES = {
     "msau_spin": (C.c_int, [vp, C.c_int]),
     "msau_fill_zero": (C.c_int, [vp, vp, i64]),
     "msau_softmax_channels_nchw": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, i64]),
+    "msau_probe_read": (C.c_int, [vp, C.c_int, vp]),
+    "msau_probe_overhead": (C.c_int, [vp, C.c_int, vp]),
     "msau_softmax_argmax_nhwc": (C.c_int, [vp, C.c_int, vp, vp, vp, i64, C.c_int, C.c_int]),
     "msau_onehot_ids": (C.c_int, [vp, C.c_int, vp, vp, i64, C.c_int, C.c_int]),
 }

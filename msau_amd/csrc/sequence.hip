@@ -5,7 +5,67 @@
 
 #include <vector>
 
-static int run_one(void* stream, const msau_op& o, int i);
+static int run_one_raw(void* stream, const msau_op& o, int i);
+
+// ---- MSAU_OP_PROBE: event pairs around selected launches ------------------------------------------------------
+namespace {
+struct ProbePair { hipEvent_t a, b; };
+thread_local std::vector<ProbePair> g_probe_pool;        // timing-enabled events, reused
+thread_local size_t g_probe_used = 0;
+}  // namespace
+
+static int run_one(void* stream, const msau_op& o_in, int i) {
+    if (!(o_in.kind & MSAU_OP_PROBE)) return run_one_raw(stream, o_in, i);
+    msau_op o = o_in;
+    o.kind &= ~MSAU_OP_PROBE;
+    if (g_probe_used == g_probe_pool.size()) {
+        ProbePair p;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess)
+            return msau_set_error(MSAU_ERR_HIP, "run_ops: cannot create probe events");
+        g_probe_pool.push_back(p);
+    }
+    ProbePair& p = g_probe_pool[g_probe_used++];
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipEventRecord(p.a, s) != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "run_ops: probe record failed");
+    int rc = run_one_raw(stream, o, i);
+    if (rc) return rc;
+    if (hipEventRecord(p.b, s) != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "run_ops: probe record failed");
+    return 0;
+}
+
+extern "C" int msau_probe_overhead(void* stream, int reps, float* us) {
+    MSAU_CHECK_ARG(us && reps > 0 && reps <= 4096, "probe_overhead: bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<ProbePair> ev(reps);
+    bool ok = true;
+    for (auto& p : ev) ok = ok && hipEventCreate(&p.a) == hipSuccess && hipEventCreate(&p.b) == hipSuccess;
+    for (auto& p : ev) ok = ok && hipEventRecord(p.a, s) == hipSuccess && hipEventRecord(p.b, s) == hipSuccess;
+    double sum = 0.0;
+    for (auto& p : ev) {
+        float ms = 0.f;
+        ok = ok && hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess;
+        sum += ms;
+    }
+    for (auto& p : ev) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (!ok) return msau_set_error(MSAU_ERR_HIP, "probe_overhead: HIP event call failed");
+    *us = (float)(sum * 1000.0 / reps);
+    return 0;
+}
+
+extern "C" int msau_probe_read(float* us, int cap, int* n) {
+    MSAU_CHECK_ARG(n && (us || cap == 0), "probe_read: null pointer");
+    int k = 0;
+    for (size_t i = 0; i < g_probe_used; ++i) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(g_probe_pool[i].b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_probe_pool[i].a, g_probe_pool[i].b);
+        if (e != hipSuccess) { g_probe_used = 0; return msau_set_error(MSAU_ERR_HIP, "probe_read: %s", hipGetErrorString(e)); }
+        if (k < cap) us[k++] = ms * 1000.f;
+    }
+    *n = k;
+    g_probe_used = 0;
+    return 0;
+}
 
 extern "C" int msau_run_ops(void* stream, const msau_op* ops, int n) {
     MSAU_CHECK_ARG(ops || n == 0, "run_ops: null list");
@@ -62,7 +122,7 @@ extern "C" int msau_run_ops_overlap(void* stream, void* side_stream, const msau_
     return 0;
 }
 
-static int run_one(void* stream, const msau_op& o, int i) {
+static int run_one_raw(void* stream, const msau_op& o, int i) {
     {
         int rc;
         switch (o.kind) {

@@ -534,7 +534,8 @@ class Plan:
         # The weight gradients form no dependency chain (each reads a finished out.grad and writes its own slabs),
         # so they run on a side stream beside the data-gradient chain.  Measured 2026-10-03 with the lean kernels:
         # 5.76 -> 5.20 ms/step (with the first, generic kernels it was 4 % slower: both chains were issue-bound).
-        self.overlap_wgrad = bool(cfg.get("overlap_wgrad", True)) and str(device).startswith("cuda")
+        self.overlap_wgrad = bool(cfg.get("overlap_wgrad", os.environ.get("MSAU_OVERLAP_WGRAD", "1") != "0")) and \
+            str(device).startswith("cuda")
         self._side = None
         self.overlap_max_pix = int(cfg.get("overlap_max_pix", 1 << 62))     # only layers this small go to the side stream
         self.x_in = Act(self, "input", H, W, cfg["channels"], needs_grad=bool(cfg.get("input_grad", False)))
@@ -767,6 +768,40 @@ class Plan:
         for a in self.acts:                       # anything no op touches (custom builders)
             if a.data is None:
                 take(a)
+
+    def set_probe(self, key: Optional[str]) -> int:
+        """Mark (or with None: unmark) every conv launch whose kernel symbol is `key` with MSAU_OP_PROBE in the forward
+        and backward sequences; the next sweeps then time those launches in place (read with `read_probe`).
+        Returns the number of marked launches per step."""
+        want = set()
+        if key is not None:
+            for op in self.ops:
+                if isinstance(op, ConvOp):
+                    if op.fkey == key:
+                        want.add(C.addressof(op.fdesc))
+                    for si, dd in enumerate(op.ddesc):
+                        if dd is not None and op.dmeta[si][0] == key:
+                            want.add(C.addressof(dd))
+        n = 0
+        for seq in (self._fwd_seq, self._bwd_seq):
+            if seq is None:
+                continue
+            arr, cnt, _ = seq
+            for i in range(cnt):
+                if arr[i].args in want:
+                    arr[i].kind |= L.OP_PROBE
+                    n += 1
+                else:
+                    arr[i].kind &= ~L.OP_PROBE
+        return n
+
+    @staticmethod
+    def read_probe(cap: int = 1 << 16):
+        """durations (us) of the probed launches since the last read, in launch order"""
+        buf = (C.c_float * cap)()
+        n = C.c_int(0)
+        L.call("msau_probe_read", buf, cap, C.byref(n))
+        return list(buf[:n.value])
 
     def _make_seq(self, recs):
         """(kind, args struct) records -> (msau_op array, n); the structs are kept alive by the ops / this list"""
