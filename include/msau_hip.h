@@ -63,6 +63,11 @@ enum {
     MSAU_CONV_ACCUM    = 8,
     MSAU_CONV_MASK_A   = 16,
     MSAU_CONV_MASK_B   = 32,
+    MSAU_CONV_DOUT     = 128,   /* two output tensors (the data gradient of a conv over concat(x1, x2), one launch instead
+                                   of two): the Cout stored rows are the channels of y (first half) and y2 (second half),
+                                   each [B][Hout][Wout][Cout/2]; `flags` / add / mask_b apply to y, `flags2` (ACCUM and
+                                   MASK_B only) / mask_b2 to y2.  Single-source 1x1 / 3x3 convs with C1 == Cout/2 in
+                                   {8, 16, 32}; msau_conv2d_launch_info: info[7] & 2 when the launch can take it. */
     MSAU_CONV_HEAD     = 64     /* inference head (kv_model.py:305-313): besides y, write softmax over the Cout real
                                    channels of the (storage-rounded) result to head_probs (fp32 [B][Hout][Wout][Cout],
                                    dense) and the index of its first maximum to head_argmax (uint8 [B][Hout][Wout]).
@@ -91,7 +96,9 @@ typedef struct {
     float* head_probs;          /* MSAU_CONV_HEAD only: fp32 [B][Hout][Wout][head_classes]          */
     uint8_t* head_argmax;       /* MSAU_CONV_HEAD only: uint8 [B][Hout][Wout]                       */
     int32_t head_classes;       /* MSAU_CONV_HEAD only: real classes (<= Cout, <= 16)               */
-    int32_t reserved;
+    int32_t flags2;             /* MSAU_CONV_DOUT only: epilogue flags of y2                        */
+    void* y2;                   /* MSAU_CONV_DOUT only                                              */
+    const void* mask_b2;        /* MSAU_CONV_DOUT only                                              */
 } msau_conv_desc;
 
 /* Geometry of the packed weight image the conv kernel expects for a given layer.
@@ -112,7 +119,7 @@ int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d);
  * info[0] = CT (16-row output-channel tiles), info[1] = PT (pixel tiles per wave: tile = 4*PT x 16),
  * info[2] = dynamic LDS bytes, info[3] = workgroups, info[4] = channel chunk, info[5] = chunks,
  * info[6] = 1 if a compile-time-specialised "lean" instance (conv_lean.hip) takes the launch,
- * info[7] = 1 if that instance implements MSAU_CONV_HEAD for this descriptor */
+ * info[7] = bit 0: that instance implements MSAU_CONV_HEAD for this descriptor, bit 1: MSAU_CONV_DOUT */
 int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info8);
 
 /* ------------------------------------------------------------------------------------------

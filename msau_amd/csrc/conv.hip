@@ -283,6 +283,7 @@ static int conv_plan(int dtype, const msau_conv_desc* d, ConvGeom* gout, TileGeo
 int msau_conv_lean_applicable(int dtype, const msau_conv_desc* d, int nchunks, int CT);
 int msau_conv_lean_try(hipStream_t s, int dtype, const msau_conv_desc* d, int kchunk, int nchunks, int CT);
 int msau_conv_lean_head_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT);
+int msau_conv_lean_dout_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT);
 
 extern "C" int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info) {
     MSAU_CHECK_ARG(d && info, "conv2d_launch_info: null pointer");
@@ -291,7 +292,7 @@ extern "C" int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32
     if (rc) return rc;
     info[0] = g.CT; info[1] = PT; info[2] = t.total; info[3] = (int32_t)nb; info[4] = g.cch; info[5] = g.nchunks;
     info[6] = msau_conv_lean_applicable(dtype, d, g.nchunks, g.CT);
-    info[7] = msau_conv_lean_head_capable(dtype, d, g.nchunks, g.CT);
+    info[7] = msau_conv_lean_head_capable(dtype, d, g.nchunks, g.CT) | (msau_conv_lean_dout_capable(dtype, d, g.nchunks, g.CT) << 1);
     return 0;
 }
 
@@ -328,8 +329,17 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
             return msau_set_error(MSAU_ERR_ARG, "conv2d: MSAU_CONV_HEAD is not implemented for this launch (see "
                                   "msau_conv2d_launch_info info[7]); run msau_softmax_argmax_nhwc on y instead");
     }
+    if (d->flags & MSAU_CONV_DOUT) {
+        const int okf = MSAU_CONV_DOUT | MSAU_CONV_ADD | MSAU_CONV_ACCUM | MSAU_CONV_MASK_B;
+        MSAU_CHECK_ARG(d->y2 && !(d->flags & ~okf) && !(d->flags2 & ~(MSAU_CONV_ACCUM | MSAU_CONV_MASK_B)) &&
+                       (!(d->flags2 & MSAU_CONV_MASK_B) || d->mask_b2), "conv2d: bad DOUT arguments");
+        if (!msau_conv_lean_dout_capable(dtype, d, g.nchunks, g.CT))
+            return msau_set_error(MSAU_ERR_ARG, "conv2d: MSAU_CONV_DOUT is not implemented for this launch (see "
+                                  "msau_conv2d_launch_info info[7]); issue one launch per output instead");
+    }
     rc = msau_conv_lean_try(static_cast<hipStream_t>(stream), dtype, d, g.kchunk, g.nchunks, g.CT);
     if (rc != 0) return rc < 0 ? rc : 0;
+    if (d->flags & MSAU_CONV_DOUT) return msau_set_error(MSAU_ERR_ARG, "conv2d: DOUT launch was not taken by a lean instance");
     ConvArgs a;
     a.d = *d;
     a.cch = g.cch; a.nchunks = g.nchunks; a.kchunk = g.kchunk; a.ngroups = g.ngroups;

@@ -43,7 +43,7 @@ struct LeanCfg {
     static constexpr int LDS = IN_BYTES + (WREG ? 0 : NCH * CT * 16 * WS);
 };
 
-template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1>
+template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false>
 __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) {
     using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL, WGW>;
     constexpr int NT = Cfg::NT;
@@ -194,6 +194,48 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
 
         // ---- epilogue: lane (pixel lr of row ty, q = lg) owns channels q*CT*4 + ct*4 + {0..3}
         const int oyw = oy0 + wave * 4;
+        if constexpr (DOUT) {
+            // two output tensors (MSAU_CONV_DOUT): Cout = 2 * CT*8, so lane groups q = 0,1 hold the channels of y and
+            // q = 2,3 those of y2; flags, base and mask pointers are picked per lane
+            const bool t2 = lg >= 2;
+            const int lfl = t2 ? d.flags2 : flags;
+            char* yb = static_cast<char*>(t2 ? d.y2 : d.y);
+            const char* mb = static_cast<const char*>(t2 ? d.mask_b2 : d.mask_b);
+            const char* ad = static_cast<const char*>(d.add);
+            if (ox0 + lr < d.Wout) {
+                const long long off0 = ((long long)(b * d.Hout + oyw)) * a.out_row + (long long)ox0 * a.out_px +
+                                       lr * a.out_px + (lg & 1) * (CT * 4) * ESZ;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                    for (int pt = 0; pt < 4; ++pt) {
+                        if (oyw + pt < d.Hout) {                   // scalar
+                            const long long o = off0 + ct * 4 * ESZ + (long long)pt * a.out_row;
+                            f32x4 v = acc[ct][pt] + bv[ct];
+                            if (lfl & MSAU_CONV_ADD) {
+                                V4 r = *reinterpret_cast<const V4*>(ad + o);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                            }
+                            if (lfl & MSAU_CONV_ACCUM) {
+                                V4 r = *reinterpret_cast<const V4*>(yb + o);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                            }
+                            if (lfl & MSAU_CONV_MASK_B) {
+                                V4 m = *reinterpret_cast<const V4*>(mb + o);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : 0.f;
+                            }
+                            V4 ov;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) ov[j] = (T)v[j];
+                            *reinterpret_cast<V4*>(yb + o) = ov;
+                        }
+                    }
+                }
+            }
+        } else
         if (ox0 + cwt * 16 + lr < d.Wout) {
             char* y = static_cast<char*>(d.y) + ((long long)(b * d.Hout + oyw)) * a.out_row + (long long)ox0 * a.out_px;
 #pragma unroll
@@ -272,7 +314,7 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
     }
 }
 
-template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1>
+template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false>
 int launch_lean(hipStream_t s, const LeanArgs& a0) {
     using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL, WGW>;
     LeanArgs a = a0;
@@ -281,7 +323,7 @@ int launch_lean(hipStream_t s, const LeanArgs& a0) {
     a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS > 60 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_lean: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -296,7 +338,7 @@ int launch_lean(hipStream_t s, const LeanArgs& a0) {
         grid &= ~7;
         a.per_xcd = cdiv(a.ntiles, 8);
     }
-    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW>), dim3(grid), dim3(256 * WGW), Cfg::LDS, s, a);
+    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT>), dim3(grid), dim3(256 * WGW), Cfg::LDS, s, a);
     MSAU_CHECK_LAUNCH("conv_lean_kernel");
     return 1;
 }
@@ -375,6 +417,21 @@ int msau_conv_lean_applicable(int dtype, const msau_conv_desc* d, int nchunks, i
     return 1;
 }
 
+// two-output data gradient (MSAU_CONV_DOUT): g [C] -> (dx1 [C], dx2 [C]) with C = CT*8 in {8, 16, 32}
+int msau_conv_lean_dout_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
+    if (!msau_conv_lean_applicable(dtype, d, nchunks, CT)) return 0;
+    return d->C2 == 0 && d->dil == 1 && (d->KH == 1 || d->KH == 3) && (CT == 1 || CT == 2 || CT == 4) &&
+           d->Cout == CT * 16 && d->C1 == CT * 8;
+}
+
+template <typename T>
+int lean_dout(hipStream_t s, const LeanArgs& a, int KS, int CT) {
+#define DO_CASE(K, C) if (KS == K && CT == C) return launch_lean<T, C, C, K, false, 1, 1, true>(s, a);
+    DO_CASE(1, 1) DO_CASE(1, 2) DO_CASE(1, 4) DO_CASE(3, 1) DO_CASE(3, 2) DO_CASE(3, 4)
+#undef DO_CASE
+    return 0;
+}
+
 // 1 if the lean instance that takes this launch implements MSAU_CONV_HEAD (the 4x4 end conv, one 16-row tile)
 int msau_conv_lean_head_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
     return msau_conv_lean_applicable(dtype, d, nchunks, CT) && d->KH == 4 && CT == 1 && d->dil == 1;
@@ -390,12 +447,17 @@ int msau_conv_lean_try(hipStream_t s, int dtype, const msau_conv_desc* d, int kc
     a.kchunk = kchunk;
     a.in_px1 = d->C1 * esz; a.in_px2 = d->C2 * esz;
     a.in_row1 = d->Win * a.in_px1; a.in_row2 = d->Win * a.in_px2;
-    a.out_px = d->Cout * esz; a.out_row = d->Wout * a.out_px;
+    const bool dout = d->flags & MSAU_CONV_DOUT;
+    a.out_px = (dout ? d->Cout / 2 : d->Cout) * esz; a.out_row = d->Wout * a.out_px;
     a.tiles_x = cdiv(d->Wout, 16); a.tiles_y = cdiv(d->Hout, 16);
     a.ntiles = d->B * a.tiles_x * a.tiles_y;
     if (a.ntiles >= (1 << 20) || a.tiles_x >= 4096 || a.tiles_y >= 4096) return 0;
     a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
     a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
+    if (dout) {
+        if (!msau_conv_lean_dout_capable(dtype, d, nchunks, CT)) return 0;
+        return dtype == MSAU_F32 ? lean_dout<float>(s, a, d->KH, CT) : lean_dout<bf16_t>(s, a, d->KH, CT);
+    }
     if (d->dil == 2) return dtype == MSAU_F32 ? lean_dil<float, 2>(s, a, cin8, CT) : lean_dil<bf16_t, 2>(s, a, cin8, CT);
     if (d->dil == 4) return dtype == MSAU_F32 ? lean_dil<float, 4>(s, a, cin8, CT) : lean_dil<bf16_t, 4>(s, a, cin8, CT);
     if (d->dil == 8) return dtype == MSAU_F32 ? lean_dil<float, 8>(s, a, cin8, CT) : lean_dil<bf16_t, 8>(s, a, cin8, CT);

@@ -165,7 +165,25 @@ class ConvOp(Op):
         P.add_pack_entry(be, out.Cs)
         # ---- data-gradient images
         self.d_off = [None, None]
-        if P.training:
+        self.dd_off = None           # one launch for both sources of a concat conv (MSAU_CONV_DOUT) when an instance has it
+        if P.training and conv and x2 is not None and None not in self.slots and x1.C == x1.Cs == x2.C == x2.Cs \
+                and os.environ.get("MSAU_FUSE_DGRAD", "1") != "0":
+            proto = L.ConvDesc()
+            proto.B, proto.Hin, proto.Win, proto.Hout, proto.Wout = P.B, out.H, out.W, x1.H, x1.W
+            proto.C1, proto.C2, proto.Cout = out.Cs, 0, x1.Cs + x2.Cs
+            proto.KH = proto.KW = self.k
+            proto.dil, proto.stride, proto.ups = self.dil, 1, 1
+            proto.pad_t = (self.k - 1) * self.dil - self.pad_t
+            proto.pad_l = (self.k - 1) * self.dil - self.pad_l
+            info = (L.i32 * 8)()
+            L.call("msau_conv2d_launch_info", P.dtype, C.byref(proto), info)
+            if info[7] & 2:
+                gd = self._geom(out.Cs, 0, x1.Cs + x2.Cs, self.dil, 1, 1)
+                self.dd_off = P.alloc_pack(gd.bytes)
+                e, n = self._pack_entry(gd, self.dd_off, row_is_dim0=False, flip=True, row_off=0,
+                                        rows_real=x1.C + x2.C, k1=(out.C, out.Cs), k2=(0, 0))
+                P.add_pack_entry(e, n)
+        if P.training and self.dd_off is None:
             for si, x in enumerate((x1, x2)):
                 if x is None or self.slots[si] is None:
                     continue
@@ -204,7 +222,7 @@ class ConvOp(Op):
             d.head_probs, d.head_argmax, d.head_classes = _ptr(P.head_probs), _ptr(P.head_argmax), out.C
             info = (L.i32 * 8)()
             L.call("msau_conv2d_launch_info", P.dtype, C.byref(d), info)
-            P.head_fused = bool(info[7]) and d.flags == 0 and out.C <= 16
+            P.head_fused = bool(info[7] & 1) and d.flags == 0 and out.C <= 16
             if P.head_fused:
                 d.flags = L.CONV_HEAD
         self.fdesc = d
@@ -212,8 +230,31 @@ class ConvOp(Op):
         self.wdesc = None
         if not P.training or out.grad is None:
             return
+        if self.dd_off is not None:
+            dd = L.ConvDesc()
+            dd.B = P.B
+            dd.Hin, dd.Win, dd.Hout, dd.Wout = out.H, out.W, x1.H, x1.W
+            dd.C1, dd.C2, dd.Cout = out.Cs, 0, x1.Cs + x2.Cs
+            dd.KH = dd.KW = self.k
+            dd.dil, dd.stride, dd.ups = self.dil, 1, 1
+            dd.pad_t = (self.k - 1) * self.dil - self.pad_t
+            dd.pad_l = (self.k - 1) * self.dil - self.pad_l
+            assert not self.relu_in
+            fl = [0, 0]
+            for si, x in enumerate((x1, x2)):
+                accum, maskb = x.slot_flags(self.slots[si])
+                fl[si] = (L.CONV_ACCUM if accum else 0) | (L.CONV_MASK_B if maskb else 0)
+                if maskb:
+                    setattr(dd, "mask_b" if si == 0 else "mask_b2", _ptr(x.data))
+            if self.bwd_add is not None:
+                fl[0] |= L.CONV_ADD
+                dd.add = _ptr(self.bwd_add.grad)
+            dd.flags, dd.flags2 = fl[0] | L.CONV_DOUT, fl[1]
+            dd.x1, dd.wpack, dd.bias = _ptr(out.grad), P.pack_ptr(self.dd_off), None
+            dd.y, dd.y2 = _ptr(x1.grad), _ptr(x2.grad)
+            self.ddesc[0] = dd
         for si, x in enumerate((x1, x2)):
-            if x is None or self.slots[si] is None:
+            if x is None or self.slots[si] is None or self.dd_off is not None:
                 continue
             accum, maskb = x.slot_flags(self.slots[si])
             dd = L.ConvDesc()
@@ -308,6 +349,12 @@ class ConvOp(Op):
             nin = d.B * d.Hin * d.Win * (d.C1 + d.C2)
             nout = d.B * d.Hout * d.Wout * d.Cout
             extra = sum(1 for f in (L.CONV_ADD, L.CONV_ACCUM, L.CONV_MASK_A, L.CONV_MASK_B) if d.flags & f)
+            if d.flags & L.CONV_DOUT:
+                # both halves are written once; the epilogue operands are per half
+                half = nout // 2
+                ex1 = sum(1 for f in (L.CONV_ADD, L.CONV_ACCUM, L.CONV_MASK_B) if d.flags & f)
+                ex2 = sum(1 for f in (L.CONV_ACCUM, L.CONV_MASK_B) if d.flags2 & f)
+                return f"conv_lean_kernel<{T},CIN{d.C1},CT{info[0]},K{d.KH},dout>", (nin + half * (2 + ex1 + ex2)) * esz
             if info[6]:
                 name = f"conv_lean_kernel<{T},CIN{d.C1 + d.C2},CT{info[0]},K{d.KH}{',dual' if d.C2 else ''}>"
             else:
@@ -319,8 +366,8 @@ class ConvOp(Op):
         self.dmeta = [None, None]
         for si, dd in enumerate(self.ddesc):
             if dd is not None:
-                src = (self.x1, self.x2)[si]
-                fl = 2.0 * P.B * (self.out.H * self.out.W if self.kind == "conv" else self.x1.H * self.x1.W) * taps * src.C * self.out.C
+                src_c = (self.x1.C + self.x2.C) if self.dd_off is not None else (self.x1, self.x2)[si].C
+                fl = 2.0 * P.B * (self.out.H * self.out.W if self.kind == "conv" else self.x1.H * self.x1.W) * taps * src_c * self.out.C
                 self.dmeta[si] = conv_meta(dd)
                 P.note_launch(self.dmeta[si][0], self.dmeta[si][1], fl)
         if self.wdesc is not None:

@@ -307,3 +307,21 @@ def test_unet_loss_and_trainer_api(tmp_path):
     assert l1 < l0 and prov.stopped == 1 and prov.restarts == 2
     assert abs(tr.adjust_lr(25) - 1e-3 * 0.95 ** 2) < 1e-12
     assert out == str(tmp_path / "model") and (tmp_path / "model1").exists()
+
+
+def test_two_output_data_gradient_is_bit_identical_to_two_launches(monkeypatch):
+    """concat convs (decoder merge, stage coupling): one MSAU_CONV_DOUT launch for both sources == one launch each"""
+    from msau_amd.plan import ConvOp
+    g, cfg, sd, x, label = load_net_case("net_cfg2_336x256x64")
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("MSAU_FUSE_DGRAD", fuse)
+        m = _model(cfg, sd, "bf16")
+        eng = TrainEngine(m)
+        eng.step(x.cuda(), label.cuda())
+        torch.cuda.synchronize()
+        plan = m._plan_for(x.cuda(), True)
+        nf = sum(1 for op in plan.ops if isinstance(op, ConvOp) and op.dd_off is not None)
+        assert (nf > 10) if fuse == "1" else (nf == 0)
+        outs.append((eng.flat_grad.clone(), m.flat_parameters.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
