@@ -256,6 +256,13 @@ int msau_label_counts(void* stream, const int64_t* labels, int32_t* counts, int 
 int64_t msau_ce_ws_floats(int64_t npix_total);
 int msau_masked_ce(void* stream, int dtype, const void* logits, const int64_t* labels, const int32_t* counts,
                    void* dlogits, float* loss_accum, float* ws, int B, int64_t hw, int C, int Cs, float scale);
+/* final + auxiliary logits in one launch (model/model.py:455-458): loss[0] = CE(logits) + CE(aux) (aux may be NULL),
+ * written, not accumulated; ws: msau_ce_multi_ws_floats(B*hw) floats of scratch.  Same arithmetic per pixel as
+ * msau_masked_ce; the block sums are added in index order by a one-wave follow-up kernel. */
+int64_t msau_ce_multi_ws_floats(int64_t npix_total);
+int msau_masked_ce_multi(void* stream, int dtype, const void* logits, const void* aux, const int64_t* labels,
+                         const int32_t* counts, void* dlogits, void* daux, float* loss, float* ws,
+                         int B, int64_t hw, int C, int Cs, float scale);
 
 /* plain cross entropy over EVERY pixel (label 0 is a class), as model/training/cost.py:35-65 `UNetLoss`:
  *   loss += scale * sum_p -log softmax(logits_p)[label_p] ; dlogits = scale * (softmax - onehot)           */

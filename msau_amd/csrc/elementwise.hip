@@ -364,6 +364,76 @@ __global__ void masked_ce_kernel(const T* __restrict__ logits, const int64_t* __
     }
 }
 
+// Final + auxiliary masked CE in ONE launch (model/model.py:455-458: CE(out) + CE(aux) over the same labelled pixels):
+// the label and the per-sample weight are read once, both gradients are written, block partial sums go to ws and the
+// one-wave follow-up kernel adds them up in index order -> loss[0], reproducibly.  (A "last block sums" ticket
+// instead of the second launch was tried: thousands of same-address atomics cost 200 us.)
+template <typename T, int NL, int CS8>
+__global__ void masked_ce_multi_kernel(const T* __restrict__ l0, const T* __restrict__ l1, const int64_t* __restrict__ labels,
+                                       const int32_t* __restrict__ counts, T* __restrict__ d0, T* __restrict__ d1,
+                                       float* __restrict__ ws, float* __restrict__ loss, int B, int hw, int C, float scale) {
+    constexpr int Cs = CS8 * 8;
+    __shared__ float red[kThreads / 64];
+    float local = 0.f;
+    const int64_t total = (int64_t)B * hw;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)((unsigned)p / (unsigned)hw);               // total < 2^31 (checked by the host)
+        const int lab = (int)labels[p];
+        const bool on = lab != 0 && lab < C && lab > 0;
+        const float w = on ? scale / (float)max(counts[b], 1) : 0.f;
+#pragma unroll
+        for (int t = 0; t < NL; ++t) {
+            const T* lg = t ? l1 : l0;
+            T* dg = t ? d1 : d0;
+            float x[Cs];                                               // every index below is a compile-time constant:
+            float mx = -INFINITY, xl = 0.f;                            // the array stays in registers
+#pragma unroll
+            for (int c0 = 0; c0 < Cs; c0 += 8) {
+                typename Vec8<T>::type v = load8<T>(lg + p * Cs + c0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    x[c0 + j] = (float)v[j];
+                    if (c0 + j < C) mx = fmaxf(mx, x[c0 + j]);
+                    xl = (c0 + j == lab) ? x[c0 + j] : xl;
+                }
+            }
+            float se = 0.f;
+#pragma unroll
+            for (int c = 0; c < Cs; ++c) se += c < C ? __expf(x[c] - mx) : 0.f;
+            const float lse = mx + __logf(se);
+            if (on) local += w * (lse - xl);
+#pragma unroll
+            for (int c0 = 0; c0 < Cs; c0 += 8) {
+                typename Vec8<T>::type o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = c0 + j;
+                    float g = 0.f;
+                    if (on && c < C) g = w * (__expf(x[c] - lse) - (c == lab ? 1.f : 0.f));
+                    o[j] = (T)g;
+                }
+                store8<T>(dg + p * Cs + c0, o);
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < kThreads / 64; ++i) s += red[i];
+        ws[blockIdx.x] = s;
+    }
+}
+
+// one wave, fixed association order -> reproducible; overwrites out[0]
+__global__ void ordered_sum_set_kernel(const float* __restrict__ partials, int n, float* __restrict__ out) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) s += partials[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
 __global__ void ordered_sum_kernel(const float* __restrict__ partials, int n, float* __restrict__ accum) {
     // one wave, fixed association order -> reproducible
     float s = 0.f;
@@ -618,6 +688,29 @@ extern "C" int msau_masked_ce(void* stream, int dtype, const void* logits, const
     MSAU_CHECK_LAUNCH("masked_ce");
     hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(64), 0, s, ws, nb, loss_accum);
     MSAU_CHECK_LAUNCH("ordered_sum");
+    return 0;
+}
+
+extern "C" int64_t msau_ce_multi_ws_floats(int64_t npix_total) { return grid_for(npix_total, 8192) + 1; }
+
+extern "C" int msau_masked_ce_multi(void* stream, int dtype, const void* logits, const void* aux, const int64_t* labels,
+                                    const int32_t* counts, void* dlogits, void* daux, float* loss, float* ws,
+                                    int B, int64_t hw, int C, int Cs, float scale) {
+    MSAU_CHECK_ARG(logits && labels && counts && dlogits && loss && ws && (!aux || daux), "masked_ce_multi: null pointer");
+    MSAU_CHECK_ARG(B > 0 && hw > 0 && C > 0 && C <= Cs && Cs % 8 == 0 && Cs <= 16 && (int64_t)B * hw < (1ll << 31),
+                   "masked_ce_multi: bad dims (n_class <= 16, B*H*W < 2^31)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nb = grid_for((int64_t)B * hw, 8192);
+#define CE_MULTI(T, NL, C8) hipLaunchKernelGGL((masked_ce_multi_kernel<T, NL, C8>), dim3(nb), dim3(kThreads), 0, s, static_cast<const T*>(logits), \
+        static_cast<const T*>(aux), labels, counts, static_cast<T*>(dlogits), static_cast<T*>(daux), ws, loss, B, (int)hw, C, scale)
+    if (aux && Cs == 8) { DISPATCH_T(dtype, CE_MULTI(float, 2, 1), CE_MULTI(bf16_t, 2, 1)); }
+    else if (aux) { DISPATCH_T(dtype, CE_MULTI(float, 2, 2), CE_MULTI(bf16_t, 2, 2)); }
+    else if (Cs == 8) { DISPATCH_T(dtype, CE_MULTI(float, 1, 1), CE_MULTI(bf16_t, 1, 1)); }
+    else { DISPATCH_T(dtype, CE_MULTI(float, 1, 2), CE_MULTI(bf16_t, 1, 2)); }
+#undef CE_MULTI
+    MSAU_CHECK_LAUNCH("masked_ce_multi");
+    hipLaunchKernelGGL(ordered_sum_set_kernel, dim3(1), dim3(64), 0, s, ws, nb, loss);
+    MSAU_CHECK_LAUNCH("ordered_sum_set");
     return 0;
 }
 

@@ -775,6 +775,7 @@ class Plan:
         if self.training:
             self.counts = torch.zeros((self.B,), dtype=torch.int32, device=self.device)
             self.ce_ws = torch.zeros((int(L.load().msau_ce_ws_floats(self.B * HW)),), dtype=torch.float32, device=self.device)
+            self.ce_multi_ws = torch.zeros((int(L.load().msau_ce_multi_ws_floats(self.B * HW)),), dtype=torch.float32, device=self.device)
             self.loss_buf = torch.zeros((1,), dtype=torch.float32, device=self.device)
 
     def _assign_buffers(self):
@@ -945,12 +946,19 @@ class Plan:
                     act.grad.mul_(act.data > 0)
 
     def loss_grads(self, labels: torch.Tensor) -> torch.Tensor:
-        """Masked CE (model/model.py:446-459, batch rule SURVEY 8e) fused with its gradient:
-        writes d(logits), d(aux) in place and returns the loss as a 1-element device tensor."""
+        """Masked CE (model/model.py:446-459, batch rule SURVEY 8e) fused with its gradient: writes d(logits), d(aux)
+        in place and returns the loss as a 1-element device tensor.  One launch for final + aux."""
         assert labels.dtype == torch.int64 and labels.is_contiguous() and tuple(labels.shape) == (self.B, self.H, self.W)
         s = self._stream()
         HW = self.H * self.W
         L.call("msau_label_counts", s, labels.data_ptr(), self.counts.data_ptr(), self.B, HW)
+        lg, ax = self.logits, self.aux
+        if lg.Cs <= 16 and self.B * HW < (1 << 31) and (ax is None or (ax.C, ax.Cs) == (lg.C, lg.Cs)) \
+                and os.environ.get("MSAU_CE_MULTI", "1") != "0":
+            L.call("msau_masked_ce_multi", s, self.dtype, lg.data.data_ptr(), _ptr(ax.data) if ax is not None else None,
+                   labels.data_ptr(), self.counts.data_ptr(), lg.grad.data_ptr(), _ptr(ax.grad) if ax is not None else None,
+                   self.loss_buf.data_ptr(), self.ce_multi_ws.data_ptr(), self.B, HW, lg.C, lg.Cs, 1.0 / self.B)
+            return self.loss_buf
         self.loss_buf.zero_()
         for act in (self.logits, self.aux):
             if act is None:
