@@ -312,3 +312,42 @@ def test_device_chargrid_rasteriser_matches_cpu_painter(tmp_path):
             assert torch.equal(got, ref["mask"]), (i, dtype)
             assert float(grid[..., C:].abs().sum()) == 0.0
             assert torch.equal(labels.cpu(), ref["label"].long())
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("C,with_aux", [(5, True), (5, False), (12, True)])
+def test_masked_ce_multi_equals_two_single_launches(dtype, C, with_aux):
+    """final + aux CE in one launch: gradients bit-identical to msau_masked_ce per tensor, loss equal to their sum"""
+    torch.manual_seed(3)
+    B, H, W = 3, 37, 29
+    Cs = -(-C // 8) * 8
+    td = torch.float32 if dtype == "fp32" else torch.bfloat16
+    dt = L.F32 if dtype == "fp32" else L.BF16
+    lg = (torch.randn(B, H, W, Cs) * 2).to(td).cuda()
+    ax = (torch.randn(B, H, W, Cs) * 2).to(td).cuda()
+    labels = torch.randint(0, C, (B, H, W), dtype=torch.int64)
+    labels[1] = 0                                              # a sample without labelled pixels contributes 0
+    labels = labels.cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    counts = torch.zeros(B, dtype=torch.int32, device="cuda")
+    L.call("msau_label_counts", s, labels.data_ptr(), counts.data_ptr(), B, H * W)
+    ws1 = torch.zeros(int(L.load().msau_ce_ws_floats(B * H * W)), device="cuda")
+    ws2 = torch.zeros(int(L.load().msau_ce_multi_ws_floats(B * H * W)), device="cuda")
+    ref_loss = torch.zeros(1, device="cuda")
+    d_ref = []
+    for t in ([lg, ax] if with_aux else [lg]):
+        d = torch.empty_like(t)
+        L.call("msau_masked_ce", s, dt, t.data_ptr(), labels.data_ptr(), counts.data_ptr(), d.data_ptr(), ref_loss.data_ptr(),
+               ws1.data_ptr(), B, H * W, C, Cs, 1.0 / B)
+        d_ref.append(d)
+    loss = torch.full((1,), 123.0, device="cuda")                # overwritten, not accumulated
+    d0, d1 = torch.empty_like(lg), torch.empty_like(ax)
+    for _ in range(2):                                           # the scratch needs no re-initialisation between calls
+        L.call("msau_masked_ce_multi", s, dt, lg.data_ptr(), ax.data_ptr() if with_aux else None, labels.data_ptr(),
+               counts.data_ptr(), d0.data_ptr(), d1.data_ptr() if with_aux else None, loss.data_ptr(), ws2.data_ptr(),
+               B, H * W, C, Cs, 1.0 / B)
+    assert torch.equal(d0, d_ref[0])
+    if with_aux:
+        assert torch.equal(d1, d_ref[1])
+    assert abs(float(loss) - float(ref_loss)) <= 2e-6 * abs(float(ref_loss))
+    assert float(d0[1].float().abs().max()) == 0.0
