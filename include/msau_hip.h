@@ -328,6 +328,9 @@ int msau_run_ops_overlap(void* stream, void* side_stream, const msau_op* ops, in
  * on, inside the normal sequence (concurrent side-stream work included): the in-situ duration bench.py's roofline
  * object quotes.  msau_probe_read synchronises on the recorded events, writes up to `cap` durations in microseconds
  * in launch order, stores the count in *n and clears the list. */
+/* An op carrying MSAU_OP_JOIN first makes `stream` wait for everything enqueued so far on `side_stream` (used by the
+ * plan's deterministic mode: the level-0 LRN backward then never shares the device with a weight-gradient kernel). */
+#define MSAU_OP_JOIN 0x800
 #define MSAU_OP_PROBE 0x200
 int msau_probe_read(float* us, int cap, int* n);
 /* cost of an event pair with nothing between its two records, averaged over `reps` pairs on `stream` (microseconds):

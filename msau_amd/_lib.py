@@ -83,6 +83,7 @@ class ReduceArgs(C.Structure):
 
 OP_SIDE = 0x100
 OP_PROBE = 0x200
+OP_JOIN = 0x800
 OP_WGRAD_REDUCE = 10
 OP_CONV2D, OP_WGRAD, OP_LRN_FWD, OP_LRN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_CHANNEL_SUM = range(1, 10)
 

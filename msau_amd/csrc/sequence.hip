@@ -70,7 +70,9 @@ extern "C" int msau_probe_read(float* us, int cap, int* n) {
 extern "C" int msau_run_ops(void* stream, const msau_op* ops, int n) {
     MSAU_CHECK_ARG(ops || n == 0, "run_ops: null list");
     for (int i = 0; i < n; ++i) {
-        int rc = run_one(stream, ops[i], i);
+        msau_op o = ops[i];
+        o.kind &= ~(MSAU_OP_SIDE | MSAU_OP_JOIN);       // one stream: nothing to fork or join
+        int rc = run_one(stream, o, i);
         if (rc) return rc;              // msau_last_error() holds the failing launch's message
     }
     return 0;
@@ -95,7 +97,15 @@ extern "C" int msau_run_ops_overlap(void* stream, void* side_stream, const msau_
     for (int i = 0; i < n; ++i) {
         msau_op o = ops[i];
         const bool side = o.kind & MSAU_OP_SIDE;
-        o.kind &= ~MSAU_OP_SIDE;
+        const bool join_first = o.kind & MSAU_OP_JOIN;
+        o.kind &= ~(MSAU_OP_SIDE | MSAU_OP_JOIN);
+        if (join_first && !side && any_side) {
+            hipEvent_t ev;
+            int rc = next_event(&ev);
+            if (rc) return rc;
+            if (hipEventRecord(ev, ss) != hipSuccess || hipStreamWaitEvent(ms, ev, 0) != hipSuccess)
+                return msau_set_error(MSAU_ERR_HIP, "run_ops_overlap: join failed");
+        }
         if (side) {
             if (main_dirty) {
                 hipEvent_t ev;

@@ -187,7 +187,7 @@ class MSAUWrapper(nn.Module):
         self.cfg = dict(channels=channels, n_class=n_class, scale_space_num=self.scale_space_num,
                         res_depth=self.res_depth, featRoot=self.featRoot, filter_size=self.filter_size,
                         pool_size=self.pool_size, num_blocks=self.num_blocks)
-        for opt in ("reuse_activations", "overlap_wgrad", "overlap_max_pix"):      # execution options of the plan
+        for opt in ("reuse_activations", "overlap_wgrad", "overlap_max_pix", "deterministic"):      # execution options of the plan
             if opt in kw:
                 self.cfg[opt] = kw[opt]
 

@@ -450,7 +450,8 @@ class LrnOp(Op):
         if y.grad is None or a.grad is None:
             return []
         self._ba = L.LrnArgs(_ptr(a.data), _ptr(y.grad), _ptr(a.grad), a.npix, a.C, a.Cs, a.C, 1e-4, 0.75, 1.0)
-        return [(L.OP_LRN_BWD, self._ba)]
+        # deterministic mode: never beside a side-stream kernel ("one-ulp finding")
+        return [(L.OP_LRN_BWD | (L.OP_JOIN if self.plan.deterministic and self.plan.overlap_wgrad else 0), self._ba)]
 
     def fwd(self, s):
         a, y = self.a, self.y
@@ -584,6 +585,8 @@ class Plan:
         self.overlap_wgrad = bool(cfg.get("overlap_wgrad", os.environ.get("MSAU_OVERLAP_WGRAD", "1") != "0")) and \
             str(device).startswith("cuda")
         self._side = None
+        # bit-reproducible training steps: costs 4 % (the LRN backward launches wait for the weight-gradient stream)
+        self.deterministic = bool(cfg.get("deterministic", os.environ.get("MSAU_DETERMINISTIC", "0") == "1"))
         self.overlap_max_pix = int(cfg.get("overlap_max_pix", 1 << 62))     # only layers this small go to the side stream
         self.x_in = Act(self, "input", H, W, cfg["channels"], needs_grad=bool(cfg.get("input_grad", False)))
         self.logits: Optional[Act] = None

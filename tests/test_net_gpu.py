@@ -16,10 +16,10 @@ pytestmark = pytest.mark.gpu
 LOGIT_TOL = {"fp32": 2e-4, "bf16": 6e-2}
 
 
-def _model(cfg, sd, dtype):
+def _model(cfg, sd, dtype, **extra):
     kw = dict(scale_space_num=cfg["scale_space_num"], res_depth=cfg["res_depth"], featRoot=cfg["featRoot"],
               filter_size=cfg["filter_size"], pool_size=cfg["pool_size"], final_act="softmax",
-              num_blocks=cfg["num_blocks"], dtype=dtype)
+              num_blocks=cfg["num_blocks"], dtype=dtype, **extra)
     m = MSAUWrapper(cfg["channels"], cfg["n_class"], kw)
     missing = m.load_state_dict(sd, strict=True)
     return m.cuda()
@@ -125,10 +125,12 @@ def test_bf16_training_step_close_to_reference():
 
 
 def test_engine_is_deterministic_and_graph_equals_eager():
+    """`deterministic=True`: bit-reproducible steps (the LRN backward never runs beside a weight-gradient kernel; in
+    the default mode ~100 of its 5.5 M outputs at level 0 can differ by one bf16 ulp between runs)."""
     g, cfg, sd, x, label = load_net_case("net_f4_c13_b2_64x48")
     outs = []
     for use_graph in (False, True, False):
-        m = _model(cfg, sd, "fp32")
+        m = _model(cfg, sd, "fp32", deterministic=True)
         eng = TrainEngine(m, use_graph=use_graph)
         for _ in range(3):
             loss = eng.step(x.cuda(), label.cuda())
@@ -208,7 +210,8 @@ def test_graph_replay_after_host_sync_matches_eager_at_bench_size():
     synchronisation corrupted the step at the bench configuration (B=16, 336x256x64, bf16) on ROCm 7.2;
     TrainEngine now replays on its own stream.  Graph and eager must agree bit for bit."""
     from oracle import msau_oracle as O
-    kw = dict(scale_space_num=4, res_depth=2, featRoot=8, final_act="softmax", num_blocks=3, dtype="bf16", seed=0)
+    kw = dict(scale_space_num=4, res_depth=2, featRoot=8, final_act="softmax", num_blocks=3, dtype="bf16", seed=0,
+              deterministic=True)
     x, label = O.synthetic_batch(16, 64, 336, 256, 5, seed=3)
     x, label = x.cuda(), label.cuda()
     res = []
@@ -316,7 +319,7 @@ def test_two_output_data_gradient_is_bit_identical_to_two_launches(monkeypatch):
     outs = []
     for fuse in ("1", "0"):
         monkeypatch.setenv("MSAU_FUSE_DGRAD", fuse)
-        m = _model(cfg, sd, "bf16")
+        m = _model(cfg, sd, "bf16", deterministic=True)
         eng = TrainEngine(m)
         eng.step(x.cuda(), label.cuda())
         torch.cuda.synchronize()
