@@ -52,6 +52,15 @@ int conv_geom(int dtype, int C1, int C2, int Cout, int KH, int KW, int dil, int 
     g.CT = ct <= 1 ? 1 : ct <= 2 ? 2 : ct <= 4 ? 4 : 8;
     g.rows = g.CT * 16;
     int best = 0;
+    // 64 -> 64 3x3 (level 3) in bf16: one K chunk, so that the compile-time-specialised instances (conv_lean.hip: one
+    // chunk per source; channel-split over blockIdx.y for small images) take it.  The generic kernel still fits with
+    // its smallest tile when the launch is too small for the lean path.
+    if (g.esz == 2 && C2 == 0 && Cin == 64 && g.CT == 4 && KH == 3 && KW == 3 && dil == 1 && stride == 1 && ups == 1) {
+        g.cch = 64;
+        g.kchunk = roundup(g.taps * 64, 32);
+        g.ngroups = g.kchunk / 8;
+        if (tile_geom(g, 1, KH, KW, dil, stride).total <= 150 * 1024) best = 64;
+    }
     for (int pass = 0; pass < 2 && !best; ++pass) {
         for (int c = (Cin < 128 ? Cin : 128); c >= 8; c -= 8) {
             if (Cin % c) continue;

@@ -20,6 +20,7 @@ struct LeanArgs {
     int tiles_x, tiles_y, ntiles;
     unsigned mag_tx, mag_ty;                     // ceil(2^32 / tiles_x), ceil(2^32 / tiles_y)
     int per_xcd;                                 // tiles per XCD chunk (0: plain grid-stride tile order)
+    int ct_total;                                // SPLIT: 16-row output-channel tiles of the whole conv (grid.y of them)
 };
 
 template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1>
@@ -43,8 +44,14 @@ struct LeanCfg {
     static constexpr int LDS = IN_BYTES + (WREG ? 0 : NCH * CT * 16 * WS);
 };
 
-template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false>
+// SPLIT: the output-channel tiles of one conv are spread over blockIdx.y (CT = 1 per workgroup).  For the level-3
+// layers (42x32 pixels: 96 pixel tiles for 256 CUs) this is what fills the device; every workgroup stages the same
+// input tile (an L2 hit for all but the first) and a quarter of the weights.
+template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false, bool SPLIT = false>
 __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) {
+    static_assert(!SPLIT || (CT == 1 && !DUAL && !DOUT && WGW == 1), "SPLIT instances are single-source, one tile per workgroup");
+    const int cty = SPLIT ? (int)blockIdx.y : 0;                 // this workgroup's channel tile
+    const int CTT = SPLIT ? a.ct_total : CT;                     // channel tiles of the conv
     using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL, WGW>;
     constexpr int NT = Cfg::NT;
     typedef typename Vec8<T>::type V8;
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
     const bool relu_in = d.flags & MSAU_CONV_RELU_IN;
 
     // ---- weights: registers (small) or LDS, once per (persistent) workgroup
-    const T* wp = static_cast<const T*>(d.wpack);
+    const T* wp = static_cast<const T*>(d.wpack) + (SPLIT ? (size_t)cty * 16 * a.kchunk : 0);     // [row][k], one chunk
     V8 afr[Cfg::WREG ? CT : 1][Cfg::WREG ? NKS : 1];
     if constexpr (Cfg::WREG) {
 #pragma unroll
@@ -93,12 +100,12 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         bv[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (d.bias && lg * (CT * 4) + ct * 4 < Cout) bv[ct] = *reinterpret_cast<const f32x4*>(d.bias + lg * (CT * 4) + ct * 4);
+        if (d.bias && lg * (CTT * 4) + (cty + ct) * 4 < Cout) bv[ct] = *reinterpret_cast<const f32x4*>(d.bias + lg * (CTT * 4) + (cty + ct) * 4);
     }
     const long long delta_add = static_cast<const char*>(d.add) - static_cast<const char*>(d.y);
     const long long delta_ma = static_cast<const char*>(d.mask_a) - static_cast<const char*>(d.y);
     const long long delta_mb = static_cast<const char*>(d.mask_b) - static_cast<const char*>(d.y);
-    const int lane_out = (cwt * 16 + lr) * a.out_px + lg * (CT * 4) * ESZ;
+    const int lane_out = (cwt * 16 + lr) * a.out_px + (lg * (CTT * 4) + cty * 4) * ESZ;
 
     // ---- staging: one source at a time so the base pointer stays scalar.  With few items per thread the
     // loads of tile t+1 are issued into registers before the MFMAs of tile t (software pipeline).
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
             char* y = static_cast<char*>(d.y) + ((long long)(b * d.Hout + oyw)) * a.out_row + (long long)ox0 * a.out_px;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                if (lg * (CT * 4) + ct * 4 >= Cout) continue;
+                if (lg * (CTT * 4) + (cty + ct) * 4 >= Cout) continue;
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) {
                     if (oyw + pt < d.Hout) {                       // scalar
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
     }
 }
 
-template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false>
+template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false, bool SPLIT = false>
 int launch_lean(hipStream_t s, const LeanArgs& a0) {
     using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL, WGW>;
     LeanArgs a = a0;
@@ -323,7 +330,7 @@ int launch_lean(hipStream_t s, const LeanArgs& a0) {
     a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS > 60 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_lean: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -338,7 +345,7 @@ int launch_lean(hipStream_t s, const LeanArgs& a0) {
         grid &= ~7;
         a.per_xcd = cdiv(a.ntiles, 8);
     }
-    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT>), dim3(grid), dim3(256 * WGW), Cfg::LDS, s, a);
+    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT>), dim3(grid, SPLIT ? a.ct_total : 1), dim3(256 * WGW), Cfg::LDS, s, a);
     MSAU_CHECK_LAUNCH("conv_lean_kernel");
     return 1;
 }
@@ -432,6 +439,25 @@ int lean_dout(hipStream_t s, const LeanArgs& a, int KS, int CT) {
     return 0;
 }
 
+// channel-split instances for small images: (CIN8, KS) in {4, 8} x {1, 3}
+static int lean_split_tiles() {
+    static const int v = std::getenv("MSAU_SPLIT_TILES") ? atoi(std::getenv("MSAU_SPLIT_TILES")) : 512;      // measured: 0 -> 5.04, 256 -> 4.90, 512 -> 4.83, 1024 -> 4.84 ms/step
+    return v;
+}
+static bool lean_split_wanted(const msau_conv_desc* d, int CT) {
+    const int cin8 = d->C1 / 8;
+    return d->C2 == 0 && d->dil == 1 && (d->KH == 1 || d->KH == 3) && (CT == 2 || CT == 4) && (cin8 == 4 || cin8 == 8) &&
+           !(d->flags & (MSAU_CONV_DOUT | MSAU_CONV_HEAD)) &&
+           (int64_t)d->B * cdiv(d->Hout, 16) * cdiv(d->Wout, 16) < lean_split_tiles();
+}
+template <typename T>
+int lean_split(hipStream_t s, const LeanArgs& a, int cin8, int KS) {
+#define SP_CASE(C8, K) if (cin8 == C8 && KS == K) return launch_lean<T, C8, 1, K, false, 1, 1, false, true>(s, a);
+    SP_CASE(4, 1) SP_CASE(4, 3) SP_CASE(8, 1) SP_CASE(8, 3)
+#undef SP_CASE
+    return 0;
+}
+
 // 1 if the lean instance that takes this launch implements MSAU_CONV_HEAD (the 4x4 end conv, one 16-row tile)
 int msau_conv_lean_head_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
     return msau_conv_lean_applicable(dtype, d, nchunks, CT) && d->KH == 4 && CT == 1 && d->dil == 1;
@@ -454,6 +480,9 @@ int msau_conv_lean_try(hipStream_t s, int dtype, const msau_conv_desc* d, int kc
     if (a.ntiles >= (1 << 20) || a.tiles_x >= 4096 || a.tiles_y >= 4096) return 0;
     a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
     a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
+    a.ct_total = CT;
+    if (lean_split_wanted(d, CT))
+        return dtype == MSAU_F32 ? lean_split<float>(s, a, cin8, d->KH) : lean_split<bf16_t>(s, a, cin8, d->KH);
     if (dout) {
         if (!msau_conv_lean_dout_capable(dtype, d, nchunks, CT)) return 0;
         return dtype == MSAU_F32 ? lean_dout<float>(s, a, d->KH, CT) : lean_dout<bf16_t>(s, a, d->KH, CT);
