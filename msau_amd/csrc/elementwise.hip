@@ -36,6 +36,32 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict
     }
 }
 
+// Tiled form for wide inputs: a workgroup moves 64 pixels x all channels through LDS, so that the plane reads are
+// 256-byte runs and every NHWC pixel (Cs * sizeof(T) bytes) is written as whole lines by neighbouring lanes.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_tiled_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                                 int C, int Cs, int64_t HW, int tiles_per_img) {
+    extern __shared__ __align__(16) unsigned char tsm[];
+    T* tile = reinterpret_cast<T*>(tsm);                       // [64][Cs + 8]
+    const int PS = Cs + 8;
+    const int b = blockIdx.x / tiles_per_img;
+    const int64_t p0 = (int64_t)(blockIdx.x - b * tiles_per_img) * 64;
+    const int px = threadIdx.x & 63, c0 = threadIdx.x >> 6;
+    const bool pv = p0 + px < HW;
+    for (int c = c0; c < Cs; c += 4) {
+        float v = 0.f;
+        if (pv && c < C) v = src[((int64_t)b * C + c) * HW + p0 + px];
+        tile[px * PS + c] = (T)v;
+    }
+    __syncthreads();
+    const int cgs = Cs >> 3;
+    for (int i = threadIdx.x; i < 64 * cgs; i += 256) {
+        const int q = i / cgs, cg = i - q * cgs;
+        if (p0 + q < HW)
+            store8<T>(dst + ((int64_t)b * HW + p0 + q) * Cs + cg * 8, *reinterpret_cast<const typename Vec8<T>::type*>(tile + q * PS + cg * 8));
+    }
+}
+
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int B, int C, int Cs, int64_t HW) {
     const int cgs = Cs >> 3;
@@ -588,6 +614,19 @@ extern "C" int msau_nchw_to_nhwc(void* stream, int dtype, const float* src, void
     MSAU_CHECK_ARG(src && dst && B > 0 && C > 0 && Cs >= C && Cs % 8 == 0 && H > 0 && W > 0, "nchw_to_nhwc: bad args");
     hipStream_t s = static_cast<hipStream_t>(stream);
     int64_t HW = (int64_t)H * W;
+    if (Cs >= 32 && Cs <= 1024) {
+        const int tiles = (int)cdiv64(HW, 64);
+        MSAU_CHECK_ARG((int64_t)B * tiles < (1ll << 31), "nchw_to_nhwc: grid too large");
+        const size_t esz = dtype == MSAU_F32 ? 4 : 2;
+        const size_t lds = 64 * (size_t)(Cs + 8) * esz;
+        if (lds <= 64 * 1024) {
+            DISPATCH_T(dtype,
+                       hipLaunchKernelGGL(nchw_to_nhwc_tiled_kernel<float>, dim3(B * tiles), dim3(256), lds, s, src, static_cast<float*>(dst), C, Cs, HW, tiles),
+                       hipLaunchKernelGGL(nchw_to_nhwc_tiled_kernel<bf16_t>, dim3(B * tiles), dim3(256), lds, s, src, static_cast<bf16_t*>(dst), C, Cs, HW, tiles));
+            MSAU_CHECK_LAUNCH("nchw_to_nhwc_tiled");
+            return 0;
+        }
+    }
     int grid = grid_for((int64_t)B * (Cs / 8) * HW);
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(kThreads), 0, s, src, static_cast<float*>(dst), B, C, Cs, HW),
