@@ -301,11 +301,11 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
                     for (int j = 0; j < 4; ++j) {
                         const float mine = (float)(T)v[j];                 // the storage-rounded logit, as written to y
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) all[q * 4 + j] = __shfl(mine, q * 16 + lr);
+                        for (int q = 0; q < 4; ++q) all[q * 4 + j] = __shfl(mine, q * 16 + lr);     // lanes of this wave
                     }
                     const int best = msau_head_softmax(all, ncls);
-                    if (oyw + pt < d.Hout && ox0 + lr < d.Wout) {
-                        const long long pix = ((long long)b * d.Hout + oyw + pt) * d.Wout + ox0 + lr;
+                    if (oyw + pt < d.Hout && ox0 + cwt * 16 + lr < d.Wout) {
+                        const long long pix = ((long long)b * d.Hout + oyw + pt) * d.Wout + ox0 + cwt * 16 + lr;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             float pr = all[j];
@@ -352,7 +352,7 @@ int launch_lean(hipStream_t s, const LeanArgs& a0) {
 
 template <typename T, int CIN8, int KS, bool DUAL>
 int lean_ct(hipStream_t s, const LeanArgs& a, int CT) {
-    if constexpr (sizeof(T) == 2 && (CIN8 == 1 || (DUAL && CIN8 == 2)) && KS == 3) {
+    if constexpr (sizeof(T) == 2 && (CIN8 == 1 || (DUAL && CIN8 == 2)) && KS == 3) {      // 4x4: measured, no gain
         // 16 x 32 output tile per 512-thread workgroup for the 8/16-channel layers: same work per wave, but a halo
         // row is 544 B (5-6 lines for 4.25 of payload) instead of 288 B (4 lines for 2.25)
         if (CT == 1 && a.d.Wout >= 64 && (int64_t)a.d.B * a.tiles_y * cdiv(a.d.Wout, 32) >= 512)
