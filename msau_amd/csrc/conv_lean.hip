@@ -23,11 +23,11 @@ struct LeanArgs {
     int ct_total;                                // SPLIT: 16-row output-channel tiles of the whole conv (grid.y of them)
 };
 
-template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1>
+template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, int STRIDE = 1>
 struct LeanCfg {
     static constexpr int ESZ = (int)sizeof(T);
-    static constexpr int TI = 16 + (KS - 1) * DIL;            // input tile rows
-    static constexpr int TIW = 16 * WGW + (KS - 1) * DIL;     // input tile columns (output tile = 16 x 16*WGW)
+    static constexpr int TI = 15 * STRIDE + 1 + (KS - 1) * DIL;               // input tile rows
+    static constexpr int TIW = (16 * WGW - 1) * STRIDE + 1 + (KS - 1) * DIL;  // input tile columns (output tile = 16 x 16*WGW)
     static constexpr int NT = 256 * WGW;                      // threads per workgroup
     static constexpr int PSRAW = CIN8 * 8 * ESZ;
     static constexpr int PS = ((PSRAW / 16) % 2 == 0) ? PSRAW + 16 : PSRAW;
@@ -47,12 +47,17 @@ struct LeanCfg {
 // SPLIT: the output-channel tiles of one conv are spread over blockIdx.y (CT = 1 per workgroup).  For the level-3
 // layers (42x32 pixels: 96 pixel tiles for 256 CUs) this is what fills the device; every workgroup stages the same
 // input tile (an L2 hit for all but the first) and a quarter of the weights.
-template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false, bool SPLIT = false>
+// STRIDE = 2: the data gradient of a transposed conv (each output pixel gathers input pixels 2y + k - pad).
+// UPS = 2: the transposed conv itself as a conv over the zero-stuffed input: the LDS tile is the virtual image, only
+// its even/even positions are loaded (the MFMAs run over the zeros; the launch is bound by its 4x larger output).
+template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false, bool SPLIT = false,
+          int STRIDE = 1, int UPS = 1>
 __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) {
     static_assert(!SPLIT || (CT == 1 && !DUAL && !DOUT && WGW == 1), "SPLIT instances are single-source, one tile per workgroup");
+    static_assert((STRIDE == 1 && UPS == 1) || (!DUAL && !DOUT && WGW == 1 && DIL == 1 && STRIDE * UPS == 2), "strided / upsampling instances");
     const int cty = SPLIT ? (int)blockIdx.y : 0;                 // this workgroup's channel tile
     const int CTT = SPLIT ? a.ct_total : CT;                     // channel tiles of the conv
-    using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL, WGW>;
+    using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL, WGW, STRIDE>;
     constexpr int NT = Cfg::NT;
     typedef typename Vec8<T>::type V8;
     typedef typename Vec4<T>::type V4;
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
         const int ky = tap / KS, kx = tap - ky * KS;
         koff[ks] = G < NG ? (ky * DIL * TI + kx * DIL) * PS + ((ks / NKSH) * C8H + cg) * 8 * ESZ : 0;
     }
-    const unsigned char* pixp = smem + ((wave * 4) * TI + cwt * 16 + lr) * PS;
+    const unsigned char* pixp = smem + ((wave * 4) * STRIDE * TI + (cwt * 16 + lr) * STRIDE) * PS;
 
     const int flags = d.flags;
     const int Cout = d.Cout;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
     auto issue_loads = [&](int tile) {
         int b, oy0, ox0;
         decode(tile, b, oy0, ox0);
-        const int vy0 = oy0 - d.pad_t, vx0 = ox0 - d.pad_l;    // forward: SAME pad; data gradient: (k-1) - pad
+        const int vy0 = oy0 * STRIDE - d.pad_t, vx0 = ox0 * STRIDE - d.pad_l;    // forward: SAME pad; data gradient: (k-1) - pad
 #pragma unroll
         for (int sidx = 0; sidx < NSRC; ++sidx) {
             const char* base = static_cast<const char*>(sidx ? d.x2 : d.x1) + (long long)b * d.Hin * (sidx ? a.in_row2 : a.in_row1);
@@ -136,8 +141,15 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
                 if ((it + 1) * NT <= NITEMS || idx < NITEMS) {
                     const int pix = idx / C8S, cg = idx - pix * C8S;
                     const int iy = pix / TI, ix = pix - iy * TI;
-                    const int vy = vy0 + iy, vx = vx0 + ix;
-                    if ((unsigned)vy < (unsigned)d.Hin && (unsigned)vx < (unsigned)d.Win)
+                    int vy = vy0 + iy, vx = vx0 + ix;
+                    bool ok;
+                    if constexpr (UPS == 2) {                      // zero-stuffed image: data at even / even virtual positions
+                        ok = vy >= 0 && vx >= 0 && !((vy | vx) & 1) && (vy >> 1) < d.Hin && (vx >> 1) < d.Win;
+                        vy >>= 1; vx >>= 1;
+                    } else {
+                        ok = (unsigned)vy < (unsigned)d.Hin && (unsigned)vx < (unsigned)d.Win;
+                    }
+                    if (ok)
                         pre[sidx][it] = *reinterpret_cast<const V8*>(base + (unsigned)(vy * in_row + vx * in_px + cg * 8 * ESZ));
                 }
             }
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
             const unsigned char* p = pixp + koff[ks];
             V8 bfrag[4];
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) bfrag[pt] = *reinterpret_cast<const V8*>(p + pt * TI * PS);
+            for (int pt = 0; pt < 4; ++pt) bfrag[pt] = *reinterpret_cast<const V8*>(p + pt * STRIDE * TI * PS);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 V8 af;
@@ -321,16 +333,17 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
     }
 }
 
-template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false, bool SPLIT = false>
+template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false, bool SPLIT = false,
+          int STRIDE = 1, int UPS = 1>
 int launch_lean(hipStream_t s, const LeanArgs& a0) {
-    using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL, WGW>;
+    using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL, WGW, STRIDE>;
     LeanArgs a = a0;
     a.tiles_x = cdiv(a.d.Wout, 16 * WGW);
     a.ntiles = a.d.B * a.tiles_x * a.tiles_y;
     a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS > 60 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT, STRIDE, UPS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_lean: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -345,7 +358,7 @@ int launch_lean(hipStream_t s, const LeanArgs& a0) {
         grid &= ~7;
         a.per_xcd = cdiv(a.ntiles, 8);
     }
-    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT>), dim3(grid, SPLIT ? a.ct_total : 1), dim3(256 * WGW), Cfg::LDS, s, a);
+    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT, STRIDE, UPS>), dim3(grid, SPLIT ? a.ct_total : 1), dim3(256 * WGW), Cfg::LDS, s, a);
     MSAU_CHECK_LAUNCH("conv_lean_kernel");
     return 1;
 }
@@ -397,9 +410,33 @@ int lean_dil(hipStream_t s, const LeanArgs& a, int cin8, int CT) {
 
 }  // namespace
 
+// transposed conv (ups = 2) and its data gradient (stride = 2), 3x3, single source: (C1/8, CT) per level
+static bool lean_strided_shape(const msau_conv_desc* d, int nchunks, int CT) {
+    if (d->KH != 3 || d->KW != 3 || d->dil != 1 || d->C2 || nchunks != 1 || d->stride * d->ups != 2) return false;
+    if (d->flags & (MSAU_CONV_DOUT | MSAU_CONV_HEAD | MSAU_CONV_RELU_IN)) return false;
+    if (d->pad_t < 0 || d->pad_l < 0 || d->pad_t > 2 || d->pad_l > 2) return false;
+    if ((int64_t)d->B * cdiv(d->Hout, 16) * cdiv(d->Wout, 16) < 64) return false;
+    const int c8 = d->C1 / 8;
+    if (d->ups == 2) return (c8 == 8 && CT == 2) || (c8 == 4 && CT == 1) || (c8 == 2 && CT == 1);
+    return (c8 == 4 && CT == 4) || (c8 == 2 && CT == 2) || (c8 == 1 && CT == 1);
+}
+template <typename T>
+int lean_strided(hipStream_t s, const LeanArgs& a, int c8, int CT, bool ups) {
+#define ST_CASE(C8, CTV, ST, UP) if (c8 == C8 && CT == CTV) return launch_lean<T, C8, CTV, 3, false, 1, 1, false, false, ST, UP>(s, a);
+    if (ups) { ST_CASE(8, 2, 1, 2) ST_CASE(4, 1, 1, 2) ST_CASE(2, 1, 1, 2) }
+    else { ST_CASE(4, 4, 2, 1) ST_CASE(2, 2, 2, 1) ST_CASE(1, 1, 2, 1) }
+#undef ST_CASE
+    return 0;
+}
+
 // Returns 1 if a lean instance handled the launch, 0 if the caller must use the generic kernel,
 // < 0 on error.  `kchunk` / `nchunks` / `CT` come from the generic geometry (same packed image).
 int msau_conv_lean_applicable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
+    if (d->stride * d->ups == 2) {
+        const int esz = dtype == MSAU_F32 ? 4 : 2;
+        if ((int64_t)d->Hin * d->Win * d->C1 * esz >= (1ll << 31) || (int64_t)d->Wout * d->Cout * esz * 20 >= (1ll << 31)) return 0;
+        return lean_strided_shape(d, nchunks, CT) ? 1 : 0;
+    }
     if (d->stride != 1 || d->ups != 1 || d->KH != d->KW || (d->KH != 1 && d->KH != 3 && d->KH != 4)) return 0;
     if (d->dil != 1) {
         if (d->KH != 3 || d->C2 || (d->dil != 2 && d->dil != 4 && d->dil != 8)) return 0;
@@ -481,6 +518,8 @@ int msau_conv_lean_try(hipStream_t s, int dtype, const msau_conv_desc* d, int kc
     a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
     a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
     a.ct_total = CT;
+    if (d->stride * d->ups == 2)
+        return dtype == MSAU_F32 ? lean_strided<float>(s, a, cin8, CT, d->ups == 2) : lean_strided<bf16_t>(s, a, cin8, CT, d->ups == 2);
     if (lean_split_wanted(d, CT))
         return dtype == MSAU_F32 ? lean_split<float>(s, a, cin8, d->KH) : lean_split<bf16_t>(s, a, cin8, d->KH);
     if (dout) {

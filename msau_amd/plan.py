@@ -356,7 +356,8 @@ class ConvOp(Op):
                 ex2 = sum(1 for f in (L.CONV_ACCUM, L.CONV_MASK_B) if d.flags2 & f)
                 return f"conv_lean_kernel<{T},CIN{d.C1},CT{info[0]},K{d.KH},dout>", (nin + half * (2 + ex1 + ex2)) * esz
             if info[6]:
-                name = f"conv_lean_kernel<{T},CIN{d.C1 + d.C2},CT{info[0]},K{d.KH}{',dual' if d.C2 else ''}>"
+                var = ",dual" if d.C2 else ",ups2" if d.ups == 2 else ",s2" if d.stride == 2 else ""
+                name = f"conv_lean_kernel<{T},CIN{d.C1 + d.C2},CT{info[0]},K{d.KH}{var}>"
             else:
                 name = f"conv_kernel<{T},CT{info[0]},PT{info[1]}>"
             return name, (nin + nout * (1 + extra)) * esz
