@@ -104,10 +104,10 @@ __global__ __launch_bounds__(256) void attn_stats_mfma(const bf16_t* __restrict_
 // the four sweep modes
 // ---------------------------------------------------------------------------------------------
 template <int DS, int CS, int MODE>
-__global__ __launch_bounds__(256) void attn_sweep_mfma(const bf16_t* __restrict__ f, const bf16_t* __restrict__ g,
-                                                       const bf16_t* __restrict__ h, const bf16_t* __restrict__ xdy,
-                                                       const float* __restrict__ stats, float* __restrict__ delta,
-                                                       bf16_t* __restrict__ out, int N) {
+__device__ __forceinline__ void attn_sweep_body(const bf16_t* __restrict__ f, const bf16_t* __restrict__ g,
+                                                const bf16_t* __restrict__ h, const bf16_t* __restrict__ xdy,
+                                                const float* __restrict__ stats, float* __restrict__ delta,
+                                                bf16_t* __restrict__ out, int N) {
     constexpr bool OWN_I = (MODE == M_DH || MODE == M_DG);        // own positions are rows of s
     constexpr bool ACC_C = (MODE == M_O || MODE == M_DH);         // second product over the C tensor
     constexpr int CTC = CS / 16, KSC = CS / 32;
@@ -288,6 +288,25 @@ __global__ __launch_bounds__(256) void attn_sweep_mfma(const bf16_t* __restrict_
 }
 
 template <int DS, int CS, int MODE>
+__global__ __launch_bounds__(256) void attn_sweep_mfma(const bf16_t* __restrict__ f, const bf16_t* __restrict__ g,
+                                                       const bf16_t* __restrict__ h, const bf16_t* __restrict__ xdy,
+                                                       const float* __restrict__ stats, float* __restrict__ delta,
+                                                       bf16_t* __restrict__ out, int N) {
+    attn_sweep_body<DS, CS, MODE>(f, g, h, xdy, stats, delta, out, N);
+}
+
+// dg and df need the same inputs (delta from the DH sweep) and nothing from each other: one launch, blockIdx.z picks
+// the mode, twice the workgroups in flight (the sweeps are latency-bound at 336 workgroups).
+template <int DS, int CS>
+__global__ __launch_bounds__(256) void attn_sweep_dgdf(const bf16_t* __restrict__ f, const bf16_t* __restrict__ g,
+                                                       const bf16_t* __restrict__ h, const bf16_t* __restrict__ dy,
+                                                       const float* __restrict__ stats, float* __restrict__ delta,
+                                                       bf16_t* __restrict__ dg, bf16_t* __restrict__ df, int N) {
+    if (blockIdx.z == 0) attn_sweep_body<DS, CS, M_DG>(f, g, h, dy, stats, delta, dg, N);
+    else attn_sweep_body<DS, CS, M_DF>(f, g, h, dy, stats, delta, df, N);
+}
+
+template <int DS, int CS, int MODE>
 int launch_sweep(hipStream_t s, const bf16_t* f, const bf16_t* g, const bf16_t* h, const bf16_t* xdy, const float* stats,
                  float* delta, bf16_t* out, int B, int N) {
     constexpr int lds = (CHUNK * DS * 2 + 64) + CHUNK * (CS * 2 + 16) + 3 * CHUNK * 4;
@@ -322,9 +341,11 @@ int bwd_t(hipStream_t s, const void* f, const void* g, const void* h, const void
     const bf16_t* hp = static_cast<const bf16_t*>(h); const bf16_t* dyp = static_cast<const bf16_t*>(dy);
     int rc = launch_sweep<DS, CS, M_DH>(s, fp, gp, hp, dyp, stats, ws, static_cast<bf16_t*>(dh), B, N);
     if (rc) return rc;
-    rc = launch_sweep<DS, CS, M_DG>(s, fp, gp, hp, dyp, stats, ws, static_cast<bf16_t*>(dg), B, N);
-    if (rc) return rc;
-    return launch_sweep<DS, CS, M_DF>(s, fp, gp, hp, dyp, stats, ws, static_cast<bf16_t*>(df), B, N);
+    constexpr int lds = (CHUNK * DS * 2 + 64) + CHUNK * (CS * 2 + 16) + 3 * CHUNK * 4;
+    hipLaunchKernelGGL((attn_sweep_dgdf<DS, CS>), dim3(cdiv(N, 64), B, 2), dim3(256), lds, s, fp, gp, hp, dyp, stats, ws,
+                       static_cast<bf16_t*>(dg), static_cast<bf16_t*>(df), N);
+    MSAU_CHECK_LAUNCH("attn_sweep_dgdf");
+    return 0;
 }
 
 }  // namespace
