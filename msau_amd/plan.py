@@ -122,6 +122,12 @@ class ConvOp(Op):
         self.stage = plan._cur_stage
         plan.ops.append(self)
 
+    def reduce_group(self):
+        """slab-reduction group: the stage, except for the level-0 encoder convs of stage 0.  They close the backward
+        sweep, and whatever is reduced behind them is exposed; with a group of their own the bulk of stage 0 (the
+        level-1..3 layers own most of the slab bytes) is reduced earlier, while the level-0 launches still run."""
+        return -1 if (self.stage == 0 and self.name.startswith("s0.d0.")) else self.stage
+
     def reads(self):
         return [t for t in (self.x1, self.x2, self.fwd_add) if t is not None]
 
@@ -329,7 +335,7 @@ class ConvOp(Op):
             self.csum_off = P.alloc_slab(self.csum_blocks * out.Cs)
             u.b_src_off, u.b_slab_stride, u.b_elem_stride, u.b_nslabs = self.csum_off, out.Cs, 1, self.csum_blocks
             u.b_count = out.C
-        P.add_unpack_entry(u, rows_real * wg.nchunks * taps * wg.cch, self.stage)
+        P.add_unpack_entry(u, rows_real * wg.nchunks * taps * wg.cch, self.reduce_group())
 
     def late_bind(self):
         P = self.plan
@@ -395,6 +401,9 @@ class ConvOp(Op):
         if self.wdesc is None:
             return []
         side = L.OP_SIDE if self.plan.overlap_wgrad else 0     # weight gradients run beside the data-gradient chain
+        if self.x1 is self.plan.x_in:
+            side = 0        # the net's first conv has no data gradient: nothing is left on the main stream to run beside,
+                            # and the side stream is still busy with the two weight gradients enqueued before this one
         recs = [(L.OP_WGRAD | side, self.wdesc)]
         if self.kind != "conv":
             P = self.plan
@@ -759,16 +768,27 @@ class Plan:
             recs = []
             stages = sorted({op.stage for op in self.ops}, reverse=True)
             esz = C.sizeof(L.UnpackEntry)
+            def reduce_rec(group):
+                idx = [i for i, st in enumerate(self._unpack_stage) if st == group]
+                if not idx:
+                    return
+                assert idx == list(range(idx[0], idx[-1] + 1)), "unpack entries of a group must be contiguous"
+                ra = L.ReduceArgs(self.slab_arena.data_ptr(), None, self.unpack_table.data_ptr() + idx[0] * esz,
+                                  len(idx), self._unpack_max)
+                self._reduce_args.append(ra)
+                recs.append((L.OP_WGRAD_REDUCE | (L.OP_SIDE if self.overlap_wgrad else 0), ra))
+
             for b in stages:
                 start = len(recs)
-                recs += [r for op in reversed(self.ops) if op.stage == b for r in op.bwd_recs()]
-                idx = [i for i, st in enumerate(self._unpack_stage) if st == b]
-                if idx:
-                    assert idx == list(range(idx[0], idx[-1] + 1)), "unpack entries of a stage must be contiguous"
-                    ra = L.ReduceArgs(self.slab_arena.data_ptr(), None, self.unpack_table.data_ptr() + idx[0] * esz,
-                                      len(idx), self._unpack_max)
-                    self._reduce_args.append(ra)
-                    recs.append((L.OP_WGRAD_REDUCE | (L.OP_SIDE if self.overlap_wgrad else 0), ra))
+                ops_b = [op for op in reversed(self.ops) if op.stage == b]
+                cut = next((i for i, op in enumerate(ops_b) if isinstance(op, ConvOp) and op.reduce_group() != b), len(ops_b))
+                assert all(not isinstance(op, ConvOp) or op.reduce_group() != b for op in ops_b[cut:]), \
+                    "separately reduced convs must close their stage's backward"
+                recs += [r for op in ops_b[:cut] for r in op.bwd_recs()]
+                reduce_rec(b)
+                if cut < len(ops_b):
+                    recs += [r for op in ops_b[cut:] for r in op.bwd_recs()]
+                    reduce_rec(-1)
                 self._bwd_segs.append((b, start, len(recs) - start))
             self._bwd_seq = self._make_seq(recs)
         HW = self.H * self.W
