@@ -232,12 +232,15 @@ def test_graph_replay_after_host_sync_matches_eager_at_bench_size():
     ("cfg1", 32, 1, 128, 128, False),        # BASELINE configs[0]: 1-stage 128x128x32, batch 2
     ("cfg4", 768, 2, 336, 256, True),        # configs[3]: BERT-embedding chargrid 336x256x768, 2 stages
     ("cfg5-geometry", 64, 3, 512, 384, False),   # configs[4] geometry with plain residual blocks (box conv: unpinned)
+    ("odd-sizes", 13, 3, 333, 251, False),   # odd at every level (333->167->84->42, 251->126->63->32), large enough for
+                                             # the specialised kernels: partial tiles, both output_padding cases of the
+                                             # transposed convs (UPS=2 / STRIDE=2 instances), two-output data gradients
 ])
 def test_baseline_configs_full_size_vs_oracle(tag, channels, stages, H, W, dense):
     """every BASELINE configuration at its full spatial / channel size: HIP fp32 forward + loss + gradient norm
     against the CPU oracle on the same seeded input (the oracle finishes these in seconds)"""
     from oracle import msau_oracle as O
-    B = 2 if tag == "cfg1" else 1
+    B = 2 if tag in ("cfg1", "odd-sizes") else 1
     cfg = dict(O.DEFAULT_CFG, channels=channels, num_blocks=stages)
     sd = O.init_params(cfg, seed=31)
     x, label = O.synthetic_batch(B, channels, H, W, 5, seed=32, dense=dense)
@@ -261,6 +264,16 @@ def test_baseline_configs_full_size_vs_oracle(tag, channels, stages, H, W, dense
     loss = eng.step(x.cuda(), label.cuda())
     assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
     assert abs(float(eng.grad_norm) - gn_ref) < 2e-3 * gn_ref
+    if tag == "odd-sizes":
+        # every parameter gradient, not just the norm
+        gmax = max(float(p.grad.abs().max()) for p in leaves.values() if p.grad is not None)
+        for k, off in m._poff.items():
+            ref = leaves[k].grad
+            got = eng.flat_grad[off:off + leaves[k].numel()].view(leaves[k].shape).cpu()
+            if ref is None:
+                assert float(got.abs().max()) == 0.0, k
+            else:
+                assert float((got - ref).abs().max()) < 2e-3 * float(ref.abs().max()) + 1e-5 * gmax, k
 
 
 def test_unet_loss_and_trainer_api(tmp_path):
