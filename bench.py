@@ -117,7 +117,8 @@ def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # MSAU_BENCH_DEVICE: all ranks on one card (2-rank gloo rehearsal of the multi-GPU control flow on a one-GPU box)
+    local_rank = int(os.environ.get("MSAU_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     if args.gpus > 1 and world == 1:
         # convenience: relaunch under torch.distributed.run as a CHILD process (never exec after HIP init)
         import subprocess
@@ -135,7 +136,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(os.environ.get("MSAU_DIST_BACKEND", "nccl"), device_id=dev)
+        backend = os.environ.get("MSAU_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     from msau_amd import _lib as L
     from msau_amd.model import MSAUWrapper, TrainEngine
@@ -175,6 +177,9 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
+        # the measuring passes below run on rank 0 only: take the gradient exchange out of the step (a collective that
+        # only one rank enters would hang); the other ranks wait at the barrier before the process group is torn down
+        eng.sync.active = False
         # per-launch HIP-event timing of the same step, eagerly, on the launch stream
         plan = model._plan_for(x, training=True)
         prof = L.Profiler()
@@ -281,6 +286,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1 or os.environ.get("MSAU_FORCE_DIST") == "1":
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 
