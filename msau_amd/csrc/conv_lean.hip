@@ -337,6 +337,7 @@ template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW 
           int STRIDE = 1, int UPS = 1>
 int launch_lean(hipStream_t s, const LeanArgs& a0) {
     using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL, WGW, STRIDE>;
+    if (Cfg::LDS + 256 > MSAU_LDS_LIMIT) return 0;          // does not fit: the generic kernel takes the launch
     LeanArgs a = a0;
     a.tiles_x = cdiv(a.d.Wout, 16 * WGW);
     a.ntiles = a.d.B * a.tiles_x * a.tiles_y;
@@ -410,6 +411,19 @@ int lean_dil(hipStream_t s, const LeanArgs& a, int cin8, int CT) {
 
 }  // namespace
 
+static bool lean_split_wanted(const msau_conv_desc* d, int CT);
+
+// LeanCfg::LDS at run time (same formula), for the applicability queries
+static int lean_lds_bytes(int esz, int cin8, int CT, int KS, int dil, int wgw, int stride, bool dual) {
+    const int ti = 15 * stride + 1 + (KS - 1) * dil, tiw = (16 * wgw - 1) * stride + 1 + (KS - 1) * dil;
+    const int psraw = cin8 * 8 * esz, ps = ((psraw / 16) % 2 == 0) ? psraw + 16 : psraw;
+    const int nch = dual ? 2 : 1, c8h = cin8 / nch, ng = KS * KS * c8h, nksh = (ng + 3) / 4, nks = nch * nksh;
+    const bool wreg = CT * nks <= 8;
+    const int ws = nksh * 32 * esz + 16;
+    const int in_bytes = ((ti * tiw * ps + 15) / 16) * 16;
+    return in_bytes + (wreg ? 0 : nch * CT * 16 * ws);
+}
+
 // transposed conv (ups = 2) and its data gradient (stride = 2), 3x3, single source: (C1/8, CT) per level
 static bool lean_strided_shape(const msau_conv_desc* d, int nchunks, int CT) {
     if (d->KH != 3 || d->KW != 3 || d->dil != 1 || d->C2 || nchunks != 1 || d->stride * d->ups != 2) return false;
@@ -435,7 +449,8 @@ int msau_conv_lean_applicable(int dtype, const msau_conv_desc* d, int nchunks, i
     if (d->stride * d->ups == 2) {
         const int esz = dtype == MSAU_F32 ? 4 : 2;
         if ((int64_t)d->Hin * d->Win * d->C1 * esz >= (1ll << 31) || (int64_t)d->Wout * d->Cout * esz * 20 >= (1ll << 31)) return 0;
-        return lean_strided_shape(d, nchunks, CT) ? 1 : 0;
+        if (!lean_strided_shape(d, nchunks, CT)) return 0;
+        return lean_lds_bytes(esz, d->C1 / 8, CT, 3, 1, 1, d->stride, false) + 256 <= MSAU_LDS_LIMIT;
     }
     if (d->stride != 1 || d->ups != 1 || d->KH != d->KW || (d->KH != 1 && d->KH != 3 && d->KH != 4)) return 0;
     if (d->dil != 1) {
@@ -458,6 +473,9 @@ int msau_conv_lean_applicable(int dtype, const msau_conv_desc* d, int nchunks, i
     if ((int64_t)d->Wout * d->Cout * esz * 20 >= (1ll << 31)) return 0;
     if (cin8 != 1 && cin8 != 2 && cin8 != 4 && cin8 != 8 && !(cin8 == 16 && dual && d->KH == 1)) return 0;
     if (dual && cin8 < 2) return 0;
+    // the instance that would take the launch must fit the LDS (fp32 storage doubles every tile)
+    const bool split = lean_split_wanted(d, CT);
+    if (lean_lds_bytes(esz, cin8, split ? 1 : CT, d->KH, d->dil, 1, 1, dual) + 256 > MSAU_LDS_LIMIT) return 0;
     return 1;
 }
 

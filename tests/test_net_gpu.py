@@ -341,3 +341,25 @@ def test_two_output_data_gradient_is_bit_identical_to_two_launches(monkeypatch):
         assert (nf > 10) if fuse == "1" else (nf == 0)
         outs.append((eng.flat_grad.clone(), m.flat_parameters.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_bench_size_step_runs_in_both_storage_types():
+    """B=16, 336x256x64 (the bench workload): every launch of the step must fit its resources in fp32 storage too
+    (fp32 doubles every LDS tile; a 2026-10-04 regression had one instance over the limit), and the two storage types
+    must agree on the loss."""
+    from oracle import msau_oracle as O
+    x, label = O.synthetic_batch(16, 64, 336, 256, 5, seed=3)
+    x, label = x.cuda(), label.cuda()
+    losses = {}
+    for dtype in ("fp32", "bf16"):
+        kw = dict(scale_space_num=4, res_depth=2, featRoot=8, final_act="softmax", num_blocks=3, dtype=dtype, seed=0)
+        m = MSAUWrapper(64, 5, kw).cuda()
+        eng = TrainEngine(m)
+        for _ in range(2):
+            loss = eng.step(x, label)
+        torch.cuda.synchronize()
+        losses[dtype] = float(loss)
+        assert 0 < losses[dtype] < 10 and float(eng.grad_norm) > 0
+        del eng, m
+        torch.cuda.empty_cache()
+    assert abs(losses["fp32"] - losses["bf16"]) < 2e-2 * losses["fp32"], losses
