@@ -254,7 +254,7 @@ int attn_bwd_d(hipStream_t s, const void* f, const void* g, const void* h, const
 }  // namespace
 
 // bf16 instances on the matrix cores (attention_mfma.hip)
-int msau_attn_mfma_supported(int Ds, int Cs);
+int msau_attn_mfma_supported(int Ds, int Cs, int N);
 int msau_attn_mfma_fwd(hipStream_t s, const void* f, const void* g, const void* h, const void* x, void* y, float* stats,
                        int B, int N, int Ds, int Cs);
 int msau_attn_mfma_bwd(hipStream_t s, const void* f, const void* g, const void* h, const void* dy, const float* stats,
@@ -265,7 +265,7 @@ extern "C" int msau_selfattn_fwd(void* stream, int dtype, const void* f, const v
     MSAU_CHECK_ARG(f && g && h && x && y && stats && B > 0 && N > 0, "selfattn_fwd: bad args");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == MSAU_F32) return attn_fwd_d<float>(s, f, g, h, x, y, stats, B, N, Ds, Cs);
-    if (dtype == MSAU_BF16 && msau_attn_mfma_supported(Ds, Cs)) return msau_attn_mfma_fwd(s, f, g, h, x, y, stats, B, N, Ds, Cs);
+    if (dtype == MSAU_BF16 && msau_attn_mfma_supported(Ds, Cs, N)) return msau_attn_mfma_fwd(s, f, g, h, x, y, stats, B, N, Ds, Cs);
     if (dtype == MSAU_BF16) return attn_fwd_d<bf16_t>(s, f, g, h, x, y, stats, B, N, Ds, Cs);
     return msau_set_error(MSAU_ERR_ARG, "selfattn_fwd: bad dtype");
 }
@@ -275,7 +275,7 @@ extern "C" int msau_selfattn_bwd(void* stream, int dtype, const void* f, const v
     MSAU_CHECK_ARG(f && g && h && dy && stats && df && dg && dh && ws && B > 0 && N > 0, "selfattn_bwd: bad args");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == MSAU_F32) return attn_bwd_d<float>(s, f, g, h, dy, stats, df, dg, dh, ws, B, N, Ds, Cs);
-    if (dtype == MSAU_BF16 && msau_attn_mfma_supported(Ds, Cs))
+    if (dtype == MSAU_BF16 && msau_attn_mfma_supported(Ds, Cs, N))
         return msau_attn_mfma_bwd(s, f, g, h, dy, stats, df, dg, dh, ws, B, N, Ds, Cs);
     if (dtype == MSAU_BF16) return attn_bwd_d<bf16_t>(s, f, g, h, dy, stats, df, dg, dh, ws, B, N, Ds, Cs);
     return msau_set_error(MSAU_ERR_ARG, "selfattn_bwd: bad dtype");

@@ -351,7 +351,11 @@ int bwd_t(hipStream_t s, const void* f, const void* g, const void* h, const void
 }  // namespace
 
 // returns 1 if the (Ds, Cs) pair has an MFMA instance (bf16 only), else 0
-int msau_attn_mfma_supported(int Ds, int Cs) { return (Ds == 8 && (Cs == 32 || Cs == 64)) || (Ds == 16 && Cs == 128); }
+// (the statistics kernel keeps f of one whole sample in LDS: larger images take the VALU kernels of attention.hip)
+int msau_attn_mfma_supported(int Ds, int Cs, int N) {
+    if (!((Ds == 8 && (Cs == 32 || Cs == 64)) || (Ds == 16 && Cs == 128))) return 0;
+    return (size_t)((N + 15) & ~15) * Ds * 2 + 64 <= 150 * 1024;
+}
 
 int msau_attn_mfma_fwd(hipStream_t s, const void* f, const void* g, const void* h, const void* x, void* y, float* stats,
                        int B, int N, int Ds, int Cs) {

@@ -390,6 +390,43 @@ __global__ void masked_ce_kernel(const T* __restrict__ logits, const int64_t* __
     }
 }
 
+// Any class count (Cs > 16: e.g. the 17-class key-value head): the logits of a pixel are read three times from the
+// cache instead of being held in registers.  Same arithmetic and summation order as masked_ce_kernel.
+template <typename T, bool ALL>
+__global__ void masked_ce_wide_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels,
+                                      const int32_t* __restrict__ counts, T* __restrict__ dlogits, float* __restrict__ partials,
+                                      int B, int64_t hw, int C, int Cs, float scale) {
+    __shared__ float red[kThreads / 64];
+    float local = 0.f;
+    const int64_t total = (int64_t)B * hw;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(p / hw);
+        const int64_t lab = labels[p];
+        const bool on = ALL ? (lab >= 0 && lab < C) : (lab != 0 && lab > 0 && lab < C);
+        const float w = on ? (ALL ? scale : scale / (float)max(counts[b], 1)) : 0.f;
+        const T* l = logits + p * Cs;
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, (float)l[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += __expf((float)l[c] - mx);
+        const float lse = mx + __logf(se);
+        if (on) local += w * (lse - (float)l[lab]);
+        for (int c = 0; c < Cs; ++c) {
+            float g = 0.f;
+            if (on && c < C) g = w * (__expf((float)l[c] - lse) - (c == (int)lab ? 1.f : 0.f));
+            dlogits[p * Cs + c] = (T)g;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < kThreads / 64; ++i) s += red[i];
+        partials[blockIdx.x] = s;
+    }
+}
+
 // Final + auxiliary masked CE in ONE launch (model/model.py:455-458: CE(out) + CE(aux) over the same labelled pixels):
 // the label and the per-sample weight are read once, both gradients are written, block partial sums go to ws and the
 // one-wave follow-up kernel adds them up in index order -> loss[0], reproducibly.  (A "last block sums" ticket
@@ -718,9 +755,18 @@ extern "C" int64_t msau_ce_ws_floats(int64_t npix_total) { return ce_blocks(npix
 extern "C" int msau_masked_ce(void* stream, int dtype, const void* logits, const int64_t* labels, const int32_t* counts,
                               void* dlogits, float* loss_accum, float* ws, int B, int64_t hw, int C, int Cs, float scale) {
     MSAU_CHECK_ARG(logits && labels && counts && dlogits && loss_accum && ws, "masked_ce: null pointer");
-    MSAU_CHECK_ARG(B > 0 && hw > 0 && C > 0 && C <= Cs && Cs % 8 == 0 && Cs <= 16, "masked_ce: bad dims (n_class <= 16)");
+    MSAU_CHECK_ARG(B > 0 && hw > 0 && C > 0 && C <= Cs && Cs % 8 == 0 && Cs <= 256, "masked_ce: bad dims (n_class <= 256)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     int nb = ce_blocks((int64_t)B * hw);
+    if (Cs > 16) {
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL((masked_ce_wide_kernel<float, false>), dim3(nb), dim3(kThreads), 0, s, static_cast<const float*>(logits), labels, counts, static_cast<float*>(dlogits), ws, B, hw, C, Cs, scale),
+                   hipLaunchKernelGGL((masked_ce_wide_kernel<bf16_t, false>), dim3(nb), dim3(kThreads), 0, s, static_cast<const bf16_t*>(logits), labels, counts, static_cast<bf16_t*>(dlogits), ws, B, hw, C, Cs, scale));
+        MSAU_CHECK_LAUNCH("masked_ce_wide");
+        hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(64), 0, s, ws, nb, loss_accum);
+        MSAU_CHECK_LAUNCH("ordered_sum");
+        return 0;
+    }
     DISPATCH_T(dtype,
                hipLaunchKernelGGL((masked_ce_kernel<float, false>), dim3(nb), dim3(kThreads), 0, s, static_cast<const float*>(logits), labels, counts, static_cast<float*>(dlogits), ws, B, hw, C, Cs, scale),
                hipLaunchKernelGGL((masked_ce_kernel<bf16_t, false>), dim3(nb), dim3(kThreads), 0, s, static_cast<const bf16_t*>(logits), labels, counts, static_cast<bf16_t*>(dlogits), ws, B, hw, C, Cs, scale));
@@ -756,9 +802,18 @@ extern "C" int msau_masked_ce_multi(void* stream, int dtype, const void* logits,
 extern "C" int msau_softmax_ce(void* stream, int dtype, const void* logits, const int64_t* labels, void* dlogits,
                                float* loss_accum, float* ws, int B, int64_t hw, int C, int Cs, float scale) {
     MSAU_CHECK_ARG(logits && labels && dlogits && loss_accum && ws, "softmax_ce: null pointer");
-    MSAU_CHECK_ARG(B > 0 && hw > 0 && C > 0 && C <= Cs && Cs % 8 == 0 && Cs <= 16, "softmax_ce: bad dims (n_class <= 16)");
+    MSAU_CHECK_ARG(B > 0 && hw > 0 && C > 0 && C <= Cs && Cs % 8 == 0 && Cs <= 256, "softmax_ce: bad dims (n_class <= 256)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     int nb = ce_blocks((int64_t)B * hw);
+    if (Cs > 16) {
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL((masked_ce_wide_kernel<float, true>), dim3(nb), dim3(kThreads), 0, s, static_cast<const float*>(logits), labels, nullptr, static_cast<float*>(dlogits), ws, B, hw, C, Cs, scale),
+                   hipLaunchKernelGGL((masked_ce_wide_kernel<bf16_t, true>), dim3(nb), dim3(kThreads), 0, s, static_cast<const bf16_t*>(logits), labels, nullptr, static_cast<bf16_t*>(dlogits), ws, B, hw, C, Cs, scale));
+        MSAU_CHECK_LAUNCH("softmax_ce_wide");
+        hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(64), 0, s, ws, nb, loss_accum);
+        MSAU_CHECK_LAUNCH("ordered_sum");
+        return 0;
+    }
     DISPATCH_T(dtype,
                hipLaunchKernelGGL((masked_ce_kernel<float, true>), dim3(nb), dim3(kThreads), 0, s, static_cast<const float*>(logits), labels, nullptr, static_cast<float*>(dlogits), ws, B, hw, C, Cs, scale),
                hipLaunchKernelGGL((masked_ce_kernel<bf16_t, true>), dim3(nb), dim3(kThreads), 0, s, static_cast<const bf16_t*>(logits), labels, nullptr, static_cast<bf16_t*>(dlogits), ws, B, hw, C, Cs, scale));

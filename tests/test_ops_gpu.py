@@ -351,3 +351,35 @@ def test_masked_ce_multi_equals_two_single_launches(dtype, C, with_aux):
         assert torch.equal(d1, d_ref[1])
     assert abs(float(loss) - float(ref_loss)) <= 2e-6 * abs(float(ref_loss))
     assert float(d0[1].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_masked_ce_more_than_16_classes(dtype):
+    """the 17-class key-value head (inference/postprocess.py CLASS_NAMES): CE value and gradient against torch"""
+    torch.manual_seed(11)
+    B, H, W, C = 2, 21, 17, 17
+    Cs = 24
+    td = torch.float32 if dtype == "fp32" else torch.bfloat16
+    dt = L.F32 if dtype == "fp32" else L.BF16
+    lg = torch.zeros(B, H, W, Cs)
+    lg[..., :C] = torch.randn(B, H, W, C) * 2
+    lg = lg.to(td).cuda()
+    labels = torch.randint(0, C, (B, H, W), dtype=torch.int64).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    counts = torch.zeros(B, dtype=torch.int32, device="cuda")
+    L.call("msau_label_counts", s, labels.data_ptr(), counts.data_ptr(), B, H * W)
+    ws = torch.zeros(int(L.load().msau_ce_ws_floats(B * H * W)), device="cuda")
+    loss = torch.zeros(1, device="cuda")
+    d = torch.empty_like(lg)
+    L.call("msau_masked_ce", s, dt, lg.data_ptr(), labels.data_ptr(), counts.data_ptr(), d.data_ptr(), loss.data_ptr(), ws.data_ptr(),
+           B, H * W, C, Cs, 1.0 / B)
+    x = lg[..., :C].float().clone().requires_grad_(True)
+    ref = 0.0
+    for b in range(B):
+        sel = labels[b] != 0
+        ref = ref + torch.nn.functional.cross_entropy(x[b][sel], labels[b][sel]) / B
+    ref.backward()
+    tol = 1e-5 if dtype == "fp32" else 1e-2
+    assert abs(float(loss) - float(ref)) < max(tol, 1e-5) * abs(float(ref)) + 1e-6
+    assert float((d[..., :C].float() - x.grad).abs().max()) < tol * float(x.grad.abs().max()) + 1e-7
+    assert float(d[..., C:].float().abs().max()) == 0.0
