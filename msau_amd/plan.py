@@ -173,7 +173,7 @@ class ConvOp(Op):
         self.d_off = [None, None]
         self.dd_off = None           # one launch for both sources of a concat conv (MSAU_CONV_DOUT) when an instance has it
         if P.training and conv and x2 is not None and None not in self.slots and x1.C == x1.Cs == x2.C == x2.Cs \
-                and os.environ.get("MSAU_FUSE_DGRAD", "1") != "0":
+                and x1.Cs + x2.Cs <= 128 and os.environ.get("MSAU_FUSE_DGRAD", "1") != "0":
             proto = L.ConvDesc()
             proto.B, proto.Hin, proto.Win, proto.Hout, proto.Wout = P.B, out.H, out.W, x1.H, x1.W
             proto.C1, proto.C2, proto.Cout = out.Cs, 0, x1.Cs + x2.Cs

@@ -148,3 +148,10 @@ def test_roofline_tool_known_answers():
     # the parameter count of the walk agrees with the model's own table
     cfg = dict(channels=64, n_class=5, featRoot=8, scale_space_num=4, res_depth=2, filter_size=3, num_blocks=3)
     assert sum(int(np.prod(s)) for s in param_shapes(cfg).values()) == w["params"]
+
+
+def test_unsupported_width_fails_at_construction():
+    """the reference's constructor defaults (6 scales -> 256 channels) are outside the kernels' envelope: loud and early"""
+    with pytest.raises(NotImplementedError, match="support up to 128"):
+        MSAUWrapper(4, 3)
+    MSAUWrapper(4, 3, dict(scale_space_num=5, featRoot=8))          # 128 channels: inside
