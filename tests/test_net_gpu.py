@@ -235,12 +235,13 @@ def test_graph_replay_after_host_sync_matches_eager_at_bench_size():
     ("odd-sizes", 13, 3, 333, 251, False),   # odd at every level (333->167->84->42, 251->126->63->32), large enough for
                                              # the specialised kernels: partial tiles, both output_padding cases of the
                                              # transposed convs (UPS=2 / STRIDE=2 instances), two-output data gradients
+    ("batch-11", 64, 3, 336, 256, False),    # 66 pixel tiles at level 3, 264 at level 2: the channel-split instances
 ])
 def test_baseline_configs_full_size_vs_oracle(tag, channels, stages, H, W, dense):
     """every BASELINE configuration at its full spatial / channel size: HIP fp32 forward + loss + gradient norm
     against the CPU oracle on the same seeded input (the oracle finishes these in seconds)"""
     from oracle import msau_oracle as O
-    B = 2 if tag in ("cfg1", "odd-sizes") else 1
+    B = {"cfg1": 2, "odd-sizes": 2, "batch-11": 11}.get(tag, 1)
     cfg = dict(O.DEFAULT_CFG, channels=channels, num_blocks=stages)
     sd = O.init_params(cfg, seed=31)
     x, label = O.synthetic_batch(B, channels, H, W, 5, seed=32, dense=dense)
@@ -264,7 +265,7 @@ def test_baseline_configs_full_size_vs_oracle(tag, channels, stages, H, W, dense
     loss = eng.step(x.cuda(), label.cuda())
     assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
     assert abs(float(eng.grad_norm) - gn_ref) < 2e-3 * gn_ref
-    if tag == "odd-sizes":
+    if tag in ("odd-sizes", "batch-11"):
         # every parameter gradient, not just the norm
         gmax = max(float(p.grad.abs().max()) for p in leaves.values() if p.grad is not None)
         for k, off in m._poff.items():
