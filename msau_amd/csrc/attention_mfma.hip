@@ -161,31 +161,50 @@ __device__ __forceinline__ void attn_sweep_body(const bf16_t* __restrict__ f, co
     const int zoff = CHUNK * RB + 32;                             // zero slot inside vs
     if (tid < 2) *reinterpret_cast<bf16x8*>(vs + CHUNK * RB + tid * 16 + 16) = zero8<bf16_t>();
 
-    for (int r0 = 0; r0 < N; r0 += CHUNK) {
-        __syncthreads();
-        // ---- stage CHUNK sweep rows (zeros beyond N)
-        for (int idx = tid; idx < CHUNK * (DS / 8); idx += 256) {
-            int r = idx / (DS / 8), c = idx % (DS / 8);
-            bf16x8 v = zero8<bf16_t>();
-            if (r0 + r < N) v = load8<bf16_t>(sweep_v + ((size_t)b * N + r0 + r) * DS + c * 8);
-            *reinterpret_cast<bf16x8*>(vs + r * RB + c * 16) = v;
+    // ---- sweep-side staging with a one-chunk register prefetch: the global loads of chunk k+1 are in flight while
+    // chunk k is consumed (the sweeps are latency-bound: 11 chunks, each one load round trip otherwise)
+    constexpr int NV = (CHUNK * (DS / 8) + 255) / 256, NTT = (CHUNK * (CS / 8) + 255) / 256;
+    bf16x8 pv[NV], ptn[NTT];
+    float pm = 0.f, piz = 0.f, pdl = 0.f;
+    auto issue = [&](int r0) {
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int idx = tid + it * 256, r = idx / (DS / 8), c = idx % (DS / 8);
+            pv[it] = zero8<bf16_t>();
+            if (idx < CHUNK * (DS / 8) && r0 + r < N) pv[it] = load8<bf16_t>(sweep_v + ((size_t)b * N + r0 + r) * DS + c * 8);
         }
-        for (int idx = tid; idx < CHUNK * (CS / 8); idx += 256) {
-            int r = idx / (CS / 8), c = idx % (CS / 8);
-            bf16x8 v = zero8<bf16_t>();
-            if (r0 + r < N) v = load8<bf16_t>(sweep_t + ((size_t)b * N + r0 + r) * CS + c * 8);
-            *reinterpret_cast<bf16x8*>(ts + r * TS + c * 16) = v;
+#pragma unroll
+        for (int it = 0; it < NTT; ++it) {
+            const int idx = tid + it * 256, r = idx / (CS / 8), c = idx % (CS / 8);
+            ptn[it] = zero8<bf16_t>();
+            if (idx < CHUNK * (CS / 8) && r0 + r < N) ptn[it] = load8<bf16_t>(sweep_t + ((size_t)b * N + r0 + r) * CS + c * 8);
         }
         if (!OWN_I && tid < CHUNK) {
-            float m = 0.f, iz = 0.f, dl = 0.f;
+            pm = 0.f; piz = 0.f; pdl = 0.f;
             if (r0 + tid < N) {
-                size_t qq = (size_t)b * N + r0 + tid;
-                m = stats[qq * 2] * LOG2E; iz = 1.f / stats[qq * 2 + 1];
-                if (MODE == M_DF) dl = delta[qq];
+                const size_t qq = (size_t)b * N + r0 + tid;
+                pm = stats[qq * 2] * LOG2E; piz = 1.f / stats[qq * 2 + 1];
+                if (MODE == M_DF) pdl = delta[qq];
             }
-            st_m[tid] = m; st_z[tid] = iz; st_d[tid] = dl;
         }
+    };
+    issue(0);
+
+    for (int r0 = 0; r0 < N; r0 += CHUNK) {
+        __syncthreads();                                          // the previous chunk has been consumed
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int idx = tid + it * 256, r = idx / (DS / 8), c = idx % (DS / 8);
+            if (idx < CHUNK * (DS / 8)) *reinterpret_cast<bf16x8*>(vs + r * RB + c * 16) = pv[it];
+        }
+#pragma unroll
+        for (int it = 0; it < NTT; ++it) {
+            const int idx = tid + it * 256, r = idx / (CS / 8), c = idx % (CS / 8);
+            if (idx < CHUNK * (CS / 8)) *reinterpret_cast<bf16x8*>(ts + r * TS + c * 16) = ptn[it];
+        }
+        if (!OWN_I && tid < CHUNK) { st_m[tid] = pm; st_z[tid] = piz; st_d[tid] = pdl; }
         __syncthreads();
+        if (r0 + CHUNK < N) issue(r0 + CHUNK);
 
         const int nstep = min(CHUNK, ((N - r0 + 31) / 32) * 32) / 32;
         for (int st = 0; st < nstep; ++st) {
