@@ -37,6 +37,11 @@ typedef enum {
 
 const char* msau_last_error(void);
 int msau_version(void);
+/* sizeof() of the structs below as the library was compiled, for bindings that mirror them (a mirror that is too short
+ * makes the library read past it): which = 0 msau_conv_desc, 1 msau_wgrad_desc, 2 msau_pack_entry, 3 msau_unpack_entry,
+ * 4 msau_op, 5 msau_lrn_args, 6 msau_pool_args, 7 msau_attn_args, 8 msau_csum_args, 9 msau_reduce_args,
+ * 10 msau_conv_pack_geom, 11 msau_wgrad_geom, 12 msau_conv_pair_desc; -1 for anything else. */
+int msau_sizeof(int which);
 
 /* ------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution, used for: SAME conv 3x3 / dilated 3x3 / 1x1 / 4x4 forward
@@ -121,6 +126,37 @@ int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d);
  * info[6] = 1 if a compile-time-specialised "lean" instance (conv_lean.hip) takes the launch,
  * info[7] = bit 0: that instance implements MSAU_CONV_HEAD for this descriptor, bit 1: MSAU_CONV_DOUT */
 int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info8);
+
+/* ------------------------------------------------------------------------------------------
+ * Two chained 3x3 SAME convolutions C -> C -> C (C stored channels in {8, 16, 32}) in one launch: the residual block
+ * of model/model.py:37-50 with res_depth 2 (forward) and its two data gradients (backward).  The intermediate tensor
+ * `mid` is written once and consumed from LDS, never re-read from HBM.
+ *   t   = W1 * in(x) + b1            in(x) = max(x, 0) if MSAU_PAIR_RELU_IN else x ;  b1 may be NULL
+ *   t   = max(t, 0)                  if MSAU_PAIR_RELU_MID      (forward: the first conv's ReLU)
+ *   t  *= (mask_mid > 0)             if MSAU_PAIR_MASK_MID      (backward: through that ReLU)
+ *   mid = t                          ([B][H][W][C], zero outside the image: the second conv's SAME padding)
+ *   y   = epilogue(W2 * mid + b2)    flags2 = MSAU_CONV_{MASK_A, ADD, ACCUM, RELU_OUT, MASK_B} exactly as msau_conv2d
+ * w1 / w2 are the packed images msau_pack_params writes for a single-source 3x3 conv C -> C (forward or flipped
+ * data-gradient image).  msau_conv_pair_applicable: 1 if an instance exists for the shape (C, enough tiles, LDS).
+ * ------------------------------------------------------------------------------------------ */
+enum { MSAU_PAIR_RELU_IN = 1, MSAU_PAIR_RELU_MID = 2, MSAU_PAIR_MASK_MID = 4 };
+typedef struct {
+    int32_t B, H, W, C;
+    int32_t flags1, flags2;
+    const void* x;
+    const void* w1;
+    const float* b1;
+    const void* mask_mid;
+    void* mid;
+    const void* w2;
+    const float* b2;
+    const void* add;
+    const void* mask_a;
+    const void* mask_b;
+    void* y;
+} msau_conv_pair_desc;
+int msau_conv_pair_applicable(int dtype, const msau_conv_pair_desc* d);
+int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc* d);
 
 /* ------------------------------------------------------------------------------------------
  * Weight / bias gradient of the same convolution (autograd of torch.nn.Conv2d reached from
@@ -291,6 +327,10 @@ int msau_raster_owner(void* stream, const int32_t* boxes, int n, int32_t* owner,
 int msau_raster_onehot(void* stream, int dtype, const int32_t* boxes, const int32_t* owner, void* grid_nhwc,
                        int B, int H, int W, int C, int Cs);
 int msau_raster_labels(void* stream, const int32_t* boxes, const int32_t* owner, int64_t* labels, int B, int H, int W);
+/* BERT-embedding chargrid (data_generator_funsd_bert.py:64-93 get_box_mask_box_label, :240): the owning box's feature
+ * vector feats[value][0..C) (fp32 [n_vectors][C], device) at every covered pixel, zeros elsewhere. */
+int msau_raster_dense(void* stream, int dtype, const int32_t* boxes, const int32_t* owner, const float* feats,
+                      void* grid_nhwc, int B, int H, int W, int C, int Cs);
 
 /* ------------------------------------------------------------------------------------------
  * Launch-sequence executor: one call enqueues a whole pre-built list of the launches above (the static
@@ -308,7 +348,8 @@ enum {
     MSAU_OP_ATTN_FWD = 7,    /* args: msau_attn_args          */
     MSAU_OP_ATTN_BWD = 8,    /* args: msau_attn_args          */
     MSAU_OP_CHANNEL_SUM = 9, /* args: msau_csum_args          */
-    MSAU_OP_WGRAD_REDUCE = 10 /* args: msau_reduce_args       */
+    MSAU_OP_WGRAD_REDUCE = 10, /* args: msau_reduce_args      */
+    MSAU_OP_CONV_PAIR = 11   /* args: msau_conv_pair_desc     */
 };
 typedef struct { int32_t kind; int32_t dtype; const void* args; } msau_op;
 typedef struct { const void* a; const void* dy; void* out; int64_t npix; int32_t C, Cs, n; float alpha, beta, k; } msau_lrn_args;

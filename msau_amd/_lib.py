@@ -25,6 +25,14 @@ class ConvDesc(C.Structure):
                [("head_classes", i32), ("flags2", i32), ("y2", vp), ("mask_b2", vp)]
 
 
+class ConvPairDesc(C.Structure):
+    _fields_ = [(n, i32) for n in ("B", "H", "W", "C", "flags1", "flags2")] + \
+               [(n, vp) for n in ("x", "w1", "b1", "mask_mid", "mid", "w2", "b2", "add", "mask_a", "mask_b", "y")]
+
+
+PAIR_RELU_IN, PAIR_RELU_MID, PAIR_MASK_MID = 1, 2, 4
+
+
 class ConvPackGeom(C.Structure):
     _fields_ = [("cch", i32), ("nchunks", i32), ("kchunk", i32), ("rows", i32), ("bytes", i64)]
 
@@ -85,14 +93,18 @@ OP_SIDE = 0x100
 OP_PROBE = 0x200
 OP_JOIN = 0x800
 OP_WGRAD_REDUCE = 10
+OP_CONV_PAIR = 11
 OP_CONV2D, OP_WGRAD, OP_LRN_FWD, OP_LRN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_CHANNEL_SUM = range(1, 10)
 
 _SIGNATURES = {
     "msau_last_error": (C.c_char_p, []),
     "msau_version": (C.c_int, []),
+    "msau_sizeof": (C.c_int, [C.c_int]),
     "msau_conv_pack_geometry": (C.c_int, [C.c_int] * 9 + [C.POINTER(ConvPackGeom)]),
     "msau_conv2d": (C.c_int, [vp, C.c_int, C.POINTER(ConvDesc)]),
     "msau_conv2d_launch_info": (C.c_int, [C.c_int, C.POINTER(ConvDesc), C.POINTER(i32)]),
+    "msau_conv_pair_applicable": (C.c_int, [C.c_int, C.POINTER(ConvPairDesc)]),
+    "msau_conv_pair": (C.c_int, [vp, C.c_int, C.POINTER(ConvPairDesc)]),
     "msau_wgrad_geometry": (C.c_int, [C.c_int, C.POINTER(WgradDesc), C.POINTER(WgradGeom)]),
     "msau_conv2d_wgrad": (C.c_int, [vp, C.c_int, C.POINTER(WgradDesc)]),
     "msau_pack_params": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int]),
@@ -118,6 +130,7 @@ _SIGNATURES = {
     "msau_raster_owner": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
     "msau_raster_onehot": (C.c_int, [vp, C.c_int, vp, vp, vp] + [C.c_int] * 5),
     "msau_raster_labels": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
+    "msau_raster_dense": (C.c_int, [vp, C.c_int, vp, vp, vp, vp] + [C.c_int] * 5),
     "msau_run_ops": (C.c_int, [vp, C.POINTER(Op), C.c_int]),
     "msau_run_ops_overlap": (C.c_int, [vp, vp, C.POINTER(Op), C.c_int, C.c_int]),
     "msau_spin": (C.c_int, [vp, C.c_int]),
@@ -130,6 +143,10 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+# ctypes mirrors in the order of msau_sizeof(which): load() refuses a library whose structs have another size
+ABI_STRUCTS = (ConvDesc, WgradDesc, PackEntry, UnpackEntry, Op, LrnArgs, PoolArgs, AttnArgs, CsumArgs, ReduceArgs,
+               ConvPackGeom, WgradGeom, ConvPairDesc)
 
 
 class MsauHipError(RuntimeError):
@@ -152,6 +169,10 @@ def load():
         fn = getattr(lib, name)            # AttributeError if the ABI and this table disagree
         fn.restype = res
         fn.argtypes = args
+    for which, st in enumerate(ABI_STRUCTS):
+        if lib.msau_sizeof(which) != C.sizeof(st):
+            raise MsauHipError(f"{LIB_PATH}: sizeof({st.__name__}) is {lib.msau_sizeof(which)} in the library, "
+                               f"{C.sizeof(st)} in msau_amd/_lib.py -- rebuild (python -m msau_amd.build)")
     _lib = lib
     return lib
 

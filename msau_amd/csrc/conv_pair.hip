@@ -1,0 +1,395 @@
+// Two chained 3x3 SAME convolutions C -> C -> C in ONE launch, the intermediate tensor never re-read from HBM:
+//   forward : MultiConvResidualBlock with res_depth 2 (model/model.py:37-50)
+//                 mid = ReLU(W1 * ReLU(x) + b1) ;  y = ReLU(W2 * mid + b2 + x)
+//   backward: its two data gradients
+//                 mid = (W2^T * g) . [r1 > 0]   ;  y = (W1^T * mid) . [x0 > 0] + g
+// `mid` is still written once (the weight gradients and the ReLU mask of the backward need it), but the second conv
+// reads it from LDS: per pair of launches 5 tensor passes (forward) / 7 (backward) become 3 / 5, and one dependent
+// launch disappears.
+//
+// Tiling: a workgroup owns a 14 x (16*TW - 2) output tile.  The intermediate is computed on the 16 x 16*TW lattice
+// around it (one pixel of halo, recomputed by the neighbouring tiles with the same arithmetic -> bit-identical), from
+// an 18 x (16*TW + 2) input tile; both phases use the MFMA mapping of conv_lean.hip (channels on rows, 16 pixels of a
+// row on columns, a wave owns 4 rows), the same packed weight images and the same epilogue arithmetic.  Intermediate
+// positions outside the image are forced to 0: that is the SAME zero padding the second conv must see.
+//
+// Every global LOAD of a tile is issued at ONE point (the register prefetch of the next tile): the input tile and, in
+// the backward, the two ReLU-mask tiles, which are squeezed to one bit per element in LDS.  The residual / other-path
+// operand (MSAU_CONV_ADD) is the input tensor itself and is read back from the LDS tile.  Why: vmcnt retires in order,
+// so a wait for an operand loaded inside an epilogue also drains the prefetch issued before it.  The first version
+// loaded masks and the residual in the epilogues and ran at 8 us per tile -- slower than the two launches it replaced.
+#include "msau_common.h"
+#include <cstdlib>
+
+namespace {
+
+struct PairArgs {
+    msau_conv_pair_desc d;
+    int kchunk;                                  // packed K elements per weight row (both convs)
+    int px, row;                                 // bytes per pixel / per image row
+    int tiles_x, tiles_y, ntiles;
+    unsigned mag_tx, mag_ty;
+    int per_xcd;
+};
+
+template <typename T, int C8, int TW, bool BWD>
+struct PairCfg {
+    static constexpr int ESZ = (int)sizeof(T);
+    static constexpr int C = C8 * 8;
+    static constexpr int CT = (C8 + 1) / 2;                   // 16-row output-channel tiles
+    static constexpr int IW = 16 * TW;                        // intermediate lattice: 16 x IW
+    static constexpr int OH = 14, OW = IW - 2;                // output tile
+    static constexpr int XH = 18, XW = IW + 2;                // input tile; the intermediate tile is allocated alike
+    static constexpr int NT = 256 * TW;
+    static constexpr int PSRAW = C * ESZ;
+    static constexpr int PS = ((PSRAW / 16) % 2 == 0) ? PSRAW + 16 : PSRAW;
+    static constexpr int NPIX = XH * XW;
+    static constexpr int NG = 9 * C8;                         // real 8-channel k-groups
+    static constexpr int NKS = (NG + 3) / 4;                  // MFMA k-steps of 32
+    static constexpr int WS = NKS * 32 * ESZ + 16;
+    static constexpr int W_BYTES = CT * 16 * WS;              // one conv's weights in LDS
+    static constexpr int X_BYTES = ((NPIX * PS + 15) / 16) * 16;
+    static constexpr int M_BYTES = BWD ? 16 * IW * C8 : 0;    // one mask tile: a byte per (lattice pixel, 8-channel group)
+    static constexpr int OFF_W = 2 * X_BYTES;
+    static constexpr int OFF_M = OFF_W + 2 * W_BYTES;
+    static constexpr int OFF_B = OFF_M + 2 * M_BYTES;
+    static constexpr int LDS = OFF_B + 2 * C * 4;
+    static constexpr int NITX = (NPIX * C8 + NT - 1) / NT;    // prefetch registers (16 B each): input tile
+    static constexpr int NITM = BWD ? (16 * IW * C8) / NT : 0;                 //                 each mask tile
+};
+
+template <typename T> __device__ __forceinline__ unsigned positive_bits(typename Vec8<T>::type v) {
+    unsigned b = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b |= ((float)v[e] > 0.f ? 1u : 0u) << e;
+    return b;
+}
+
+template <typename T, int C8, int TW, bool BWD>
+__global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
+    using Cfg = PairCfg<T, C8, TW, BWD>;
+    typedef typename Vec8<T>::type V8;
+    typedef typename Vec4<T>::type V4;
+    constexpr int ESZ = Cfg::ESZ, XW = Cfg::XW, IW = Cfg::IW, PS = Cfg::PS, NKS = Cfg::NKS, NG = Cfg::NG, CT = Cfg::CT, NT = Cfg::NT;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* xt = smem;
+    unsigned char* rt = smem + Cfg::X_BYTES;
+    unsigned char* mt = smem + Cfg::OFF_M;                          // [16][IW][C8] bits of mask_mid at the lattice
+    unsigned char* at = smem + Cfg::OFF_M + Cfg::M_BYTES;           // [16][IW][C8] bits of mask_a at the output tile
+    float* lbias = reinterpret_cast<float*>(smem + Cfg::OFF_B);
+    const msau_conv_pair_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all & 3, cwt = wave_all >> 2;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int H = d.H, W = d.W;
+
+    // ---- weights and biases of both convs: LDS, once per persistent workgroup
+    {
+        constexpr int WG8 = NKS * 4;
+        for (int idx = tid; idx < 2 * CT * 16 * WG8; idx += NT) {
+            const int which = idx / (CT * 16 * WG8), rem = idx - which * (CT * 16 * WG8);
+            const int r = rem / WG8, g8 = rem - r * WG8;
+            const T* wp = static_cast<const T*>(which ? d.w2 : d.w1);
+            *reinterpret_cast<V8*>(smem + Cfg::OFF_W + which * Cfg::W_BYTES + r * Cfg::WS + g8 * 8 * ESZ) =
+                load8<T>(wp + (size_t)r * a.kchunk + g8 * 8);
+        }
+        for (int c = tid; c < 2 * Cfg::C; c += NT) {
+            const float* src = c < Cfg::C ? d.b1 : d.b2;
+            lbias[c] = src ? src[c < Cfg::C ? c : c - Cfg::C] : 0.f;
+        }
+    }
+
+    int koff[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int G = ks * 4 + lg;
+        const int tap = G / C8, cg = G - tap * C8;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        koff[ks] = G < NG ? (ky * XW + kx) * PS + cg * 8 * ESZ : 0;
+    }
+    const int pix_off = ((wave * 4) * XW + cwt * 16 + lr) * PS;      // lattice (wave*4 + pt, cwt*16 + lr), pt adds XW*PS
+    const int ch0 = lg * (CT * 4);                                  // this lane's first channel (ct adds 4)
+    const bool ch_ok = C8 > 1 || lg < 2;                            // 8-channel layers fill half of the 16 MFMA rows
+    const int lane_c = (cwt * 16 + lr) * a.px + ch0 * ESZ;          // per-lane part of the global epilogue addresses
+
+    V8 pre_x[Cfg::NITX];
+    V8 pre_m[BWD ? Cfg::NITM : 1], pre_a[BWD ? Cfg::NITM : 1];
+    auto decode = [&](int tile, int& b, int& ty0, int& tx0) {
+        const int t1 = a.tiles_x > 1 ? __umulhi((unsigned)tile, a.mag_tx) : tile;
+        tx0 = (tile - t1 * a.tiles_x) * Cfg::OW;
+        b = a.tiles_y > 1 ? __umulhi((unsigned)t1, a.mag_ty) : t1;
+        ty0 = (t1 - b * a.tiles_y) * Cfg::OH;
+    };
+    auto issue_loads = [&](int tile) {
+        int b, ty0, tx0;
+        decode(tile, b, ty0, tx0);
+        const long long img = (long long)b * H * a.row;
+        const char* base = static_cast<const char*>(d.x) + img;
+        constexpr int NITEMS = Cfg::NPIX * C8;
+#pragma unroll
+        for (int it = 0; it < Cfg::NITX; ++it) {
+            const int idx = tid + it * NT;
+            pre_x[it] = zero8<T>();
+            if ((it + 1) * NT <= NITEMS || idx < NITEMS) {
+                const int pix = idx / C8, cg = idx - pix * C8;
+                const int iy = pix / XW, ix = pix - iy * XW;
+                const int vy = ty0 - 2 + iy, vx = tx0 - 2 + ix;
+                if ((unsigned)vy < (unsigned)H && (unsigned)vx < (unsigned)W)
+                    pre_x[it] = *reinterpret_cast<const V8*>(base + (unsigned)(vy * a.row + vx * a.px + cg * 8 * ESZ));
+            }
+        }
+        if constexpr (BWD) {
+            const char* mb = static_cast<const char*>(d.mask_mid) + img;
+            const char* ab = static_cast<const char*>(d.mask_a) + img;
+#pragma unroll
+            for (int it = 0; it < Cfg::NITM; ++it) {
+                const int idx = tid + it * NT;
+                const int pix = idx / C8, cg = idx - pix * C8;
+                const int iy = pix / IW, ix = pix - iy * IW;
+                pre_m[it] = zero8<T>();
+                pre_a[it] = zero8<T>();
+                const int my = ty0 - 1 + iy, mx = tx0 - 1 + ix;      // lattice position
+                if ((unsigned)my < (unsigned)H && (unsigned)mx < (unsigned)W)
+                    pre_m[it] = *reinterpret_cast<const V8*>(mb + (unsigned)(my * a.row + mx * a.px + cg * 8 * ESZ));
+                const int ay = ty0 + iy, ax = tx0 + ix;              // output position
+                if (ay < H && ax < W)
+                    pre_a[it] = *reinterpret_cast<const V8*>(ab + (unsigned)(ay * a.row + ax * a.px + cg * 8 * ESZ));
+            }
+        }
+    };
+    int tile0 = blockIdx.x, tend = a.ntiles, tstep = gridDim.x;
+    if (a.per_xcd) {
+        const int xcd = blockIdx.x & 7;
+        tile0 = xcd * a.per_xcd + (blockIdx.x >> 3);
+        tend = min(a.ntiles, (xcd + 1) * a.per_xcd);
+        tstep = gridDim.x >> 3;
+    }
+    if (tile0 < tend) issue_loads(tile0);
+
+    for (int tile = tile0; tile < tend; tile += tstep) {
+        int b, ty0, tx0;
+        decode(tile, b, ty0, tx0);
+        __syncthreads();                                       // previous tile's reads of the LDS tiles are done
+        {
+            constexpr int NITEMS = Cfg::NPIX * C8;
+#pragma unroll
+            for (int it = 0; it < Cfg::NITX; ++it) {
+                const int idx = tid + it * NT;
+                if ((it + 1) * NT <= NITEMS || idx < NITEMS) {
+                    const int pix = idx / C8, cg = idx - pix * C8;
+                    *reinterpret_cast<V8*>(xt + pix * PS + cg * 8 * ESZ) = pre_x[it];     // raw: ReLU at the fragment read
+                }
+            }
+            if constexpr (BWD) {
+#pragma unroll
+                for (int it = 0; it < Cfg::NITM; ++it) {
+                    const int idx = tid + it * NT;
+                    mt[idx] = (unsigned char)positive_bits<T>(pre_m[it]);
+                    at[idx] = (unsigned char)positive_bits<T>(pre_a[it]);
+                }
+            }
+        }
+        __syncthreads();
+        if (tile + tstep < tend) issue_loads(tile + tstep);
+
+        const long long img = (long long)b * H * a.row;
+        // ================= phase 1: intermediate on the 16 x IW lattice, image position (ty0-1+i, tx0-1+j) ===========
+        {
+            f32x4 acc[CT][4];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const unsigned char* p = xt + pix_off + koff[ks];
+                V8 bfrag[4];
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) {
+                    bfrag[pt] = *reinterpret_cast<const V8*>(p + pt * XW * PS);
+                    if constexpr (!BWD) bfrag[pt] = relu8<T>(bfrag[pt]);         // MSAU_PAIR_RELU_IN
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const V8 af = *reinterpret_cast<const V8*>(smem + Cfg::OFF_W + (ct * 16 + lr) * Cfg::WS + (ks * 32 + lg * 8) * ESZ);
+#pragma unroll
+                    for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = mma8(af, bfrag[pt], acc[ct][pt]);
+                }
+            }
+            if (ch_ok) {
+                const int j = cwt * 16 + lr;
+                const int xx = tx0 - 1 + j;
+                const bool colin = (unsigned)xx < (unsigned)W;
+                const bool colown = j >= 1 && j <= Cfg::OW;
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) {
+                    const int i = wave * 4 + pt;                 // wave-uniform
+                    const int yy = ty0 - 1 + i;
+                    const bool inimg = colin && (unsigned)yy < (unsigned)H;
+                    char* orow = static_cast<char*>(d.mid) + img + (long long)yy * a.row + (long long)(tx0 - 1) * a.px;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        f32x4 v = acc[ct][pt];
+                        if constexpr (!BWD) {
+                            v += *reinterpret_cast<const f32x4*>(lbias + ch0 + ct * 4);
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) v[jj] = fmaxf(v[jj], 0.f);        // MSAU_PAIR_RELU_MID
+                        } else {
+                            const unsigned bits = mt[(i * IW + j) * C8 + ((ch0 + ct * 4) >> 3)] >> ((ch0 + ct * 4) & 7);
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) v[jj] = (bits >> jj) & 1u ? v[jj] : 0.f;   // MSAU_PAIR_MASK_MID
+                        }
+                        V4 o;
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) o[jj] = (T)(inimg ? v[jj] : 0.f);
+                        *reinterpret_cast<V4*>(rt + (i * XW + j) * PS + (ch0 + ct * 4) * ESZ) = o;
+                        if (inimg && colown && i >= 1 && i <= Cfg::OH)
+                            *reinterpret_cast<V4*>(orow + (unsigned)(lane_c + ct * 4 * ESZ)) = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ================= phase 2: output tile, image position (ty0+oy, tx0+ox), reads the intermediate from LDS ====
+        {
+            f32x4 acc[CT][4];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const unsigned char* p = rt + pix_off + koff[ks];
+                V8 bfrag[4];
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) bfrag[pt] = *reinterpret_cast<const V8*>(p + pt * XW * PS);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const V8 af = *reinterpret_cast<const V8*>(smem + Cfg::OFF_W + Cfg::W_BYTES + (ct * 16 + lr) * Cfg::WS + (ks * 32 + lg * 8) * ESZ);
+#pragma unroll
+                    for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = mma8(af, bfrag[pt], acc[ct][pt]);
+                }
+            }
+            const int ox = cwt * 16 + lr;
+            if (ch_ok && ox < Cfg::OW && tx0 + ox < W) {
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) {
+                    const int oy = wave * 4 + pt;                // wave-uniform
+                    const int yy = ty0 + oy;
+                    if (oy < Cfg::OH && yy < H) {
+                        char* yrow = static_cast<char*>(d.y) + img + (long long)yy * a.row + (long long)tx0 * a.px;
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) {
+                            // the residual (forward) / other-path gradient (backward) operand is the input tensor itself:
+                            // read it back from the raw LDS input tile, position (oy + 2, ox + 2)
+                            const V4 r = *reinterpret_cast<const V4*>(xt + ((oy + 2) * XW + ox + 2) * PS + (ch0 + ct * 4) * ESZ);
+                            f32x4 v = acc[ct][pt];
+                            if constexpr (!BWD) {
+                                v += *reinterpret_cast<const f32x4*>(lbias + Cfg::C + ch0 + ct * 4);
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj) v[jj] = fmaxf(v[jj] + (float)r[jj], 0.f);      // ADD, RELU_OUT
+                            } else {
+                                const unsigned bits = at[(oy * IW + ox) * C8 + ((ch0 + ct * 4) >> 3)] >> ((ch0 + ct * 4) & 7);
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj) v[jj] = ((bits >> jj) & 1u ? v[jj] : 0.f) + (float)r[jj];   // MASK_A, ADD
+                            }
+                            V4 ov;
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) ov[jj] = (T)v[jj];
+                            *reinterpret_cast<V4*>(yrow + (unsigned)(lane_c + ct * 4 * ESZ)) = ov;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int C8, int TW, bool BWD>
+int launch_pair(hipStream_t s, const PairArgs& a0) {
+    using Cfg = PairCfg<T, C8, TW, BWD>;
+    static_assert(Cfg::LDS + 256 <= MSAU_LDS_LIMIT, "conv_pair instance does not fit the LDS");
+    PairArgs a = a0;
+    a.tiles_x = cdiv(a.d.W, Cfg::OW);
+    a.tiles_y = cdiv(a.d.H, Cfg::OH);
+    a.ntiles = a.d.B * a.tiles_x * a.tiles_y;
+    a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
+    a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
+    static bool attr_set = false;
+    if (!attr_set && Cfg::LDS > 60 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
+        if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_pair: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    int per_cu = MSAU_LDS_LIMIT / (Cfg::LDS + 256);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 8 / TW ? 8 / TW : per_cu);
+    int grid = 256 * per_cu;
+    if (grid > a.ntiles) grid = a.ntiles;
+    static const bool xcd_off = std::getenv("MSAU_XCD") && std::getenv("MSAU_XCD")[0] == '0';
+    a.per_xcd = 0;
+    if (!xcd_off && grid >= 64) {
+        grid &= ~7;
+        a.per_xcd = cdiv(a.ntiles, 8);
+    }
+    hipLaunchKernelGGL((conv_pair_kernel<T, C8, TW, BWD>), dim3(grid), dim3(256 * TW), Cfg::LDS, s, a);
+    MSAU_CHECK_LAUNCH("conv_pair_kernel");
+    return 0;
+}
+
+// tile width: 30-pixel tiles (512 threads) for wide images, 14-pixel tiles otherwise (less padding waste, more tiles)
+int pair_tw(int dtype, const msau_conv_pair_desc* d) {
+    const int c8 = d->C / 8;
+    if (c8 == 4 || (dtype == MSAU_F32 && c8 == 2)) return 1;     // LDS: the wide tile does not fit
+    static const int force = std::getenv("MSAU_PAIR_TW") ? atoi(std::getenv("MSAU_PAIR_TW")) : 0;
+    if (force == 1 || force == 2) return force;
+    return d->W >= 120 ? 2 : 1;
+}
+
+// the two flag combinations the kernel is compiled for: the residual block's forward, and its data gradient
+constexpr int kFwd1 = MSAU_PAIR_RELU_IN | MSAU_PAIR_RELU_MID, kFwd2 = MSAU_CONV_ADD | MSAU_CONV_RELU_OUT;
+constexpr int kBwd1 = MSAU_PAIR_MASK_MID, kBwd2 = MSAU_CONV_MASK_A | MSAU_CONV_ADD;
+
+}  // namespace
+
+extern "C" int msau_conv_pair_applicable(int dtype, const msau_conv_pair_desc* d) {
+    if (!d || (dtype != MSAU_F32 && dtype != MSAU_BF16)) return 0;
+    static const int maxc = std::getenv("MSAU_PAIR_MAXC") ? atoi(std::getenv("MSAU_PAIR_MAXC")) : 16;   // measured: C = 32 (84x64 images) gains nothing, 4.03 vs 4.00 ms/step
+    if ((d->C != 8 && d->C != 16 && d->C != 32) || d->C > maxc) return 0;
+    if (dtype == MSAU_F32 && d->C == 32) return 0;                 // two fp32 tiles + two weight sets exceed the LDS
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0) return 0;
+    const bool fwd = d->flags1 == kFwd1 && d->flags2 == kFwd2, bwd = d->flags1 == kBwd1 && d->flags2 == kBwd2;
+    if (!fwd && !bwd) return 0;
+    if (d->add != d->x) return 0;                                  // the ADD operand is read back from the input tile
+    const int esz = dtype == MSAU_F32 ? 4 : 2;
+    if ((int64_t)d->H * d->W * d->C * esz >= (1ll << 31)) return 0;             // 32-bit lane offsets inside an image
+    const int tw = pair_tw(dtype, d);
+    const int64_t tiles = (int64_t)d->B * cdiv(d->H, 14) * cdiv(d->W, 16 * tw - 2);
+    if (tiles < 64 || tiles >= (1 << 20)) return 0;                            // small launches: the one-conv kernels
+    return 1;
+}
+
+extern "C" int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc* d) {
+    MSAU_CHECK_ARG(d && d->x && d->w1 && d->w2 && d->mid && d->y, "conv_pair: null pointer");
+    MSAU_CHECK_ARG(msau_conv_pair_applicable(dtype, d), "conv_pair: unsupported shape or flags (C %d, %dx%d, B %d, flags 0x%x / 0x%x; "
+                   "MSAU_CONV_ADD must name the input tensor)", d->C, d->H, d->W, d->B, d->flags1, d->flags2);
+    const bool bwd = d->flags1 == kBwd1;
+    MSAU_CHECK_ARG(!bwd || (d->mask_mid && d->mask_a), "conv_pair: backward without mask_mid / mask_a");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int esz = dtype == MSAU_F32 ? 4 : 2;
+    PairArgs a;
+    a.d = *d;
+    a.kchunk = roundup(9 * d->C, 32);
+    a.px = d->C * esz;
+    a.row = d->W * a.px;
+    const int c8 = d->C / 8, tw = pair_tw(dtype, d);
+#define PAIR_CASE(T, C8V, TWV) if (c8 == C8V && tw == TWV) return bwd ? launch_pair<T, C8V, TWV, true>(s, a) : launch_pair<T, C8V, TWV, false>(s, a);
+    if (dtype == MSAU_BF16) {
+        PAIR_CASE(bf16_t, 1, 1) PAIR_CASE(bf16_t, 1, 2) PAIR_CASE(bf16_t, 2, 1) PAIR_CASE(bf16_t, 2, 2) PAIR_CASE(bf16_t, 4, 1)
+    } else {
+        PAIR_CASE(float, 1, 1) PAIR_CASE(float, 1, 2) PAIR_CASE(float, 2, 1)
+    }
+#undef PAIR_CASE
+    return msau_set_error(MSAU_ERR_ARG, "conv_pair: no instance for C %d tile width %d", d->C, tw);
+}

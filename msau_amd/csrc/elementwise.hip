@@ -154,9 +154,17 @@ __global__ void lrn_fast_kernel(const T* __restrict__ a, const T* __restrict__ d
                 win[j] = (l < G / 2) ? Xo : tot - Xo;
             }
         }
-        float d[8], dnb[8];
+        // d^-beta and (backward) 1/d without an IEEE division: v_div_scale / v_div_fmas are VCC-dependent multi-instruction
+        // sequences; rsq / rcp are single transcendental ops (d >= k = 1, so no range problems)
+        float dnb[8], invd[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { d[j] = k + alpha_over_n * win[j]; dnb[j] = pow_neg_beta(d[j], beta, beta075); }
+        for (int j = 0; j < 8; ++j) {
+            const float d = k + alpha_over_n * win[j];
+            // raw v_rsq_f32 / v_sqrt_f32 (1 ulp each, d >= k > 0: no denormal or range fix-ups needed) instead of the
+            // library forms, whose correction sequences are a dozen VCC-dependent instructions per call
+            if (beta075) { const float r = __builtin_amdgcn_rsqf(d); dnb[j] = r * __builtin_amdgcn_sqrtf(r); invd[j] = r * r; }
+            else { dnb[j] = __expf(-beta * __logf(d)); invd[j] = __builtin_amdgcn_rcpf(d); }
+        }
         typename Vec8<T>::type ov;
         if constexpr (!BWD) {
 #pragma unroll
@@ -165,7 +173,7 @@ __global__ void lrn_fast_kernel(const T* __restrict__ a, const T* __restrict__ d
             typename Vec8<T>::type gv = load8<T>(dy + i * 8);
             float g[8], qv[8], adj[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { g[j] = (float)gv[j]; qv[j] = g[j] * x[j] * dnb[j] / d[j]; }
+            for (int j = 0; j < 8; ++j) { g[j] = (float)gv[j]; qv[j] = g[j] * x[j] * dnb[j] * invd[j]; }
             if constexpr (G == 1) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -336,13 +344,40 @@ __global__ void pool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restr
 // =============================================================================================
 // masked cross entropy (model/model.py:446-459), batch rule of SURVEY 8(e)
 // =============================================================================================
-__global__ void label_count_kernel(const int64_t* __restrict__ labels, int32_t* __restrict__ counts, int64_t hw) {
-    const int b = blockIdx.y;
+// One 1024-thread workgroup per sample, 16-byte loads (two labels), eight in flight per thread, no atomics and no
+// memset: counts[b] is written, not accumulated.  (The first version spread a sample over 64 workgroups and let every
+// wave atomicAdd into counts[b]: 4096 same-address atomics took 51 us for 11 MB of labels.)
+__global__ __launch_bounds__(1024) void label_count_kernel(const int64_t* __restrict__ labels, int32_t* __restrict__ counts, int64_t hw) {
+    __shared__ int red[16];
+    const int b = blockIdx.x;
+    const int64_t* base = labels + (int64_t)b * hw;
     int local = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (int64_t)gridDim.x * blockDim.x)
-        local += labels[(int64_t)b * hw + i] != 0;
+    typedef long long ll2 __attribute__((ext_vector_type(2)));
+    const int64_t npair = hw >> 1;                                   // base is 16-byte aligned when hw is even or b == 0
+    const bool aligned = ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+    if (aligned) {
+        const ll2* p2 = reinterpret_cast<const ll2*>(base);
+        int64_t i = threadIdx.x;
+        for (; i + 7 * 1024 < npair; i += 8 * 1024) {
+            ll2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p2[i + u * 1024];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) local += (v[u][0] > 0) + (v[u][1] > 0);
+        }
+        for (; i < npair; i += 1024) { ll2 v = p2[i]; local += (v[0] > 0) + (v[1] > 0); }
+        if ((hw & 1) && threadIdx.x == 0) local += base[hw - 1] > 0;
+    } else {
+        for (int64_t i = threadIdx.x; i < hw; i += 1024) local += base[i] > 0;
+    }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&counts[b], local);            // integer: order-independent
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        counts[b] = t;
+    }
 }
 
 template <typename T, bool ALL>
@@ -355,7 +390,7 @@ __global__ void masked_ce_kernel(const T* __restrict__ logits, const int64_t* __
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
         const int b = (int)(p / hw);
         const int64_t lab = labels[p];
-        const bool on = ALL ? (lab >= 0 && lab < C) : (lab != 0 && lab < C);
+        const bool on = ALL ? (lab >= 0 && lab < C) : (lab > 0 && lab < C);
         const float w = on ? (ALL ? scale : scale / (float)max(counts[b], 1)) : 0.f;
         float x[16];
         float mx = -INFINITY;
@@ -489,20 +524,20 @@ __global__ void masked_ce_multi_kernel(const T* __restrict__ l0, const T* __rest
     }
 }
 
-// one wave, fixed association order -> reproducible; overwrites out[0]
-__global__ void ordered_sum_set_kernel(const float* __restrict__ partials, int n, float* __restrict__ out) {
+// 256 threads, fixed association order (thread t adds elements t, t+256, ...; lanes, then waves, combine in index
+// order) -> reproducible.  SET overwrites out[0], otherwise out[0] += sum.
+template <bool SET>
+__global__ __launch_bounds__(256) void ordered_sum_kernel_t(const float* __restrict__ partials, int n, float* __restrict__ out) {
+    __shared__ float red[4];
     float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 64) s += partials[i];
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if (threadIdx.x == 0) out[0] = s;
-}
-
-__global__ void ordered_sum_kernel(const float* __restrict__ partials, int n, float* __restrict__ accum) {
-    // one wave, fixed association order -> reproducible
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 64) s += partials[i];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if (threadIdx.x == 0) *accum += s;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (red[0] + red[1]) + (red[2] + red[3]);
+        if (SET) out[0] = t; else out[0] += t;
+    }
 }
 
 // =============================================================================================
@@ -741,10 +776,7 @@ extern "C" int msau_maxpool2x2_bwd(void* stream, int dtype, const void* dy, cons
 extern "C" int msau_label_counts(void* stream, const int64_t* labels, int32_t* counts, int B, int64_t hw) {
     MSAU_CHECK_ARG(labels && counts && B > 0 && hw > 0, "label_counts: bad args");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * B, s);
-    if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "label_counts: memset: %s", hipGetErrorString(e));
-    int gx = grid_for(hw, 64);
-    hipLaunchKernelGGL(label_count_kernel, dim3(gx, B), dim3(kThreads), 0, s, labels, counts, hw);
+    hipLaunchKernelGGL(label_count_kernel, dim3(B), dim3(1024), 0, s, labels, counts, hw);
     MSAU_CHECK_LAUNCH("label_count");
     return 0;
 }
@@ -763,7 +795,7 @@ extern "C" int msau_masked_ce(void* stream, int dtype, const void* logits, const
                    hipLaunchKernelGGL((masked_ce_wide_kernel<float, false>), dim3(nb), dim3(kThreads), 0, s, static_cast<const float*>(logits), labels, counts, static_cast<float*>(dlogits), ws, B, hw, C, Cs, scale),
                    hipLaunchKernelGGL((masked_ce_wide_kernel<bf16_t, false>), dim3(nb), dim3(kThreads), 0, s, static_cast<const bf16_t*>(logits), labels, counts, static_cast<bf16_t*>(dlogits), ws, B, hw, C, Cs, scale));
         MSAU_CHECK_LAUNCH("masked_ce_wide");
-        hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(64), 0, s, ws, nb, loss_accum);
+        hipLaunchKernelGGL(ordered_sum_kernel_t<false>, dim3(1), dim3(256), 0, s, ws, nb, loss_accum);
         MSAU_CHECK_LAUNCH("ordered_sum");
         return 0;
     }
@@ -771,12 +803,13 @@ extern "C" int msau_masked_ce(void* stream, int dtype, const void* logits, const
                hipLaunchKernelGGL((masked_ce_kernel<float, false>), dim3(nb), dim3(kThreads), 0, s, static_cast<const float*>(logits), labels, counts, static_cast<float*>(dlogits), ws, B, hw, C, Cs, scale),
                hipLaunchKernelGGL((masked_ce_kernel<bf16_t, false>), dim3(nb), dim3(kThreads), 0, s, static_cast<const bf16_t*>(logits), labels, counts, static_cast<bf16_t*>(dlogits), ws, B, hw, C, Cs, scale));
     MSAU_CHECK_LAUNCH("masked_ce");
-    hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(64), 0, s, ws, nb, loss_accum);
+    hipLaunchKernelGGL(ordered_sum_kernel_t<false>, dim3(1), dim3(256), 0, s, ws, nb, loss_accum);
     MSAU_CHECK_LAUNCH("ordered_sum");
     return 0;
 }
 
-extern "C" int64_t msau_ce_multi_ws_floats(int64_t npix_total) { return grid_for(npix_total, 8192) + 1; }
+static int ce_multi_blocks(int64_t npix) { return grid_for(npix, 2048); }
+extern "C" int64_t msau_ce_multi_ws_floats(int64_t npix_total) { return ce_multi_blocks(npix_total) + 1; }
 
 extern "C" int msau_masked_ce_multi(void* stream, int dtype, const void* logits, const void* aux, const int64_t* labels,
                                     const int32_t* counts, void* dlogits, void* daux, float* loss, float* ws,
@@ -785,7 +818,7 @@ extern "C" int msau_masked_ce_multi(void* stream, int dtype, const void* logits,
     MSAU_CHECK_ARG(B > 0 && hw > 0 && C > 0 && C <= Cs && Cs % 8 == 0 && Cs <= 16 && (int64_t)B * hw < (1ll << 31),
                    "masked_ce_multi: bad dims (n_class <= 16, B*H*W < 2^31)");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int nb = grid_for((int64_t)B * hw, 8192);
+    const int nb = ce_multi_blocks((int64_t)B * hw);
 #define CE_MULTI(T, NL, C8) hipLaunchKernelGGL((masked_ce_multi_kernel<T, NL, C8>), dim3(nb), dim3(kThreads), 0, s, static_cast<const T*>(logits), \
         static_cast<const T*>(aux), labels, counts, static_cast<T*>(dlogits), static_cast<T*>(daux), ws, loss, B, (int)hw, C, scale)
     if (aux && Cs == 8) { DISPATCH_T(dtype, CE_MULTI(float, 2, 1), CE_MULTI(bf16_t, 2, 1)); }
@@ -794,7 +827,7 @@ extern "C" int msau_masked_ce_multi(void* stream, int dtype, const void* logits,
     else { DISPATCH_T(dtype, CE_MULTI(float, 1, 2), CE_MULTI(bf16_t, 1, 2)); }
 #undef CE_MULTI
     MSAU_CHECK_LAUNCH("masked_ce_multi");
-    hipLaunchKernelGGL(ordered_sum_set_kernel, dim3(1), dim3(64), 0, s, ws, nb, loss);
+    hipLaunchKernelGGL(ordered_sum_kernel_t<true>, dim3(1), dim3(256), 0, s, ws, nb, loss);
     MSAU_CHECK_LAUNCH("ordered_sum_set");
     return 0;
 }
@@ -810,7 +843,7 @@ extern "C" int msau_softmax_ce(void* stream, int dtype, const void* logits, cons
                    hipLaunchKernelGGL((masked_ce_wide_kernel<float, true>), dim3(nb), dim3(kThreads), 0, s, static_cast<const float*>(logits), labels, nullptr, static_cast<float*>(dlogits), ws, B, hw, C, Cs, scale),
                    hipLaunchKernelGGL((masked_ce_wide_kernel<bf16_t, true>), dim3(nb), dim3(kThreads), 0, s, static_cast<const bf16_t*>(logits), labels, nullptr, static_cast<bf16_t*>(dlogits), ws, B, hw, C, Cs, scale));
         MSAU_CHECK_LAUNCH("softmax_ce_wide");
-        hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(64), 0, s, ws, nb, loss_accum);
+        hipLaunchKernelGGL(ordered_sum_kernel_t<false>, dim3(1), dim3(256), 0, s, ws, nb, loss_accum);
         MSAU_CHECK_LAUNCH("ordered_sum");
         return 0;
     }
@@ -818,7 +851,7 @@ extern "C" int msau_softmax_ce(void* stream, int dtype, const void* logits, cons
                hipLaunchKernelGGL((masked_ce_kernel<float, true>), dim3(nb), dim3(kThreads), 0, s, static_cast<const float*>(logits), labels, nullptr, static_cast<float*>(dlogits), ws, B, hw, C, Cs, scale),
                hipLaunchKernelGGL((masked_ce_kernel<bf16_t, true>), dim3(nb), dim3(kThreads), 0, s, static_cast<const bf16_t*>(logits), labels, nullptr, static_cast<bf16_t*>(dlogits), ws, B, hw, C, Cs, scale));
     MSAU_CHECK_LAUNCH("softmax_ce");
-    hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(64), 0, s, ws, nb, loss_accum);
+    hipLaunchKernelGGL(ordered_sum_kernel_t<false>, dim3(1), dim3(256), 0, s, ws, nb, loss_accum);
     MSAU_CHECK_LAUNCH("ordered_sum");
     return 0;
 }

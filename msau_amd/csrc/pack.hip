@@ -14,7 +14,27 @@ int msau_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* msau_last_error(void) { return g_err; }
-extern "C" int msau_version(void) { return 1; }
+extern "C" int msau_version(void) { return 2; }
+
+// sizeof() of every struct that crosses the ABI by pointer, so that a binding can check its mirror (tests/test_host_cpu.py)
+extern "C" int msau_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(msau_conv_desc);
+        case 1: return (int)sizeof(msau_wgrad_desc);
+        case 2: return (int)sizeof(msau_pack_entry);
+        case 3: return (int)sizeof(msau_unpack_entry);
+        case 4: return (int)sizeof(msau_op);
+        case 5: return (int)sizeof(msau_lrn_args);
+        case 6: return (int)sizeof(msau_pool_args);
+        case 7: return (int)sizeof(msau_attn_args);
+        case 8: return (int)sizeof(msau_csum_args);
+        case 9: return (int)sizeof(msau_reduce_args);
+        case 10: return (int)sizeof(msau_conv_pack_geom);
+        case 11: return (int)sizeof(msau_wgrad_geom);
+        case 12: return (int)sizeof(msau_conv_pair_desc);
+        default: return -1;
+    }
+}
 
 namespace {
 
@@ -64,80 +84,88 @@ __global__ void pack_kernel(const float* __restrict__ params, unsigned char* __r
     }
 }
 
-// 256 threads = 32 consecutive K columns (one 128-B line per slab) x 8 slab lanes: slab lane t sums slabs
-// t, t+8, ... with independent loads in flight, then the 8 partial sums are combined in a fixed order.
+// Slab reduction.  A slab is treated as the flat array it is ([chunk][row][kext], `slab_elems` floats, 256-byte
+// aligned): a workgroup owns runs of 64 consecutive floats, 16 threads x float4 cover a run (whole 128-byte lines, each
+// read exactly once), the 16 thread rows sum slabs t, t+16, ... with four independent loads in flight, and the 16
+// partial sums are combined in a fixed order (bit-reproducible).  Only then is the flat position decoded into the
+// parameter's OIHW / IOHW element.  The "ones" column of a conv's slab (bias gradient) is part of the same pass.
+// (The first version gave each workgroup 32 columns of ONE row: rows are 64-byte aligned, so most 128-byte groups
+// straddled two lines, every line was fetched twice from different XCDs and the reduction ran at 0.9 TB/s -- 150 us per
+// stage on the side stream, during which the data-gradient kernels of the main stream stalled.)
 __global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ slabs, float* __restrict__ grads,
                                                      const msau_unpack_entry* __restrict__ table) {
-    constexpr int NC = 32, NS = 8;
-    __shared__ float red[NS][NC + 1];
+    constexpr int NC = 64, NS = 16;
+    __shared__ float red[NS][NC + 4];
     const msau_unpack_entry e = table[blockIdx.y];
     const int taps = e.KH * e.KW;
-    const int kcols = e.nchunks * taps * e.cch;                 // stored K columns
-    const int kc16 = (kcols + NC - 1) / NC;
+    const int kreal = taps * e.cch;                             // real K columns per chunk (the ones column follows)
     const int rows_store = e.slab_elems / (e.kext * e.nchunks);
-    const int ngroups = e.rows_real * kc16;                     // groups of 16 consecutive columns of one row
+    const int ngroups = (e.slab_elems + NC - 1) / NC;
     const float* s0 = slabs + e.slab_off;
-    const int col = threadIdx.x & (NC - 1), sl = threadIdx.x / NC;
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const bool conv_bias = e.b_off >= 0 && e.b_elem_stride == e.kext;     // bias = ones column of these slabs
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const int r = grp / kc16;
-        const int kk = (grp - r * kc16) * NC + col;
-        float sum = 0.f;
-        int chunk = 0, k = 0, tap = 0, c = 0, kc = -1;
-        if (kk < kcols) {
-            chunk = kk / (taps * e.cch);
-            k = kk - chunk * taps * e.cch;
-            tap = k / e.cch; c = k - tap * e.cch;
-            kc = real_channel(chunk * e.cch + c, e.k1_real, e.k1_store, e.k2_real, e.k2_store);
-        }
-        if (kc >= 0) {
-            const float* p = s0 + ((int64_t)chunk * rows_store + r) * e.kext + k;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const int f0 = grp * NC + cl * 4;                       // flat position of this thread's 4 floats
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        if (f0 < e.slab_elems) {
+            const float* p = s0 + f0;
             int s = sl;
             for (; s + 3 * NS < e.nslabs; s += 4 * NS) {
-                a0 += p[(int64_t)s * e.slab_elems];
-                a1 += p[(int64_t)(s + NS) * e.slab_elems];
-                a2 += p[(int64_t)(s + 2 * NS) * e.slab_elems];
-                a3 += p[(int64_t)(s + 3 * NS) * e.slab_elems];
+                a0 += *reinterpret_cast<const f32x4*>(p + (int64_t)s * e.slab_elems);
+                a1 += *reinterpret_cast<const f32x4*>(p + (int64_t)(s + NS) * e.slab_elems);
+                a2 += *reinterpret_cast<const f32x4*>(p + (int64_t)(s + 2 * NS) * e.slab_elems);
+                a3 += *reinterpret_cast<const f32x4*>(p + (int64_t)(s + 3 * NS) * e.slab_elems);
             }
-            for (; s < e.nslabs; s += NS) a0 += p[(int64_t)s * e.slab_elems];
-            sum = (a0 + a1) + (a2 + a3);
+            for (; s < e.nslabs; s += NS) a0 += *reinterpret_cast<const f32x4*>(p + (int64_t)s * e.slab_elems);
         }
+        const f32x4 sum = (a0 + a1) + (a2 + a3);
         __syncthreads();
-        red[sl][col] = sum;
+        *reinterpret_cast<f32x4*>(&red[sl][cl * 4]) = sum;
         __syncthreads();
-        if (sl == 0 && kc >= 0) {
-            float t = 0.f;
-#pragma unroll
-            for (int i = 0; i < NS; ++i) t += red[i][col];
-            int ky = tap / e.KW, kx = tap - ky * e.KW;
-            int i0 = e.row_is_dim0 ? r : kc;
-            int i1 = e.row_is_dim0 ? kc : r;
-            float* dst = grads + e.w_off + (((int64_t)i0 * e.dim1 + i1) * e.KH + ky) * e.KW + kx;
-            *dst = e.accumulate ? *dst + t : t;
-        }
-    }
-    if (e.b_off >= 0) {
-        // bias gradient: the "ones" column of the wgrad slabs, or channel-sum partials; same 16 x 16 scheme
-        const int bgroups = (e.b_count + NC - 1) / NC;
-        for (int grp = blockIdx.x; grp < bgroups; grp += gridDim.x) {
-            const int r = grp * NC + col;
-            float a0 = 0.f, a1 = 0.f;
-            if (r < e.b_count) {
-                const float* p = slabs + e.b_src_off + (int64_t)r * e.b_elem_stride;
-                int s = sl;
-                for (; s + NS < e.b_nslabs; s += 2 * NS) {
-                    a0 += p[(int64_t)s * e.b_slab_stride];
-                    a1 += p[(int64_t)(s + NS) * e.b_slab_stride];
-                }
-                for (; s < e.b_nslabs; s += NS) a0 += p[(int64_t)s * e.b_slab_stride];
-            }
-            __syncthreads();
-            red[sl][col] = a0 + a1;
-            __syncthreads();
-            if (sl == 0 && r < e.b_count) {
+        if (threadIdx.x < NC) {
+            const int f = grp * NC + threadIdx.x;
+            if (f < e.slab_elems) {
                 float t = 0.f;
 #pragma unroll
-                for (int i = 0; i < NS; ++i) t += red[i][col];
+                for (int i = 0; i < NS; ++i) t += red[i][threadIdx.x];
+                const int k = f % e.kext;
+                const int rr = f / e.kext;
+                const int r = rr % rows_store, chunk = rr / rows_store;
+                if (r < e.rows_real) {
+                    if (k < kreal) {
+                        const int tap = k / e.cch, c = k - tap * e.cch;
+                        const int kc = real_channel(chunk * e.cch + c, e.k1_real, e.k1_store, e.k2_real, e.k2_store);
+                        if (kc >= 0) {
+                            const int ky = tap / e.KW, kx = tap - ky * e.KW;
+                            const int i0 = e.row_is_dim0 ? r : kc;
+                            const int i1 = e.row_is_dim0 ? kc : r;
+                            float* dst = grads + e.w_off + (((int64_t)i0 * e.dim1 + i1) * e.KH + ky) * e.KW + kx;
+                            *dst = e.accumulate ? *dst + t : t;
+                        }
+                    } else if (k == kreal && chunk == 0 && conv_bias && r < e.b_count) {
+                        float* dst = grads + e.b_off + r;
+                        *dst = e.accumulate ? *dst + t : t;
+                    }
+                }
+            }
+        }
+    }
+    if (e.b_off >= 0 && !conv_bias) {
+        // bias gradient from msau_channel_sum partials (transposed conv): [b_nslabs][b_slab_stride], element stride 1
+        const int col = threadIdx.x & 63, s4 = threadIdx.x >> 6;
+        const int bgroups = (e.b_count + 63) / 64;
+        for (int grp = blockIdx.x; grp < bgroups; grp += gridDim.x) {
+            const int r = grp * 64 + col;
+            float a = 0.f;
+            if (r < e.b_count) {
+                const float* p = slabs + e.b_src_off + (int64_t)r * e.b_elem_stride;
+                for (int s = s4; s < e.b_nslabs; s += 4) a += p[(int64_t)s * e.b_slab_stride];
+            }
+            __syncthreads();
+            red[s4][col] = a;
+            __syncthreads();
+            if (s4 == 0 && r < e.b_count) {
+                const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
                 float* dst = grads + e.b_off + r;
                 *dst = e.accumulate ? *dst + t : t;
             }
@@ -162,7 +190,7 @@ extern "C" int msau_pack_params(void* stream, const float* flat_params, void* pa
 extern "C" int msau_wgrad_reduce(void* stream, const float* slab_arena, float* flat_grads,
                                  const msau_unpack_entry* table_dev, int n_entries, int max_elems_per_entry) {
     MSAU_CHECK_ARG(slab_arena && flat_grads && table_dev && n_entries > 0, "wgrad_reduce: bad args");
-    int bx = cdiv(max_elems_per_entry, 32);
+    int bx = cdiv(max_elems_per_entry, 64);
     if (bx > 128) bx = 128;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(unpack_kernel, dim3(bx, n_entries), dim3(256), 0, static_cast<hipStream_t>(stream),

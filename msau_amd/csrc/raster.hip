@@ -48,7 +48,45 @@ __global__ void raster_label_kernel(const int32_t* __restrict__ boxes, const int
     }
 }
 
+// dense painter (data_generator_funsd_bert.py:64-93 get_box_mask_box_label): the owning box's feature vector
+// feats[value][0..C) (fp32, row stride C) at every covered pixel, zeros elsewhere and in the padded channels
+template <typename T>
+__global__ void raster_dense_kernel(const int32_t* __restrict__ boxes, const int32_t* __restrict__ owner,
+                                    const float* __restrict__ feats, T* __restrict__ grid, int64_t npix, int C, int Cs) {
+    const int cgs = Cs >> 3;
+    const int64_t total = npix * cgs;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / cgs;
+        const int cg = (int)(i - p * cgs);
+        const int o = owner[p];
+        const int v = o >= 0 ? boxes[(size_t)o * 6 + 5] : -1;
+        typename Vec8<T>::type out;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cg * 8 + j;
+            out[j] = (T)((v >= 0 && c < C) ? feats[(size_t)v * C + c] : 0.0f);
+        }
+        store8<T>(grid + i * 8, out);
+    }
+}
+
 }  // namespace
+
+extern "C" int msau_raster_dense(void* stream, int dtype, const int32_t* boxes, const int32_t* owner, const float* feats,
+                                 void* grid, int B, int H, int W, int C, int Cs) {
+    MSAU_CHECK_ARG(owner && grid && feats && B > 0 && H > 0 && W > 0 && C > 0 && Cs >= C && Cs % 8 == 0, "raster_dense: bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t npix = (int64_t)B * H * W;
+    int64_t blocks = cdiv64(npix * (Cs / 8), 256);
+    if (blocks > 8192) blocks = 8192;
+    if (dtype == MSAU_F32)
+        hipLaunchKernelGGL(raster_dense_kernel<float>, dim3((int)blocks), dim3(256), 0, s, boxes, owner, feats, static_cast<float*>(grid), npix, C, Cs);
+    else if (dtype == MSAU_BF16)
+        hipLaunchKernelGGL(raster_dense_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, s, boxes, owner, feats, static_cast<bf16_t*>(grid), npix, C, Cs);
+    else return msau_set_error(MSAU_ERR_ARG, "raster_dense: bad dtype");
+    MSAU_CHECK_LAUNCH("raster_dense");
+    return 0;
+}
 
 extern "C" int msau_raster_owner(void* stream, const int32_t* boxes, int n, int32_t* owner, int B, int H, int W) {
     MSAU_CHECK_ARG(owner && B > 0 && H > 0 && W > 0 && n >= 0 && (n == 0 || boxes), "raster_owner: bad args");

@@ -152,6 +152,48 @@ def get_box_mask_box_label_word(dataset_instance, idx):
     return {"ocr_values": [c.ocr_value for c in words], "mask": grid, "label": label}
 
 
+def getitem_box_bert(dataset_instance, idx):
+    """data_generator_funsd_bert.py:22-29"""
+    doc = dataset_instance.inp_list[idx]
+    return {"ocr_values": [c.ocr_value for c in doc["cells"]], "feats": doc["transformer_feature"], "label": doc["labels"]}
+
+
+def getitem_box_chargrid(dataset_instance, idx):
+    """data_generator_funsd_bert.py:30-37"""
+    doc = dataset_instance.inp_list[idx]
+    return {"ocr_values": [c.ocr_value for c in doc["cells"]], "feats": np.array(doc["charset_feature"]), "label": doc["labels"]}
+
+
+def line_boxes(lines: List[CellNode]):
+    """grid size and (line index, y0, y1, x0, x1) of every text-line box of the dense painter, in painting order
+    (data_generator_funsd_bert.py:71-83: both scales are the minimum LINE width / height)"""
+    min_x, min_y, max_x, max_y, min_w, min_h = get_min_max_x_y_w_h(lines)
+    W = int((max_x - min_x) / min_w) + 1
+    H = int((max_y - min_y) / min_h) + 1
+    out = []
+    for li, c in enumerate(lines):
+        x = int((c.x - min_x) / min_w)
+        y = int((c.y - min_y) / min_h)
+        w = max(int(c.w / min_w), 1)
+        h = max(int(c.h / min_h), 1)
+        out.append((li, y, y + h, x, x + w))
+    return H, W, out
+
+
+def get_box_mask_box_label(dataset_instance, idx):
+    """BERT-embedding chargrid (data_generator_funsd_bert.py:64-93): one feature vector per text LINE painted over its box,
+    labels over the same boxes (+1, 0 = unlabelled)"""
+    lines = dataset_instance.inp_list[idx]["cells"]
+    box = dataset_instance.getitem_box(dataset_instance, idx)
+    H, W, boxes = line_boxes(lines)
+    label = np.zeros((H, W)).astype("uint8")
+    grid = np.zeros((box["feats"].shape[-1], H, W))
+    for li, y0, y1, x0, x1 in boxes:
+        grid[:, y0:y1, x0:x1] = np.asarray(box["feats"][li])[:, None, None]
+        label[y0:y1, x0:x1] = box["label"][li] + 1
+    return {"ocr_values": box["ocr_values"], "mask": grid, "label": label}
+
+
 class FUNSDMaskDataLoader(Dataset):
     """pickle of preprocessed documents -> items {"ocr_values", "mask": [1,C,H,W], "label": [1,H,W]}.
     The label -> id map comes from the FIRST document's label set unless given; like the reference it is
@@ -190,4 +232,13 @@ class FUNSDMaskDataLoader(Dataset):
 
 class FUNSDCharGridDataLoaderBoxMaskBoxLabel(FUNSDMaskDataLoader):
     def __init__(self, funsd_pickle_path, labels_dict=None, **kw):
-        super().__init__(funsd_pickle_path, labels_dict=labels_dict, getitem_mask=get_box_mask_box_label_word, **kw)
+        super().__init__(funsd_pickle_path, labels_dict=labels_dict, getitem_box=getitem_box_chargrid,
+                         getitem_mask=get_box_mask_box_label_word, **kw)
+
+
+class FUNSDBertDataLoaderBoxMaskBoxLabel(FUNSDMaskDataLoader):
+    """data_generator_funsd_bert.py:240-245: the loader BASELINE.json configs[3] names (768-d line embeddings)"""
+
+    def __init__(self, funsd_pickle_path, labels_dict=None, **kw):
+        super().__init__(funsd_pickle_path, labels_dict=labels_dict, getitem_box=getitem_box_bert,
+                         getitem_mask=get_box_mask_box_label, **kw)

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from .. import _lib as L
-from .funsd import chargrid_geometry, word_char_boxes
+from .funsd import chargrid_geometry, line_boxes, word_char_boxes
 
 
 def document_boxes(doc: dict, sample: int = 0) -> Tuple[np.ndarray, np.ndarray, int, int]:
@@ -51,4 +51,38 @@ def rasterize(char_boxes: np.ndarray, label_boxes: np.ndarray, B: int, H: int, W
         else:
             L.call("msau_raster_labels", s, bt.data_ptr(), owner.data_ptr(), labels.data_ptr(), B, H, W)
         torch.cuda.current_stream(dev).synchronize()          # `bt` must outlive the launches that read it
+    return grid, labels
+
+
+def document_line_boxes(doc: dict, sample: int = 0, feat_base: int = 0):
+    """-> (feature boxes [n,6] with value = feat_base + line index, label boxes [n,6], H, W) for the dense (BERT) painter
+    `funsd.get_box_mask_box_label`: both the feature vectors and the labels cover the text-LINE boxes"""
+    H, W, boxes = line_boxes(doc["cells"])
+    fb = [(sample, y0, y1, x0, x1, feat_base + li) for li, y0, y1, x0, x1 in boxes]
+    lb = [(sample, y0, y1, x0, x1, int(doc["labels"][li]) + 1) for li, y0, y1, x0, x1 in boxes]
+    return np.asarray(fb, np.int32).reshape(-1, 6), np.asarray(lb, np.int32).reshape(-1, 6), H, W
+
+
+def rasterize_dense(feat_boxes: np.ndarray, label_boxes: np.ndarray, feats: np.ndarray, B: int, H: int, W: int,
+                    dtype: str = "bf16", device="cuda") -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (grid [B,H,W,Cs] with feats[value] painted over each box in `dtype` storage, labels int64 [B,H,W]); only the
+    box list and the [n_lines, C] feature table cross PCIe (at 768 channels the dense fp32 grid is 264 MB per tile)"""
+    dt = L.BF16 if dtype in ("bf16", "bfloat16") else L.F32
+    feats = np.ascontiguousarray(feats, dtype=np.float32)
+    C = feats.shape[1]
+    Cs = -(-C // 8) * 8
+    dev = torch.device(device)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    owner = torch.empty((B, H, W), dtype=torch.int32, device=dev)
+    grid = torch.empty((B, H, W, Cs), dtype=torch.bfloat16 if dt == L.BF16 else torch.float32, device=dev)
+    labels = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    ft = torch.from_numpy(feats).to(dev)
+    for boxes, kind in ((feat_boxes, "grid"), (label_boxes, "labels")):
+        bt = torch.from_numpy(np.ascontiguousarray(boxes, dtype=np.int32)).to(dev)
+        L.call("msau_raster_owner", s, bt.data_ptr() if len(boxes) else None, len(boxes), owner.data_ptr(), B, H, W)
+        if kind == "grid":
+            L.call("msau_raster_dense", s, dt, bt.data_ptr(), owner.data_ptr(), ft.data_ptr(), grid.data_ptr(), B, H, W, C, Cs)
+        else:
+            L.call("msau_raster_labels", s, bt.data_ptr(), owner.data_ptr(), labels.data_ptr(), B, H, W)
+        torch.cuda.current_stream(dev).synchronize()          # `bt` / `ft` must outlive the launches that read them
     return grid, labels

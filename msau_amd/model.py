@@ -95,8 +95,11 @@ class _MSAUFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, wrapper, x, *params):
         plan = wrapper._plan_for(x, training=True)
+        # The saved activations are the plan's own buffers: a second grad-mode forward of the same shape overwrites them.
+        # backward() checks that it still belongs to the latest forward instead of returning silently wrong gradients.
+        plan.generation += 1
         logits, aux = plan.forward(wrapper._flat, x)
-        ctx.wrapper, ctx.plan = wrapper, plan
+        ctx.wrapper, ctx.plan, ctx.generation = wrapper, plan, plan.generation
         outs = (logits.clone(), aux.clone() if aux is not None else None)
         ctx.has_aux = aux is not None
         return outs if aux is not None else (outs[0],)
@@ -104,6 +107,10 @@ class _MSAUFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gouts):
         w, plan = ctx.wrapper, ctx.plan
+        if plan.generation != ctx.generation:
+            raise RuntimeError("MSAUWrapper: backward() of a forward whose saved activations were overwritten by a later "
+                               f"forward of the same input shape {(plan.B, plan.H, plan.W)} (gradient accumulation over "
+                               "micro-batches: call backward() before the next forward, or use TrainEngine)")
         g_logits = gouts[0]
         g_aux = gouts[1] if ctx.has_aux else None
         plan.set_external_grads(g_logits, g_aux)
@@ -230,7 +237,8 @@ class MSAUWrapper(nn.Module):
         self.predictor = nn.Softmax(dim=1) if self.final_act == "softmax" else nn.Sequential()
         self.criterion = nn.CrossEntropyLoss()
         self._plans: "OrderedDict[tuple, Plan]" = OrderedDict()
-        self.max_cached_plans = 4
+        self.max_cached_plans = 4               # LRU bounds: number of plans and bytes of their activation buffers
+        self.max_plan_bytes = 64 << 30
 
     # ---- flat parameter storage ---------------------------------------------------------------
     def _rebind(self):
@@ -269,9 +277,11 @@ class MSAUWrapper(nn.Module):
         plan = self._plans.get(key)
         if plan is None:
             plan = Plan(self.cfg, B, H, W, self._dtype, device, self._poff, self._pshape, training=training)
+            plan.generation = 0                 # bumped by every grad-mode forward (see _MSAUFunction)
             self._plans[key] = plan
-            while len(self._plans) > self.max_cached_plans:
-                self._plans.popitem(last=False)
+            while len(self._plans) > 1 and (len(self._plans) > self.max_cached_plans or
+                                            sum(p.activation_bytes() for p in self._plans.values()) > self.max_plan_bytes):
+                self._plans.popitem(last=False)     # captured graphs live on the plan object and go with it
         else:
             self._plans.move_to_end(key)
         return plan
@@ -392,8 +402,6 @@ class TrainEngine:
         self.sync = GradSync(self.flat_grad, stage_buckets(model._poff, model._total, model.num_blocks), process_group)
         self.world = self.sync.world
         self.use_graph = use_graph
-        self._graphs = {}
-        self._static = {}
         # Graph replays run on a dedicated non-default stream.  Replaying on the legacy NULL stream after the
         # host had synchronised produced corrupted steps on ROCm 7.2 / gfx950 (nodes of consecutive launches
         # overlapping; found 2026-10-03 with tools/loss_trace.py) -- never launch these graphs into stream 0.
@@ -439,12 +447,15 @@ class TrainEngine:
             self._allreduce()
             self._optim()
             return loss
-        key = (x.shape[0], x.shape[2], x.shape[3])
+        # The captured graphs hold the plan's buffer addresses: they are stored ON the plan (as predict_nhwc does), so
+        # that an evicted / rebuilt plan can never be replayed through a stale graph.
+        graphs = plan.__dict__.setdefault("_tgraphs", {})
+        key = id(self)
         cur = torch.cuda.current_stream()
         gs = self._gstream
         gs.wait_stream(cur)
         with torch.cuda.stream(gs):
-            if key not in self._graphs:
+            if key not in graphs:
                 sx, sl = x.clone(), labels.clone()
                 # warm up outside capture (hipFuncSetAttribute calls, lazy allocations)
                 self._fwd_bwd(plan, sx, sl)
@@ -455,10 +466,8 @@ class TrainEngine:
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, stream=gs):
                     self._optim()
-                self._graphs[key] = (g1, g2, loss)
-                self._static[key] = (sx, sl)
-            g1, g2, loss = self._graphs[key]
-            sx, sl = self._static[key]
+                graphs[key] = (g1, g2, loss, sx, sl)
+            g1, g2, loss, sx, sl = graphs[key]
             sx.copy_(x, non_blocking=True)
             sl.copy_(labels, non_blocking=True)
             g1.replay()
@@ -470,3 +479,47 @@ class TrainEngine:
     @property
     def grad_norm(self) -> torch.Tensor:
         return self.state[1]
+
+    # -- optimiser state (resume): the counterpart of torch.optim.Adam.state_dict() for the flat buffers --
+    def state_dict(self) -> dict:
+        """{"engine": 1, "step", "exp_avg", "exp_avg_sq" (flat fp32, the model's parameter order), hyper-parameters}"""
+        return {"engine": 1, "step": int(round(float(self.state[0]))), "exp_avg": self.m.detach().clone(),
+                "exp_avg_sq": self.v.detach().clone(), "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps,
+                "max_norm": self.max_norm, "numel": int(self.m.numel())}
+
+    def load_state_dict(self, sd: dict):
+        """Accepts `TrainEngine.state_dict()` or a `torch.optim.Adam.state_dict()` over the model's parameters in
+        registration order (what the reference's `save_checkpoint` stores: utils/io_utils.py:83-105); parameters Adam
+        never stepped (the dead last-stage attention) have no entry and keep zero moments."""
+        if sd.get("engine") == 1:
+            if int(sd["numel"]) != self.m.numel():
+                raise ValueError(f"optimizer state is for {sd['numel']} parameters, the model has {self.m.numel()}")
+            self.m.copy_(sd["exp_avg"])
+            self.v.copy_(sd["exp_avg_sq"])
+            self.state.zero_()
+            self.state[0] = float(sd["step"])
+            self.lr, self.betas, self.eps = float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"])
+            self.max_norm = float(sd.get("max_norm", self.max_norm))
+            return
+        groups, state = sd["param_groups"], sd["state"]
+        order = [pid for g in groups for pid in g["params"]]
+        named = [(k, p) for k, p in self.model._named if p.requires_grad]
+        if len(order) != len(named):
+            raise ValueError(f"optimizer state covers {len(order)} parameters, the model has {len(named)}")
+        self.m.zero_()
+        self.v.zero_()
+        step = 0
+        for pid, (key, p) in zip(order, named):
+            st = state.get(pid)
+            if st is None:
+                continue
+            off, n = self.model._poff[key], p.numel()
+            if st["exp_avg"].numel() != n:
+                raise ValueError(f"optimizer state of {key}: {st['exp_avg'].numel()} elements, parameter has {n}")
+            self.m[off:off + n] = st["exp_avg"].reshape(-1).to(self.m)
+            self.v[off:off + n] = st["exp_avg_sq"].reshape(-1).to(self.v)
+            step = max(step, int(round(float(st["step"]))))
+        self.state.zero_()
+        self.state[0] = float(step)
+        g0 = groups[0]
+        self.lr, self.betas, self.eps = float(g0["lr"]), tuple(g0["betas"]), float(g0["eps"])

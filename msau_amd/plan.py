@@ -104,6 +104,7 @@ class ConvOp(Op):
         self.wname, self.bname, self.k, self.dil, self.kind = wname, bname, k, dil, kind
         self.relu_in, self.relu_out, self.fwd_add = relu_in, relu_out, fwd_add
         self.bwd_add: Optional[Act] = None
+        self.pair: Optional["PairOp"] = None        # set when this conv runs as half of a fused two-conv launch
         assert out.relu_out == relu_out
         if kind == "conv":
             assert out.H == x1.H and out.W == x1.W
@@ -335,7 +336,7 @@ class ConvOp(Op):
             self.csum_off = P.alloc_slab(self.csum_blocks * out.Cs)
             u.b_src_off, u.b_slab_stride, u.b_elem_stride, u.b_nslabs = self.csum_off, out.Cs, 1, self.csum_blocks
             u.b_count = out.C
-        P.add_unpack_entry(u, rows_real * wg.nchunks * taps * wg.cch, self.reduce_group())
+        P.add_unpack_entry(u, slab_elems, self.reduce_group())
 
     def late_bind(self):
         P = self.plan
@@ -392,9 +393,15 @@ class ConvOp(Op):
             P.note_launch(self.wkey, self.wbytes, self.flops)
 
     def fwd(self, s):
+        if self.pair is not None and self.pair.active:
+            if self is self.pair.c2:
+                L.call("msau_conv_pair", s, self.plan.dtype, C.byref(self.pair.fdesc), key=self.pair.key)
+            return
         L.call("msau_conv2d", s, self.plan.dtype, C.byref(self.fdesc), key=self.fkey)
 
     def fwd_recs(self):
+        if self.pair is not None and self.pair.active:
+            return [(L.OP_CONV_PAIR, self.pair.fdesc)] if self is self.pair.c2 else []
         return [(L.OP_CONV2D, self.fdesc)]
 
     def bwd_recs(self):
@@ -409,6 +416,10 @@ class ConvOp(Op):
             P = self.plan
             self._csum = L.CsumArgs(_ptr(self.out.grad), self.out.npix, self.out.Cs, P.slab_ptr(self.csum_off), self.csum_blocks)
             recs.append((L.OP_CHANNEL_SUM | side, self._csum))
+        if self.pair is not None and self.pair.active and self.pair.bdesc is not None:
+            if self is self.pair.c2:                    # both data gradients in one launch, behind the second conv's wgrad
+                recs.append((L.OP_CONV_PAIR, self.pair.bdesc))
+            return recs
         recs += [(L.OP_CONV2D, dd) for dd in self.ddesc if dd is not None]
         return recs
 
@@ -426,6 +437,10 @@ class ConvOp(Op):
         if self.wdesc is None:
             return
         P = self.plan
+        if self.pair is not None and self.pair.active and self.pair.bdesc is not None:
+            if self is self.pair.c2:
+                L.call("msau_conv_pair", s, P.dtype, C.byref(self.pair.bdesc), key=self.pair.key)
+            return
         for si, dd in enumerate(self.ddesc):
             if dd is not None:
                 L.call("msau_conv2d", s, P.dtype, C.byref(dd), key=self.dmeta[si][0])
@@ -433,6 +448,73 @@ class ConvOp(Op):
     def bwd(self, s):
         self.bwd_wgrad(s)
         self.bwd_dgrad(s)
+
+
+class PairOp:
+    """The two convs of a res_depth-2 residual block (model/model.py:37-50) as ONE launch per sweep (msau_conv_pair,
+    csrc/conv_pair.hip): forward r1 = ReLU(conv1(ReLU(x0))), out = ReLU(conv2(r1) + x0); backward both data gradients.
+    The ConvOps keep their packed images, weight-gradient launches and bookkeeping; only their forward / data-gradient
+    launches are replaced.  Not an entry of plan.ops: the ConvOps emit the fused records."""
+
+    def __init__(self, plan: "Plan", c1: ConvOp, c2: ConvOp):
+        self.plan, self.c1, self.c2 = plan, c1, c2
+        self.active = False
+        self.fdesc = self.bdesc = None
+        c1.pair = c2.pair = self
+        plan.pairs.append(self)
+
+    def bind(self):
+        """after both ConvOps are bound: build the fused descriptors if an instance takes the shape"""
+        P, c1, c2 = self.plan, self.c1, self.c2
+        x0, r1, out = c1.x1, c1.out, c2.out
+        if os.environ.get("MSAU_FUSE_PAIR", "1") == "0" or not P.cfg.get("fuse_pair", True):
+            return
+        ok = (c1.kind == c2.kind == "conv" and c1.k == c2.k == 3 and c1.dil == c2.dil == 1 and c1.x2 is None and c2.x2 is None
+              and c1.relu_in and c1.relu_out and c1.fwd_add is None and not c2.relu_in and c2.relu_out and c2.fwd_add is x0
+              and c2.x1 is r1 and x0.C == x0.Cs == r1.C == out.C and x0.Cs in (8, 16, 32) and not c1.head and not c2.head
+              and r1.n_contrib == (1 if P.training else 0))
+        if not ok:
+            return
+        f = L.ConvPairDesc()
+        f.B, f.H, f.W, f.C = P.B, x0.H, x0.W, x0.Cs
+        f.flags1, f.flags2 = L.PAIR_RELU_IN | L.PAIR_RELU_MID, L.CONV_ADD | L.CONV_RELU_OUT
+        f.x, f.w1, f.b1, f.mid = _ptr(x0.data), P.pack_ptr(c1.w_off), P.pack_ptr(c1.b_off), _ptr(r1.data)
+        f.w2, f.b2, f.add, f.y = P.pack_ptr(c2.w_off), P.pack_ptr(c2.b_off), _ptr(x0.data), _ptr(out.data)
+        if not L.load().msau_conv_pair_applicable(P.dtype, C.byref(f)):
+            return
+        self.fdesc = f
+        T = "f32" if P.dtype == L.F32 else "bf16"
+        esz = 4 if P.dtype == L.F32 else 2
+        self.key = f"conv_pair_kernel<{T},C{x0.Cs}>"
+        n = P.B * x0.H * x0.W * x0.Cs
+        self.fbytes = 4 * n * esz                       # x0 once, r1 once, out once, residual operand once
+        if P.training and c1.ddesc[0] is not None and c2.ddesc[0] is not None and c1.ddesc[1] is None and c2.ddesc[1] is None \
+                and c1.d_off[0] is not None and c2.d_off[0] is not None:
+            d1, d2 = c1.ddesc[0], c2.ddesc[0]
+            if d2.flags == L.CONV_MASK_B and not (d1.flags & ~(L.CONV_MASK_A | L.CONV_ADD | L.CONV_ACCUM | L.CONV_MASK_B)):
+                b = L.ConvPairDesc()
+                b.B, b.H, b.W, b.C = P.B, x0.H, x0.W, x0.Cs
+                b.flags1, b.flags2 = L.PAIR_MASK_MID, d1.flags
+                b.x, b.w1, b.b1, b.mask_mid, b.mid = _ptr(out.grad), P.pack_ptr(c2.d_off[0]), None, d2.mask_b, _ptr(r1.grad)
+                b.w2, b.b2, b.add, b.mask_a, b.mask_b, b.y = P.pack_ptr(c1.d_off[0]), None, d1.add, d1.mask_a, d1.mask_b, d1.y
+                if L.load().msau_conv_pair_applicable(P.dtype, C.byref(b)):     # MASK_A + ADD of the input tensor only
+                    self.bdesc = b
+                nex = sum(1 for fl in (L.CONV_MASK_A, L.CONV_ADD, L.CONV_ACCUM, L.CONV_MASK_B) if d1.flags & fl)
+                self.bbytes = (4 + nex) * n * esz       # g once, r1 mask once, g_r1 once, dx once + epilogue operands
+        self.active = True
+
+    def note(self):
+        """replace the two convs' launch accounting by the fused launches' (bench.py roofline)"""
+        P, c1, c2 = self.plan, self.c1, self.c2
+        if not self.active:
+            return
+        for c in (c1, c2):
+            P.unnote_launch(c.fkey, c.fbytes, c.flops)
+        P.note_launch(self.key, self.fbytes, c1.flops + c2.flops)
+        if self.bdesc is not None:
+            for c in (c1, c2):
+                P.unnote_launch(c.dmeta[0][0], c.dmeta[0][1], c.flops)
+            P.note_launch(self.key, self.bbytes, c1.flops + c2.flops)
 
 
 class LrnOp(Op):
@@ -580,6 +662,7 @@ class Plan:
         self.head_fused = False
         self.acts: List[Act] = []
         self.ops: List[Op] = []
+        self.pairs: List[PairOp] = []
         self._pack_bytes = 0
         self._slab_elems = 0
         self._pack_entries: List[L.PackEntry] = []
@@ -632,6 +715,13 @@ class Plan:
         c, b, f = self.launch_meta.get(key, (0, 0.0, 0.0))
         self.launch_meta[key] = (c + 1, b + nbytes, f + flops)
 
+    def unnote_launch(self, key: str, nbytes: float, flops: float):
+        c, b, f = self.launch_meta[key]
+        if c <= 1:
+            del self.launch_meta[key]
+        else:
+            self.launch_meta[key] = (c - 1, b - nbytes, f - flops)
+
     def pack_ptr(self, off: int) -> int:
         return self.pack_arena.data_ptr() + off
 
@@ -651,6 +741,8 @@ class Plan:
             first = first or op
             r_in = o
         first.bwd_add = r_in                    # d(x0) += g(block output): the in-place residual add
+        if R == 2:
+            PairOp(self, first, op)             # one launch per sweep when an instance takes the shape (bind() decides)
         return r_in
 
     def _build_net(self):
@@ -758,6 +850,9 @@ class Plan:
         for op in self.ops:
             if isinstance(op, ConvOp):
                 op.late_bind()
+        for pr in self.pairs:
+            pr.bind()
+            pr.note()
         self._fwd_seq = self._make_seq([r for op in self.ops for r in op.fwd_recs()])
         self.pack_table = self._upload(self._pack_entries, L.PackEntry) if self._pack_entries else None
         self.unpack_table = self._upload(self._unpack_entries, L.UnpackEntry) if self._unpack_entries else None
@@ -854,6 +949,11 @@ class Plan:
                     for si, dd in enumerate(op.ddesc):
                         if dd is not None and op.dmeta[si][0] == key:
                             want.add(C.addressof(dd))
+            for pr in self.pairs:
+                if pr.active and pr.key == key:
+                    want.add(C.addressof(pr.fdesc))
+                    if pr.bdesc is not None:
+                        want.add(C.addressof(pr.bdesc))
         n = 0
         for seq in (self._fwd_seq, self._bwd_seq):
             if seq is None:

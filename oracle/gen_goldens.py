@@ -34,7 +34,7 @@ with contextlib.redirect_stdout(io.StringIO()):
     from model.layers import layers as RL                                  # reference
     from model.layers import attention as RA                               # reference
 
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("MSAU_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden"))
 os.makedirs(OUT, exist_ok=True)
 torch.set_num_threads(8)
 
@@ -179,6 +179,7 @@ def op_goldens():
 
 if __name__ == "__main__" and os.environ.get("MSAU_GOLDEN_NET", "1") == "1":
     op_goldens()
+if __name__ == "__main__" and os.environ.get("MSAU_GOLDEN_NET", "1") == "1" and os.environ.get("MSAU_GOLDEN_NETS", "1") == "1":
     base = dict(n_class=5, scale_space_num=4, res_depth=2, featRoot=8, filter_size=3, pool_size=2, num_blocks=3)
     # G2: the hyper-parameters the reference instantiates (train_chargrid_funsd_msau.py:211-214), odd size
     net_golden("net_f8_c13_33x26", dict(base, channels=13), 1, 33, 26, seed=11)
@@ -266,13 +267,45 @@ def funsd_goldens():
                 res[f"{split}{i}.feat_sums"] = np.array([f.sum() for f in ds.inp_list[i]["charset_feature"]])
         np.savez_compressed(os.path.join(out_dir, "chargrid.npz"), **res)
         print("wrote funsd goldens", {k: v.shape for k, v in res.items() if k.endswith("mask")})
+        # BERT-embedding variant (BASELINE configs[3]): get_box_mask_box_label paints one `transformer_feature` vector per
+        # text LINE box (data_generator_funsd_bert.py:64-93,240).  No script in the tree produces that pickle field
+        # (SURVEY appendix B), so seeded N(0,1) vectors stand in for the sentence embeddings (24-d keeps the fixture small;
+        # the painter is width-agnostic).
+        bres = {}
+        for split in ("train", "test"):
+            docs = pickle.load(open(f"{split}.pkl", "rb"))
+            for di, d in enumerate(docs):
+                r = np.random.RandomState(500 + di + (0 if split == "train" else 50))
+                d["transformer_feature"] = r.randn(len(d["cells"]), 24).astype(np.float32)
+                bres[f"{split}{di}.feats"] = d["transformer_feature"]
+                bres[f"{split}{di}.cells"] = np.array([[c.x, c.y, c.w, c.h] for c in d["cells"]], np.int64)
+                bres[f"{split}{di}.labels"] = np.array(d["labels"])
+            pickle.dump(docs, open(f"{split}_bert.pkl", "wb"))
+        btr = RD.FUNSDBertDataLoaderBoxMaskBoxLabel("train_bert.pkl")
+        bte = RD.FUNSDBertDataLoaderBoxMaskBoxLabel("test_bert.pkl", btr.labels)
+        bres["labels_json"] = np.array(json.dumps(btr.labels))
+        for split, ds in (("train", btr), ("test", bte)):
+            for i in range(len(ds)):
+                it = ds[i]
+                bres[f"{split}{i}.mask"] = it["mask"].numpy().astype(np.float32)
+                bres[f"{split}{i}.label"] = it["label"].numpy().astype(np.uint8)
+        np.savez_compressed(os.path.join(out_dir, "bertgrid.npz"), **bres)
+        print("wrote bert goldens", {k: v.shape for k, v in bres.items() if k.endswith("mask")})
     finally:
         os.chdir(cwd)
         shutil.rmtree(tmp)
 
 
 if __name__ == "__main__" and os.environ.get("MSAU_GOLDEN_FUNSD", "1") == "1":
-    funsd_goldens()
+    # label ids follow Python set() order (data_generator_funsd_bert.py:196-201): pin the hash seed by running
+    # this part in a child interpreter started with PYTHONHASHSEED=0 (CPU-only script, build container only)
+    if os.environ.get("PYTHONHASHSEED") == "0":
+        funsd_goldens()
+    else:
+        import subprocess
+        env = dict(os.environ, PYTHONHASHSEED="0", MSAU_GOLDEN_NET="0", MSAU_GOLDEN_KV="0", MSAU_GOLDEN_FUNSD="1",
+                   MSAU_GOLDEN_TRAIN="0", PYTHONDONTWRITEBYTECODE="1")
+        subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, check=True)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -430,3 +463,71 @@ def kv_goldens():
 
 if __name__ == "__main__" and os.environ.get("MSAU_GOLDEN_KV", "1") == "1":
     kv_goldens()
+
+
+# ---------------------------------------------------------------------------------------------
+# G6: training-side goldens.  The reference's own `UNetLoss` (model/training/cost.py:35-65) on
+# random logits / one-hot targets, and a dict checkpoint written by the reference's
+# `utils.io_utils.save_checkpoint` (io_utils.py:83-105) for a miniature net after one Adam step.
+# ---------------------------------------------------------------------------------------------
+def train_goldens():
+    import types, tempfile, shutil
+    for name in ("tensorboardX", "cv2"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            if name == "tensorboardX":
+                m.SummaryWriter = lambda *a, **k: None
+            sys.modules[name] = m
+    with contextlib.redirect_stdout(io.StringIO()):
+        from model.training.cost import UNetLoss                    # reference
+        from utils import io_utils as RIO                           # reference
+    out_dir = os.path.join(OUT, "train")
+    os.makedirs(out_dir, exist_ok=True)
+    res = {}
+    g = torch.Generator().manual_seed(4242)
+    crit = UNetLoss({})
+    for tag, (B, C, H, W, with_aux) in (("a", (2, 5, 9, 7, True)), ("b", (1, 17, 6, 11, True)), ("c", (3, 4, 5, 5, False))):
+        logits = (2.0 * torch.randn(B, C, H, W, generator=g)).requires_grad_(True)
+        aux = (2.0 * torch.randn(B, C, H, W, generator=g)).requires_grad_(True) if with_aux else None
+        lab = torch.randint(0, C, (B, H, W), generator=g)
+        tgt = torch.nn.functional.one_hot(lab, C).permute(0, 3, 1, 2).float()
+        kw = {"aux_logits": aux, "aux_tgt": tgt} if with_aux else {}
+        acc, loss, final = crit(logits, tgt, kw)
+        loss.backward()
+        res[f"{tag}.logits"], res[f"{tag}.label"] = logits.detach().numpy(), lab.numpy()
+        res[f"{tag}.acc"], res[f"{tag}.loss"] = float(acc), float(loss)
+        res[f"{tag}.final"] = float(final) if final is not None else np.nan
+        res[f"{tag}.glogits"] = logits.grad.numpy()
+        if with_aux:
+            res[f"{tag}.aux"], res[f"{tag}.gaux"] = aux.detach().numpy(), aux.grad.numpy()
+    np.savez_compressed(os.path.join(out_dir, "unet_loss.npz"), **res)
+    # reference-written checkpoint: miniature net (featRoot 4, 2 scales), one clip + Adam step, then save_checkpoint
+    cfg = dict(channels=6, n_class=3, scale_space_num=2, res_depth=1, featRoot=4, filter_size=3, pool_size=2, num_blocks=3)
+    sd = O.init_params(cfg, 91)
+    net = build_ref(cfg)
+    net.load_state_dict(sd)
+    x, label = O.synthetic_batch(1, cfg["channels"], 12, 10, cfg["n_class"], 92)
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, net.parameters()), lr=1e-4)
+    pred, logits, aux = net(x)
+    loss = net.loss(logits, aux, label)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+    opt.step()
+    args = types.SimpleNamespace(ckptdir=tempfile.mkdtemp(), bmname=None, dataset="funsd", method="msau", hidden_dim=20, output_dim=20)
+    try:
+        RIO.save_checkpoint(net, opt, args, num_epochs=7)
+        src = RIO.create_filename(args.ckptdir, args, False, num_epochs=7)
+        shutil.copy(src, os.path.join(out_dir, "ref_checkpoint.pth.tar"))
+        rel = os.path.relpath(src, args.ckptdir)
+    finally:
+        shutil.rmtree(args.ckptdir)
+    with torch.no_grad():
+        pred2, logits2, aux2 = net(x)
+    np.savez_compressed(os.path.join(out_dir, "ref_checkpoint_meta.npz"), cfg=np.array(repr(cfg)), x=x.numpy(),
+                        logits_after=logits2.numpy(), aux_after=aux2.numpy(), rel_path=np.array(rel),
+                        state_checksum=checksum(net.state_dict()), loss=float(loss))
+    print("wrote train goldens", sorted(res)[:4], rel)
+
+
+if __name__ == "__main__" and os.environ.get("MSAU_GOLDEN_TRAIN", "1") == "1":
+    train_goldens()

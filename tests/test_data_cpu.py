@@ -61,3 +61,27 @@ def test_charset_helpers():
     assert cs == ["A", "a", "b", "c"]
     m = F.transform_from_charset("a?c", inv)
     assert m.shape == (3, 4) and m[1].sum() == 0 and m[0, 1] == 1 and m[2, 3] == 1
+
+
+def test_bert_dense_painter_matches_reference(tmp_path):
+    """`get_box_mask_box_label` / `FUNSDBertDataLoaderBoxMaskBoxLabel` (data_generator_funsd_bert.py:64-93,240: the loader
+    BASELINE.json configs[3] names) against arrays the reference's own loader painted from the same documents and the
+    same per-line feature vectors (tests/golden/funsd/bertgrid.npz)."""
+    g = np.load(os.path.join(G, "bertgrid.npz"), allow_pickle=True)
+    train, inv = F.get_preprocessed_list_word_msau(os.path.join(G, "train"))
+    test, _ = F.get_preprocessed_list_word_msau(os.path.join(G, "test"), inv_dict_charset=inv)
+    labels = json.loads(str(g["labels_json"]))
+    for name, docs in (("train", train), ("test", test)):
+        docs.sort(key=lambda d: d["file_path"])
+        for di, d in enumerate(docs):
+            d["transformer_feature"] = g[f"{name}{di}.feats"]
+            assert np.array_equal(np.array([[c.x, c.y, c.w, c.h] for c in d["cells"]]), g[f"{name}{di}.cells"])
+        with open(tmp_path / f"{name}.pkl", "wb") as fh:
+            pickle.dump(docs, fh)
+        ds = F.FUNSDBertDataLoaderBoxMaskBoxLabel(str(tmp_path / f"{name}.pkl"), labels, write_labels_file=False)
+        for i in range(len(ds)):
+            it = ds[i]
+            assert it["mask"].dtype == torch.float32 and tuple(it["mask"].shape) == tuple(g[f"{name}{i}.mask"].shape)
+            assert np.array_equal(it["mask"].numpy(), g[f"{name}{i}.mask"]), (name, i)             # bit exact
+            assert np.array_equal(it["label"].numpy().astype(np.uint8), g[f"{name}{i}.label"]), (name, i)
+            assert it["ocr_values"] == [c.ocr_value for c in ds.inp_list[i]["cells"]]

@@ -155,3 +155,79 @@ def test_unsupported_width_fails_at_construction():
     with pytest.raises(NotImplementedError, match="support up to 128"):
         MSAUWrapper(4, 3)
     MSAUWrapper(4, 3, dict(scale_space_num=5, featRoot=8))          # 128 channels: inside
+
+
+def test_abi_struct_mirrors_have_the_librarys_sizes():
+    """every struct that crosses the ABI by pointer: ctypes mirror size == sizeof() in the compiled library"""
+    lib = L.load()
+    import ctypes
+    for which, st in enumerate(L.ABI_STRUCTS):
+        assert lib.msau_sizeof(which) == ctypes.sizeof(st), st.__name__
+    assert lib.msau_sizeof(len(L.ABI_STRUCTS)) == -1
+
+
+def test_integration_md_stub_matches_the_header():
+    """The ctypes stub printed in INTEGRATION.md is executed: its msau_conv_desc must have the library's size and the
+    field order of msau_amd._lib.ConvDesc (round 1 shipped a stub 16 bytes short of the struct the library copies)."""
+    import ctypes, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    m = re.search(r"class msau_conv_desc\(C\.Structure\):.*?\n\n", text, re.S)
+    assert m, "INTEGRATION.md no longer contains the msau_conv_desc stub"
+    ns = {"C": ctypes}
+    exec(m.group(0), ns)
+    stub = ns["msau_conv_desc"]
+    assert ctypes.sizeof(stub) == L.load().msau_sizeof(0) == ctypes.sizeof(L.ConvDesc)
+    assert [f[0] for f in stub._fields_] == [f[0] for f in L.ConvDesc._fields_]
+    assert [ctypes.sizeof(f[1]) for f in stub._fields_] == [ctypes.sizeof(f[1]) for f in L.ConvDesc._fields_]
+
+
+def test_reference_written_checkpoint_loads(tmp_path):
+    """A dict checkpoint written by the reference's own utils.io_utils.save_checkpoint (tests/golden/train, generator:
+    oracle/gen_goldens.py::train_goldens) loads into MSAUWrapper: keys epoch / model_type / optimizer / model_state /
+    optimizer_state / cg, the pickled Adam object included (io_utils.py:83-105)."""
+    import ast
+    from msau_amd.training import create_filename, load_checkpoint
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train")
+    meta = np.load(os.path.join(gdir, "ref_checkpoint_meta.npz"), allow_pickle=True)
+    cfg = ast.literal_eval(str(meta["cfg"]))
+    m = MSAUWrapper(cfg["channels"], cfg["n_class"], dict(scale_space_num=cfg["scale_space_num"], res_depth=cfg["res_depth"],
+                                                         featRoot=cfg["featRoot"], final_act="softmax"))
+    ckpt = load_checkpoint(os.path.join(gdir, "ref_checkpoint.pth.tar"), model=m, map_location="cpu")
+    assert set(ckpt) == {"epoch", "model_type", "optimizer", "model_state", "optimizer_state", "cg"}
+    assert ckpt["epoch"] == 7 and ckpt["model_type"] == "msau" and ckpt["cg"] is None
+    assert isinstance(ckpt["optimizer"], torch.optim.Adam)
+    cs = float(sum(float(v.double().abs().sum()) for v in m.state_dict().values()))
+    assert abs(cs - float(meta["state_checksum"])) <= 1e-9 * cs
+    assert list(m.state_dict()) == list(ckpt["model_state"])
+    # the file name rule of io_utils.py:65-80
+    import types
+    args = types.SimpleNamespace(ckptdir=str(tmp_path), bmname=None, dataset="funsd", method="msau", hidden_dim=20, output_dim=20)
+    assert os.path.relpath(create_filename(args.ckptdir, args, False, num_epochs=7), args.ckptdir) == str(meta["rel_path"])
+    assert create_filename(args.ckptdir, args, False, num_epochs=0).endswith("funsd_msau_h20_o20.pth.tar")
+    assert create_filename(args.ckptdir, args, True).endswith(os.path.join("funsd_msau_h20_o20", "best.pth.tar"))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference (build container only)")
+def test_golden_recipe_reproduces_committed_fixtures(tmp_path):
+    """oracle/gen_goldens.py re-run against the reference reproduces ops.npz, the FUNSD fixtures (hash seed pinned in a
+    child interpreter) and the training-side fixtures bit for bit."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for sub in ("train", "test"):
+        os.makedirs(tmp_path / "funsd" / sub)
+    env = dict(os.environ, MSAU_GOLDEN_OUT=str(tmp_path), MSAU_GOLDEN_NETS="0", MSAU_GOLDEN_KV="0", PYTHONDONTWRITEBYTECODE="1",
+               PYTHONHASHSEED="random")
+    subprocess.run([sys.executable, os.path.join(root, "oracle", "gen_goldens.py")], env=env, check=True, cwd=str(tmp_path),
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    gold = os.path.join(root, "tests", "golden")
+    for rel in ("ops.npz", os.path.join("funsd", "chargrid.npz"), os.path.join("funsd", "bertgrid.npz"),
+                os.path.join("train", "unet_loss.npz")):
+        a = np.load(os.path.join(gold, rel), allow_pickle=True)
+        b = np.load(os.path.join(str(tmp_path), rel), allow_pickle=True)
+        assert sorted(a.files) == sorted(b.files), rel
+        for k in a.files:
+            if a[k].dtype == object or a[k].dtype.kind in "US":
+                assert str(a[k]) == str(b[k]), (rel, k)
+            else:
+                assert np.array_equal(a[k], b[k], equal_nan=True), (rel, k)

@@ -201,8 +201,13 @@ def test_train_script_end_to_end_on_synthetic_funsd(tmp_path, monkeypatch):
         assert l1 < l0, (loop, l0, l1)
         # epoch 0 and the final dict checkpoint share one file name (the reference's own quirk,
         # utils/io_utils.py:74-77: only epochs > 0 get a number): the final write wins
-        ck = torch.load(T.ckpt_filename(args.ckptdir, args, 0))
+        from msau_amd.training import load_checkpoint
+        ck = load_checkpoint(T.ckpt_filename(args.ckptdir, args, 0))
         assert set(ck["model_state"].keys()) == set(m.state_dict().keys()) and ck["epoch"] == -1
+        # the reference's keys (utils/io_utils.py:94-101); the engine loop stores its Adam moments as a tensor dict
+        assert set(ck) == {"epoch", "model_type", "optimizer", "model_state", "optimizer_state", "cg"}
+        assert (ck["optimizer"] is None and ck["optimizer_state"]["engine"] == 1) if loop == "engine" else \
+            isinstance(ck["optimizer"], torch.optim.Adam)
 
 
 def test_graph_replay_after_host_sync_matches_eager_at_bench_size():
@@ -364,3 +369,48 @@ def test_bench_size_step_runs_in_both_storage_types():
         del eng, m
         torch.cuda.empty_cache()
     assert abs(losses["fp32"] - losses["bf16"]) < 2e-2 * losses["fp32"], losses
+
+
+@pytest.mark.parametrize("dtype,B,channels,H,W", [
+    ("bf16", 16, 64, 336, 256),      # the bench workload: C = 8 / 16 (30-pixel tiles; MSAU_PAIR_MAXC=32 adds the 32-channel level)
+    ("bf16", 4, 13, 333, 251),       # odd at every level: partial tiles on both axes, tiles straddling the image border
+    ("fp32", 4, 13, 333, 251),       # fp32 storage: C = 8 (30-pixel tiles) and 16 (14-pixel tiles); 32 does not fit the LDS
+    ("bf16", 32, 8, 45, 150),        # narrow images: the 14-pixel-tile instance of the 8-channel layers
+])
+def test_fused_residual_pair_is_bit_identical_to_two_launches(monkeypatch, dtype, B, channels, H, W):
+    """msau_conv_pair (both convs of a residual block in one launch, forward and data gradient; csrc/conv_pair.hip) against
+    the one-conv-per-launch path: same MFMA sequences, same roundings -> identical bits in every activation, every
+    gradient and the updated parameters."""
+    from oracle import msau_oracle as O
+    x, label = O.synthetic_batch(B, channels, H, W, 5, seed=5)
+    x, label = x.cuda(), label.cuda()
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("MSAU_FUSE_PAIR", fuse)
+        kw = dict(scale_space_num=4, res_depth=2, featRoot=8, final_act="softmax", num_blocks=3, dtype=dtype, seed=3,
+                  deterministic=True)
+        m = MSAUWrapper(channels, 5, kw).cuda()
+        eng = TrainEngine(m)
+        loss = eng.step(x, label)
+        torch.cuda.synchronize()
+        plan = m._plan_for(x, True)
+        n_act = sum(1 for pr in plan.pairs if pr.active)
+        n_bwd = sum(1 for pr in plan.pairs if pr.active and pr.bdesc is not None)
+        if fuse == "1":
+            assert n_act >= 6 and n_bwd == n_act, (n_act, n_bwd, len(plan.pairs))
+            widths = {pr.c1.x1.Cs for pr in plan.pairs if pr.active}
+            assert {8, 16} <= widths or (channels == 8 and 8 in widths), widths
+        else:
+            assert n_act == 0
+        acts = {a.name: (a.data.clone(), a.grad.clone() if a.grad is not None else None) for a in plan.acts}
+        with torch.no_grad():
+            pred = m.predict_nhwc(x)[0].clone()             # forward-only plan (buffer reuse) takes the fused path too
+        outs.append((float(loss), eng.flat_grad.clone(), m.flat_parameters.clone(), acts, pred))
+        del eng, m, plan
+        torch.cuda.empty_cache()
+    (l1, g1, p1, a1, q1), (l0, g0, p0, a0, q0) = outs
+    for name in a0:
+        assert torch.equal(a1[name][0], a0[name][0]), ("activation", name)
+        if a0[name][1] is not None:
+            assert torch.equal(a1[name][1], a0[name][1]), ("gradient", name)
+    assert l1 == l0 and torch.equal(g1, g0) and torch.equal(p1, p0) and torch.equal(q1, q0)

@@ -1,0 +1,281 @@
+"""GPU: training-side parity that round 1 left thin (VERDICT r1 "what's weak" 1, "next" 3 and 7):
+  * bf16 (the benchmarked storage type): every parameter gradient against the reference's fixtures, a 20-step loss
+    trajectory against fp32 storage, and a per-parameter comparison at the bench size so that the bf16-only kernel
+    instances (16x32 tiles, two-output data gradients, channel-split, strided / upsampling) are each hit;
+  * `UNetLoss` against values the reference's own model/training/cost.py produced;
+  * a checkpoint written by the reference's utils.io_utils.save_checkpoint, loaded and resumed;
+  * plan-cache / graph-cache / saved-activation hazards."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from msau_amd.model import MSAUWrapper, TrainEngine
+from tests.golden_util import GOLDEN, load_net_case, rel_err, rel_l2, summarize
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(cfg, sd, dtype, **extra):
+    kw = dict(scale_space_num=cfg["scale_space_num"], res_depth=cfg["res_depth"], featRoot=cfg["featRoot"],
+              filter_size=cfg["filter_size"], pool_size=cfg["pool_size"], final_act="softmax",
+              num_blocks=cfg["num_blocks"], dtype=dtype, **extra)
+    m = MSAUWrapper(cfg["channels"], cfg["n_class"], kw)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda()
+
+
+def _param_grads(m, eng):
+    return {k: eng.flat_grad[m._poff[k]:m._poff[k] + p.numel()].view(p.shape) for k, p in m.named_parameters()}
+
+
+# ---- (a) bf16 gradients of every parameter against the reference's fixtures ------------------------------------------
+# Tolerances (stated, bf16 storage / fp32 accumulate, ~60 sequential convs): the reference fixture holds each gradient's
+# L2 norm and 64 strided samples.  Per tensor: norm within NORM_TOL of the reference's, samples within SAMPLE_TOL in
+# relative L2 (plus a floor of FLOOR x the largest gradient norm, for tensors whose gradient is rounding noise);
+# whole network: global norm within 3e-2.
+BF16_NORM_TOL, BF16_SAMPLE_TOL, BF16_FLOOR = 1e-1, 1.5e-1, 2e-3
+
+
+@pytest.mark.parametrize("name", ["net_cfg2_336x256x64", "net_f4_c13_b2_64x48"])
+def test_bf16_parameter_gradients_match_reference(name):
+    g, cfg, sd, x, label = load_net_case(name)
+    m = _model(cfg, sd, "bf16")
+    eng = TrainEngine(m, lr=1e-4)
+    loss = eng.step(x.cuda(), label.cuda())
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(g["loss"])) < 3e-2 * abs(float(g["loss"]))
+    assert abs(float(eng.grad_norm) - float(g["grad_norm"])) < 3e-2 * float(g["grad_norm"])
+    grads = _param_grads(m, eng)
+    names = [str(s) for s in g["param_names"]]
+    dead = set(str(s) for s in g["dead_params"])
+    gmax = max(float(s[0]) for s in g["grad_summary"])
+    worst = (0.0, 0.0)
+    for i, k in enumerate(names):
+        if k in dead:
+            assert float(grads[k].abs().max()) == 0.0, k
+            continue
+        s, smp = summarize(grads[k])
+        ref_n, ref_smp = float(g["grad_summary"][i][0]), np.asarray(g["grad_samples"][i], np.float64)
+        dn = abs(s[0] - ref_n)
+        ds = float(np.linalg.norm(smp - ref_smp))
+        floor = BF16_FLOOR * gmax
+        assert dn <= BF16_NORM_TOL * ref_n + floor, (k, s[0], ref_n)
+        assert ds <= BF16_SAMPLE_TOL * float(np.linalg.norm(ref_smp)) + floor * np.sqrt(len(smp) / max(grads[k].numel(), 1)) + \
+            1e-3 * float(np.abs(ref_smp).max()), (k, ds, float(np.linalg.norm(ref_smp)))
+        worst = (max(worst[0], dn / (ref_n + floor)), max(worst[1], ds / (float(np.linalg.norm(ref_smp)) + floor)))
+    print(f"{name}: worst per-tensor norm deviation {worst[0]:.3e}, worst sample rel-L2 {worst[1]:.3e}")
+
+
+# ---- (b) 20 steps, fp32 vs bf16 storage, same weights, same batch ------------------------------------------------------
+def test_bf16_loss_trajectory_tracks_fp32_over_20_steps():
+    g, cfg, sd, x, label = load_net_case("net_f4_c13_b2_64x48")
+    traj = {}
+    for dtype in ("fp32", "bf16"):
+        m = _model(cfg, sd, dtype)
+        eng = TrainEngine(m, lr=1e-3)
+        losses = [eng.step(x.cuda(), label.cuda()).clone() for _ in range(20)]
+        torch.cuda.synchronize()
+        traj[dtype] = np.array([float(l) for l in losses])
+    f, b = traj["fp32"], traj["bf16"]
+    assert abs(f[0] - float(g["loss"])) < 1e-4 * float(g["loss"])
+    assert f[-1] < 0.9 * f[0], f                                       # it trains
+    gap = np.abs(f - b) / f
+    print("fp32", np.round(f, 4), "\nbf16", np.round(b, 4), "\nmax rel gap", gap.max())
+    assert gap.max() < 1e-2, (f, b)                                    # stated tolerance: 1e-2 of the loss at every step (observed 1.5e-3)
+
+
+# ---- (c) bench size: every parameter gradient, bf16 storage vs the fp32-storage engine -----------------------------------
+def test_bench_size_bf16_gradients_track_fp32_storage_per_parameter():
+    """B=16, 336x256x64, 3 stages: the workload bench.py times.  This is the only size at which the 16x32-tile (WGW=2),
+    two-output (DOUT), channel-split (SPLIT) and strided / upsampling bf16 instances are all selected."""
+    from oracle import msau_oracle as O
+    from msau_amd.plan import ConvOp
+    x, label = O.synthetic_batch(16, 64, 336, 256, 5, seed=3)
+    x, label = x.cuda(), label.cuda()
+    res = {}
+    for dtype in ("fp32", "bf16"):
+        kw = dict(scale_space_num=4, res_depth=2, featRoot=8, final_act="softmax", num_blocks=3, dtype=dtype, seed=0)
+        m = MSAUWrapper(64, 5, kw).cuda()
+        eng = TrainEngine(m)
+        loss = eng.step(x, label)
+        torch.cuda.synchronize()
+        if dtype == "bf16":
+            plan = m._plan_for(x, True)
+            keys = {op.fkey for op in plan.ops if isinstance(op, ConvOp)} | \
+                   {dm[0] for op in plan.ops if isinstance(op, ConvOp) for dm in op.dmeta if dm is not None}
+            for want in ("dout", "ups2", "s2", "dual"):
+                assert any(want in k for k in keys), (want, sorted(keys))
+        res[dtype] = (float(loss), float(eng.grad_norm), {k: v.clone() for k, v in _param_grads(m, eng).items()})
+        del eng, m
+        torch.cuda.empty_cache()
+    (lf, nf, gf), (lb, nb, gb) = res["fp32"], res["bf16"]
+    assert abs(lf - lb) < 2e-2 * lf and abs(nf - nb) < 3e-2 * nf, (lf, lb, nf, nb)
+    gmax = max(float(v.norm()) for v in gf.values())
+    worst = 0.0
+    for k, ref in gf.items():
+        if float(ref.abs().max()) == 0.0:
+            assert float(gb[k].abs().max()) == 0.0, k
+            continue
+        e = float((gb[k] - ref).norm()) / (float(ref.norm()) + 2e-3 * gmax)
+        worst = max(worst, e)
+        assert e < 1e-1, (k, e)                                        # stated tolerance: rel-L2 1e-1 per tensor
+    print("bench-size bf16 vs fp32 storage: worst per-parameter rel-L2", worst)
+
+
+# ---- N3: UNetLoss against the reference's own values -----------------------------------------------------------------------
+def test_unet_loss_matches_reference_fixture():
+    """model/training/cost.py:35-65 run by oracle/gen_goldens.py::train_goldens -> (acc, loss, final, gradients)"""
+    from msau_amd.training import UNetLoss
+    g = np.load(os.path.join(GOLDEN, "train", "unet_loss.npz"))
+    crit = UNetLoss({})
+    for tag in ("a", "b", "c"):
+        lg = torch.from_numpy(g[f"{tag}.logits"]).cuda().requires_grad_(True)
+        lab = torch.from_numpy(g[f"{tag}.label"]).cuda()
+        C = lg.shape[1]
+        tgt = torch.nn.functional.one_hot(lab, C).permute(0, 3, 1, 2).float()
+        with_aux = f"{tag}.aux" in g.files
+        ax = torch.from_numpy(g[f"{tag}.aux"]).cuda().requires_grad_(True) if with_aux else None
+        acc, loss, final = crit(lg, tgt, {"aux_logits": ax, "aux_tgt": tgt} if with_aux else {})
+        loss.backward()
+        assert abs(acc - float(g[f"{tag}.acc"])) < 1e-6, tag
+        assert abs(float(loss) - float(g[f"{tag}.loss"])) < 1e-5 * abs(float(g[f"{tag}.loss"])), tag
+        if with_aux:
+            assert abs(float(final) - float(g[f"{tag}.final"])) < 1e-5 * abs(float(g[f"{tag}.final"])), tag
+            assert rel_err(ax.grad.cpu(), g[f"{tag}.gaux"]) < 1e-5, tag
+        else:
+            assert final is None and np.isnan(g[f"{tag}.final"])
+        assert rel_err(lg.grad.cpu(), g[f"{tag}.glogits"]) < 1e-5, tag
+
+
+# ---- N3: a checkpoint the reference wrote --------------------------------------------------------------------------------------
+def test_reference_checkpoint_resumes_on_the_engine(tmp_path):
+    """utils.io_utils.save_checkpoint's file (after one clip + Adam step of the reference): the HIP network reproduces the
+    reference's post-step logits, TrainEngine takes over the Adam moments, and our own checkpoint round-trips."""
+    import types
+    from msau_amd.training import load_checkpoint, save_checkpoint
+    gdir = os.path.join(GOLDEN, "train")
+    meta = np.load(os.path.join(gdir, "ref_checkpoint_meta.npz"), allow_pickle=True)
+    cfg = ast.literal_eval(str(meta["cfg"]))
+    m = MSAUWrapper(cfg["channels"], cfg["n_class"], dict(scale_space_num=cfg["scale_space_num"], res_depth=cfg["res_depth"],
+                                                         featRoot=cfg["featRoot"], final_act="softmax", dtype="fp32")).cuda()
+    eng = TrainEngine(m, lr=3e-3)
+    ck = load_checkpoint(os.path.join(gdir, "ref_checkpoint.pth.tar"), model=m, optimizer=eng)
+    x = torch.from_numpy(meta["x"]).cuda()
+    with torch.no_grad():
+        _, logits, aux = m(x)
+    assert rel_err(logits.cpu(), meta["logits_after"]) < 2e-4 and rel_err(aux.cpu(), meta["aux_after"]) < 2e-4
+    # Adam state: per-parameter moments by registration order, step count, hyper-parameters of the reference's optimizer
+    assert eng.lr == 1e-4 and float(eng.state[0]) == 1.0
+    st = ck["optimizer_state"]
+    live = [(k, p) for k, p in m._named]
+    order = [pid for grp in st["param_groups"] for pid in grp["params"]]
+    assert len(order) == len(live)
+    n_seen = 0
+    for pid, (k, p) in zip(order, live):
+        off, n = m._poff[k], p.numel()
+        if pid in st["state"]:
+            assert torch.equal(eng.m[off:off + n].cpu(), st["state"][pid]["exp_avg"].reshape(-1).cpu()), k
+            assert torch.equal(eng.v[off:off + n].cpu(), st["state"][pid]["exp_avg_sq"].reshape(-1).cpu()), k
+            n_seen += 1
+        else:
+            assert k in m._dead and float(eng.m[off:off + n].abs().max()) == 0.0, k
+    assert n_seen == len(live) - len(m._dead)
+    # our writer: same keys, resumable
+    lab = (torch.rand(1, x.shape[2], x.shape[3], device="cuda") * cfg["n_class"]).long()
+    eng.step(x, lab)
+    args = types.SimpleNamespace(ckptdir=str(tmp_path), bmname=None, dataset="funsd", method="msau", hidden_dim=20, output_dim=20)
+    path = save_checkpoint(m, eng, args, num_epochs=8)
+    m2 = MSAUWrapper(cfg["channels"], cfg["n_class"], dict(scale_space_num=cfg["scale_space_num"], res_depth=cfg["res_depth"],
+                                                          featRoot=cfg["featRoot"], final_act="softmax", dtype="fp32")).cuda()
+    eng2 = TrainEngine(m2)
+    ck2 = load_checkpoint(path, model=m2, optimizer=eng2)
+    assert set(ck2) == set(ck) and ck2["epoch"] == 8
+    assert torch.equal(m2.flat_parameters, m.flat_parameters) and torch.equal(eng2.m, eng.m) and torch.equal(eng2.v, eng.v)
+    assert float(eng2.state[0]) == 2.0 and eng2.lr == eng.lr
+    l1, l2 = eng.step(x, lab), eng2.step(x, lab)
+    torch.cuda.synchronize()
+    assert float(l1) == float(l2) and torch.equal(m2.flat_parameters, m.flat_parameters)
+
+
+# ---- stale graphs, plan thrash, overwritten saved activations --------------------------------------------------------
+def test_train_graphs_die_with_their_plan():
+    """use_graph=True with more shapes than the plan cache holds: returning to an evicted shape must rebuild plan AND
+    graph (round 1 kept the graph keyed by shape and replayed it into freed buffers)."""
+    from oracle import msau_oracle as O
+    g, cfg, sd, x, label = load_net_case("net_f4_c13_b2_64x48")
+    shapes = [(24, 40), (33, 31), (17, 48), (40, 24), (25, 25), (24, 40)]
+    res = {}
+    for use_graph in (False, True):
+        m = _model(cfg, sd, "fp32", deterministic=True)
+        m.max_cached_plans = 2
+        eng = TrainEngine(m, use_graph=use_graph)
+        out = []
+        for (H, W) in shapes:
+            xs, ls = O.synthetic_batch(2, cfg["channels"], H, W, cfg["n_class"], H * 100 + W)
+            out.append(float(eng.step(xs.cuda(), ls.cuda())))
+        torch.cuda.synchronize()
+        assert len(m._plans) <= 2
+        res[use_graph] = (out, m.flat_parameters.clone())
+    assert res[False][0] == res[True][0], res
+    assert torch.equal(res[False][1], res[True][1])
+
+
+def test_backward_after_a_second_forward_of_the_same_shape_raises():
+    g, cfg, sd, x, label = load_net_case("net_f8_c13_33x26")
+    m = _model(cfg, sd, "fp32")
+    xa, xb = x.cuda(), (x * 0.5).cuda()
+    _, la, aa = m(xa)
+    _, lb, ab = m(xb)                                    # overwrites the activations the first backward would read
+    loss_a = m.loss(la, aa, label.cuda())
+    with pytest.raises(RuntimeError, match="overwritten"):
+        loss_a.backward()
+    m.zero_grad()
+    m.loss(lb, ab, label.cuda()).backward()              # the latest forward is fine
+    assert all(p.grad is not None for k, p in m.named_parameters() if k not in m._dead)
+
+
+def test_plan_cache_is_bounded_by_bytes_as_well_as_count():
+    g, cfg, sd, x, label = load_net_case("net_f4_c13_b2_64x48")
+    m = _model(cfg, sd, "fp32")
+    m.max_cached_plans = 64
+    with torch.no_grad():
+        m(x.cuda())
+        one = sum(p.activation_bytes() for p in m._plans.values())
+        m.max_plan_bytes = int(2.5 * one)
+        for k in range(1, 6):
+            m(x[:, :, :64 - k, :].contiguous().cuda())
+    assert 1 <= len(m._plans) <= 3 and sum(p.activation_bytes() for p in m._plans.values()) <= m.max_plan_bytes
+
+
+# ---- N1: dense (BERT) painter on the device ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_device_dense_rasteriser_matches_cpu_painter(dtype, tmp_path):
+    """msau_raster_dense + msau_raster_labels against `funsd.get_box_mask_box_label`, which tests/test_data_cpu.py pins to
+    the reference's own loader output"""
+    import json, pickle
+    from msau_amd.data import funsd as F
+    from msau_amd.data.raster import document_line_boxes, rasterize_dense
+    G = os.path.join(GOLDEN, "funsd")
+    g = np.load(os.path.join(G, "bertgrid.npz"), allow_pickle=True)
+    docs, inv = F.get_preprocessed_list_word_msau(os.path.join(G, "train"))
+    docs.sort(key=lambda d: d["file_path"])
+    for di, d in enumerate(docs):
+        d["transformer_feature"] = g[f"train{di}.feats"]
+    with open(tmp_path / "t.pkl", "wb") as fh:
+        pickle.dump(docs, fh)
+    ds = F.FUNSDBertDataLoaderBoxMaskBoxLabel(str(tmp_path / "t.pkl"), json.loads(str(g["labels_json"])), write_labels_file=False)
+    for i in range(len(ds)):
+        it = ds[i]
+        fb, lb, H, W = document_line_boxes(ds.inp_list[i])
+        feats = np.asarray(ds.inp_list[i]["transformer_feature"], np.float32)
+        grid, labels = rasterize_dense(fb, lb, feats, 1, H, W, dtype)
+        C = feats.shape[1]
+        want = it["mask"][0].permute(1, 2, 0)                               # [H,W,C]
+        if dtype == "bf16":
+            want = want.to(torch.bfloat16)
+        assert torch.equal(grid[0, :, :, :C].float().cpu(), want.float()), i   # bit exact in the storage type
+        assert float(grid[0, :, :, C:].abs().max()) == 0.0 if grid.shape[3] > C else True
+        assert torch.equal(labels[0].cpu(), it["label"][0].long()), i

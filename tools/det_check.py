@@ -35,14 +35,26 @@ def run(out):
 
 
 def cmp(files):
+    """group the processes into classes of bit-identical results; report every minority class against the largest one"""
     ds = [torch.load(f) for f in files]
-    ref, n_bad = ds[0], 0
-    for f, d in zip(files[1:], ds[1:]):
-        bad = [k for k in ref if not torch.equal(ref[k], d[k])]
-        n_bad += bool(bad)
-        print(f, "identical" if not bad else f"{len(bad)} tensors differ; activations: {[k for k in bad if k.startswith('act:')][:4]}; "
-              f"last gradients in backward order: {[k for k in bad if k.startswith('grad:')][-2:]}")
-    print(f"{n_bad} of {len(files) - 1} processes differ from the first")
+    keys = list(ds[0])
+    classes = []                                   # [(representative index, [member indices])]
+    for i, d in enumerate(ds):
+        for rep, members in classes:
+            if all(torch.equal(ds[rep][k], d[k]) for k in keys):
+                members.append(i)
+                break
+        else:
+            classes.append((i, [i]))
+    classes.sort(key=lambda c: -len(c[1]))
+    ref = ds[classes[0][0]]
+    print(f"{len(files)} processes, {len(classes)} distinct result(s); class sizes {[len(m) for _, m in classes]}")
+    for rep, members in classes[1:]:
+        d = ds[rep]
+        bad = [k for k in keys if not torch.equal(ref[k], d[k])]
+        print(f"  class of {[files[m] for m in members]}: {len(bad)} tensors differ from the majority; activations: "
+              f"{[k for k in bad if k.startswith('act:')][:4]}; last gradients in backward order: {[k for k in bad if k.startswith('grad:')][-2:]}")
+    print(f"{len(files) - len(classes[0][1])} of {len(files)} processes differ from the majority")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Micro-benchmark: msau_conv_pair (two chained 3x3 convs, one launch) against the two msau_conv2d launches it replaces,
+forward flags and data-gradient flags, on the residual-block shapes of cfg 2 (B=16).  Serialised, device time by events.
+
+    python tools/pair_bench.py [reps]
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from msau_amd import _lib as L
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+dev = torch.device("cuda")
+s = torch.cuda.current_stream().cuda_stream
+B = 16
+
+
+def timed(fn):
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    L.call("msau_spin", s, 3000)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+for (H, W, Cc) in ((336, 256, 8), (168, 128, 16), (84, 64, 32)):
+    n = B * H * W * Cc
+    t = lambda: (torch.randn(B, H, W, Cc, device=dev) * 0.5).to(torch.bfloat16)
+    x, r1, out, g, gr1, gx = t(), t(), t(), t(), t(), t()
+    kchunk = -(-9 * Cc // 32) * 32
+    rows = max(16, Cc)
+    w1 = (torch.randn(rows * kchunk, device=dev) * 0.05).to(torch.bfloat16)
+    w2 = (torch.randn(rows * kchunk, device=dev) * 0.05).to(torch.bfloat16)
+    b1 = torch.zeros(rows, device=dev)
+    b2 = torch.zeros(rows, device=dev)
+
+    def conv_desc(xi, wi, bi, yo, flags, add=None, mask_a=None, mask_b=None):
+        d = L.ConvDesc()
+        d.B, d.Hin, d.Win, d.Hout, d.Wout = B, H, W, H, W
+        d.C1, d.C2, d.Cout = Cc, 0, Cc
+        d.KH = d.KW = 3
+        d.dil, d.pad_t, d.pad_l, d.stride, d.ups = 1, 1, 1, 1, 1
+        d.flags = flags
+        d.x1, d.wpack, d.bias, d.y = xi.data_ptr(), wi.data_ptr(), bi.data_ptr() if bi is not None else None, yo.data_ptr()
+        d.add = add.data_ptr() if add is not None else None
+        d.mask_a = mask_a.data_ptr() if mask_a is not None else None
+        d.mask_b = mask_b.data_ptr() if mask_b is not None else None
+        return d
+
+    def pair_desc(fwd):
+        p = L.ConvPairDesc()
+        p.B, p.H, p.W, p.C = B, H, W, Cc
+        if fwd:
+            p.flags1, p.flags2 = L.PAIR_RELU_IN | L.PAIR_RELU_MID, L.CONV_ADD | L.CONV_RELU_OUT
+            p.x, p.w1, p.b1, p.mid = x.data_ptr(), w1.data_ptr(), b1.data_ptr(), r1.data_ptr()
+            p.w2, p.b2, p.add, p.y = w2.data_ptr(), b2.data_ptr(), x.data_ptr(), out.data_ptr()
+        else:
+            p.flags1, p.flags2 = L.PAIR_MASK_MID, L.CONV_MASK_A | L.CONV_ADD
+            p.x, p.w1, p.b1, p.mask_mid, p.mid = g.data_ptr(), w2.data_ptr(), None, r1.data_ptr(), gr1.data_ptr()
+            p.w2, p.b2, p.add, p.mask_a, p.y = w1.data_ptr(), None, g.data_ptr(), x.data_ptr(), gx.data_ptr()
+        return p
+
+    f1 = conv_desc(x, w1, b1, r1, L.CONV_RELU_IN | L.CONV_RELU_OUT)
+    f2 = conv_desc(r1, w2, b2, out, L.CONV_ADD | L.CONV_RELU_OUT, add=x)
+    d2 = conv_desc(g, w2, None, gr1, L.CONV_MASK_B, mask_b=r1)
+    d1 = conv_desc(gr1, w1, None, gx, L.CONV_MASK_A | L.CONV_ADD, add=g, mask_a=x)
+    pf, pb = pair_desc(True), pair_desc(False)
+    lib = L.load()
+    assert lib.msau_conv_pair_applicable(L.BF16, C.byref(pf))
+
+    def two(a, b):
+        L.check(lib.msau_conv2d(s, L.BF16, C.byref(a)))
+        L.check(lib.msau_conv2d(s, L.BF16, C.byref(b)))
+
+    res = {}
+    res["fwd 2 launches"] = timed(lambda: two(f1, f2))
+    res["fwd pair"] = timed(lambda: L.check(lib.msau_conv_pair(s, L.BF16, C.byref(pf))))
+    res["bwd 2 launches"] = timed(lambda: two(d2, d1))
+    res["bwd pair"] = timed(lambda: L.check(lib.msau_conv_pair(s, L.BF16, C.byref(pb))))
+    mb = n * 2 / 1e6
+    print(f"C={Cc} {H}x{W}: tensor {mb:.1f} MB | " + " | ".join(f"{k} {v:.1f} us" for k, v in res.items()))

@@ -23,6 +23,7 @@ import torch
 from msau_amd import MSAUWrapper as MSAU
 from msau_amd import TrainEngine
 from msau_amd.data import FUNSDCharGridDataLoaderBoxMaskBoxLabel
+from msau_amd.training import save_checkpoint
 
 
 def ckpt_filename(save_dir, args, epoch=-1, isbest=False):
@@ -104,8 +105,8 @@ def train(dataset, model, args, val_dataset=None, test_dataset=None, labels_map=
         print("Best val result: ", best_val)
         if epoch % 10 == 0:
             torch.save(model.state_dict(), ckpt_filename(args.ckptdir, args, epoch))
-    torch.save({"epoch": -1, "model_type": args.method, "model_state": model.state_dict()},
-               ckpt_filename(args.ckptdir, args, -1))
+    # final dict checkpoint with the reference's keys (utils/io_utils.py:83-105, called at train_...py:116)
+    save_checkpoint(model, engine if args.loop == "engine" else optimizer, args, num_epochs=-1)
     return model, val_accs
 
 
@@ -146,6 +147,12 @@ def main():
     test_instances = [data_loader_test[i] for i in range(len(data_loader_test))]
     print("Num training instances: ", len(train_instances), "; Num validation instances: ", len(val_instances),
           "; Num testing instances: ", len(test_instances))
+    # batch 1 with a different H x W per document (data_generator_funsd_bert.py:216-222): every shape has its own static
+    # plan (buffers + launch list).  Keep them all -- one training and one forward-only plan per distinct shape, bounded
+    # by model.max_plan_bytes -- instead of rebuilding a plan on every step of every epoch.
+    shapes = {tuple(d["mask"].shape[2:]) for d in train_instances + val_instances + test_instances}
+    model.max_cached_plans = max(model.max_cached_plans, 2 * len(shapes))
+    print("Distinct document shapes: ", len(shapes))
     train(train_instances, model, args, val_dataset=val_instances, test_dataset=test_instances,
           labels_map=data_loader.labels)
     print("Finished\n\n")
