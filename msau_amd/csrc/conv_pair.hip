@@ -53,7 +53,8 @@ struct PairCfg {
     static constexpr int OFF_W = 2 * X_BYTES;
     static constexpr int OFF_M = OFF_W + 2 * W_BYTES;
     static constexpr int OFF_B = OFF_M + 2 * M_BYTES;
-    static constexpr int LDS = OFF_B + 2 * C * 4;
+    static constexpr int LDS = OFF_B + 2 * C * 4;              // + LDS_PAD bytes of dummy slots for lanes that own nothing
+    static constexpr int LDS_PAD = 1024;
     static constexpr int NITX = (NPIX * C8 + NT - 1) / NT;    // prefetch registers (16 B each): input tile
     static constexpr int NITM = BWD ? (16 * IW * C8) / NT : 0;                 //                 each mask tile
 };
@@ -63,6 +64,34 @@ template <typename T> __device__ __forceinline__ unsigned positive_bits(typename
 #pragma unroll
     for (int e = 0; e < 8; ++e) b |= ((float)v[e] > 0.f ? 1u : 0u) << e;
     return b;
+}
+
+// ---- raw buffer accesses: an out-of-range offset makes a load return 0 and drops a store IN HARDWARE, so the zero
+// padding, the partial tiles and the "not my pixel" lanes need no branch.  That matters beyond instruction count: with
+// every VMEM instruction in straight-line code the compiler knows how many stores follow the prefetch loads and waits
+// for the loads with vmcnt(N) instead of vmcnt(0) -- a wait that would otherwise also sit out the write
+// acknowledgements of the stores issued a moment ago (measured: 8 us -> 5.7 us -> ... per tile, see the header).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned kOOB = 0x80000000u;                     // >= any num_records here (images are < 2^31 bytes), +16 does not wrap
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t image_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);     // gfx9 raw buffer, 32-bit format
+}
+template <typename T> __device__ __forceinline__ typename Vec8<T>::type buf_load8(__amdgpu_buffer_rsrc_t r, unsigned off);
+template <> __device__ __forceinline__ bf16x8 buf_load8<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+template <> __device__ __forceinline__ f32x8 buf_load8<float>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, 0));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned off, bf16x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, off, 0, 0);
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
 }
 
 template <typename T, int C8, int TW, bool BWD>
@@ -83,6 +112,7 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
     const int wave = wave_all & 3, cwt = wave_all >> 2;
     const int lr = lane & 15, lg = lane >> 4;
     const int H = d.H, W = d.W;
+    const unsigned img_bytes = (unsigned)H * (unsigned)a.row;
 
     // ---- weights and biases of both convs: LDS, once per persistent workgroup
     {
@@ -111,7 +141,10 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
     const int pix_off = ((wave * 4) * XW + cwt * 16 + lr) * PS;      // lattice (wave*4 + pt, cwt*16 + lr), pt adds XW*PS
     const int ch0 = lg * (CT * 4);                                  // this lane's first channel (ct adds 4)
     const bool ch_ok = C8 > 1 || lg < 2;                            // 8-channel layers fill half of the 16 MFMA rows
-    const int lane_c = (cwt * 16 + lr) * a.px + ch0 * ESZ;          // per-lane part of the global epilogue addresses
+    const int jcol = cwt * 16 + lr;                                 // this lane's lattice / tile column
+    const int lane_c = jcol * a.px + ch0 * ESZ;                     // per-lane part of the global epilogue offsets
+    // LDS slot of this lane in the intermediate tile (row i adds XW*PS); lanes without channels write a dummy slot
+    const int rt_lane = ch_ok ? Cfg::X_BYTES + jcol * PS + ch0 * ESZ : Cfg::LDS + (lane & 15) * 16;
 
     V8 pre_x[Cfg::NITX];
     V8 pre_m[BWD ? Cfg::NITM : 1], pre_a[BWD ? Cfg::NITM : 1];
@@ -121,40 +154,53 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
         b = a.tiles_y > 1 ? __umulhi((unsigned)t1, a.mag_ty) : t1;
         ty0 = (t1 - b * a.tiles_y) * Cfg::OH;
     };
-    auto issue_loads = [&](int tile) {
+    // all loads of one tile; `live` false (no next tile) turns every offset out of range: nothing is fetched
+    auto issue_loads = [&](int tile, bool live) {
         int b, ty0, tx0;
-        decode(tile, b, ty0, tx0);
-        const long long img = (long long)b * H * a.row;
-        const char* base = static_cast<const char*>(d.x) + img;
+        decode(live ? tile : 0, b, ty0, tx0);
+        const long long img = (long long)b * img_bytes;
+        const __amdgpu_buffer_rsrc_t rx = image_rsrc(static_cast<const char*>(d.x) + img, live ? img_bytes : 0u);
         constexpr int NITEMS = Cfg::NPIX * C8;
 #pragma unroll
         for (int it = 0; it < Cfg::NITX; ++it) {
             const int idx = tid + it * NT;
-            pre_x[it] = zero8<T>();
-            if ((it + 1) * NT <= NITEMS || idx < NITEMS) {
-                const int pix = idx / C8, cg = idx - pix * C8;
-                const int iy = pix / XW, ix = pix - iy * XW;
-                const int vy = ty0 - 2 + iy, vx = tx0 - 2 + ix;
-                if ((unsigned)vy < (unsigned)H && (unsigned)vx < (unsigned)W)
-                    pre_x[it] = *reinterpret_cast<const V8*>(base + (unsigned)(vy * a.row + vx * a.px + cg * 8 * ESZ));
-            }
+            const int pix = idx / C8, cg = idx - pix * C8;
+            const int iy = pix / XW, ix = pix - iy * XW;
+            const int vy = ty0 - 2 + iy, vx = tx0 - 2 + ix;
+            const bool ok = ((it + 1) * NT <= NITEMS || idx < NITEMS) && (unsigned)vy < (unsigned)H && (unsigned)vx < (unsigned)W;
+            pre_x[it] = buf_load8<T>(rx, ok ? (unsigned)(vy * a.row + vx * a.px + cg * 8 * ESZ) : kOOB);
         }
         if constexpr (BWD) {
-            const char* mb = static_cast<const char*>(d.mask_mid) + img;
-            const char* ab = static_cast<const char*>(d.mask_a) + img;
+            const __amdgpu_buffer_rsrc_t rm = image_rsrc(static_cast<const char*>(d.mask_mid) + img, live ? img_bytes : 0u);
+            const __amdgpu_buffer_rsrc_t ra = image_rsrc(static_cast<const char*>(d.mask_a) + img, live ? img_bytes : 0u);
 #pragma unroll
             for (int it = 0; it < Cfg::NITM; ++it) {
                 const int idx = tid + it * NT;
                 const int pix = idx / C8, cg = idx - pix * C8;
                 const int iy = pix / IW, ix = pix - iy * IW;
-                pre_m[it] = zero8<T>();
-                pre_a[it] = zero8<T>();
                 const int my = ty0 - 1 + iy, mx = tx0 - 1 + ix;      // lattice position
-                if ((unsigned)my < (unsigned)H && (unsigned)mx < (unsigned)W)
-                    pre_m[it] = *reinterpret_cast<const V8*>(mb + (unsigned)(my * a.row + mx * a.px + cg * 8 * ESZ));
+                const bool mok = (unsigned)my < (unsigned)H && (unsigned)mx < (unsigned)W;
+                pre_m[it] = buf_load8<T>(rm, mok ? (unsigned)(my * a.row + mx * a.px + cg * 8 * ESZ) : kOOB);
                 const int ay = ty0 + iy, ax = tx0 + ix;              // output position
-                if (ay < H && ax < W)
-                    pre_a[it] = *reinterpret_cast<const V8*>(ab + (unsigned)(ay * a.row + ax * a.px + cg * 8 * ESZ));
+                pre_a[it] = buf_load8<T>(ra, (ay < H && ax < W) ? (unsigned)(ay * a.row + ax * a.px + cg * 8 * ESZ) : kOOB);
+            }
+        }
+    };
+    auto write_tiles = [&]() {
+        constexpr int NITEMS = Cfg::NPIX * C8;
+#pragma unroll
+        for (int it = 0; it < Cfg::NITX; ++it) {
+            const int idx = tid + it * NT;
+            const int pix = idx / C8, cg = idx - pix * C8;
+            const bool ok = (it + 1) * NT <= NITEMS || idx < NITEMS;
+            *reinterpret_cast<V8*>(smem + (ok ? pix * PS + cg * 8 * ESZ : Cfg::LDS + 256 + (tid & 15) * 32)) = pre_x[it];   // raw
+        }
+        if constexpr (BWD) {
+#pragma unroll
+            for (int it = 0; it < Cfg::NITM; ++it) {
+                const int idx = tid + it * NT;
+                mt[idx] = (unsigned char)positive_bits<T>(pre_m[it]);
+                at[idx] = (unsigned char)positive_bits<T>(pre_a[it]);
             }
         }
     };
@@ -165,35 +211,21 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
         tend = min(a.ntiles, (xcd + 1) * a.per_xcd);
         tstep = gridDim.x >> 3;
     }
-    if (tile0 < tend) issue_loads(tile0);
+    if (tile0 >= tend) return;                                 // workgroup-uniform
+    issue_loads(tile0, true);
+    __syncthreads();                                           // weights / biases staged
+    write_tiles();
+    __syncthreads();
 
     for (int tile = tile0; tile < tend; tile += tstep) {
         int b, ty0, tx0;
         decode(tile, b, ty0, tx0);
-        __syncthreads();                                       // previous tile's reads of the LDS tiles are done
-        {
-            constexpr int NITEMS = Cfg::NPIX * C8;
-#pragma unroll
-            for (int it = 0; it < Cfg::NITX; ++it) {
-                const int idx = tid + it * NT;
-                if ((it + 1) * NT <= NITEMS || idx < NITEMS) {
-                    const int pix = idx / C8, cg = idx - pix * C8;
-                    *reinterpret_cast<V8*>(xt + pix * PS + cg * 8 * ESZ) = pre_x[it];     // raw: ReLU at the fragment read
-                }
-            }
-            if constexpr (BWD) {
-#pragma unroll
-                for (int it = 0; it < Cfg::NITM; ++it) {
-                    const int idx = tid + it * NT;
-                    mt[idx] = (unsigned char)positive_bits<T>(pre_m[it]);
-                    at[idx] = (unsigned char)positive_bits<T>(pre_a[it]);
-                }
-            }
-        }
-        __syncthreads();
-        if (tile + tstep < tend) issue_loads(tile + tstep);
+        // the next tile's loads fly during both phases; they are waited for at the bottom, BEHIND this tile's stores
+        issue_loads(tile + tstep, tile + tstep < tend);
 
-        const long long img = (long long)b * H * a.row;
+        const long long img = (long long)b * img_bytes;
+        const __amdgpu_buffer_rsrc_t rmid = image_rsrc(static_cast<char*>(d.mid) + img, img_bytes);
+        const __amdgpu_buffer_rsrc_t ry = image_rsrc(static_cast<char*>(d.y) + img, img_bytes);
         // ================= phase 1: intermediate on the 16 x IW lattice, image position (ty0-1+i, tx0-1+j) ===========
         {
             f32x4 acc[CT][4];
@@ -217,36 +249,37 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
                     for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = mma8(af, bfrag[pt], acc[ct][pt]);
                 }
             }
-            if (ch_ok) {
-                const int j = cwt * 16 + lr;
-                const int xx = tx0 - 1 + j;
-                const bool colin = (unsigned)xx < (unsigned)W;
-                const bool colown = j >= 1 && j <= Cfg::OW;
+            const int xx = tx0 - 1 + jcol;
+            const bool colin = (unsigned)xx < (unsigned)W;
+            const bool colown = ch_ok && colin && jcol >= 1 && jcol <= Cfg::OW;
+            f32x4 bias[CT];
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt) {
-                    const int i = wave * 4 + pt;                 // wave-uniform
-                    const int yy = ty0 - 1 + i;
-                    const bool inimg = colin && (unsigned)yy < (unsigned)H;
-                    char* orow = static_cast<char*>(d.mid) + img + (long long)yy * a.row + (long long)(tx0 - 1) * a.px;
+            for (int ct = 0; ct < CT; ++ct) bias[ct] = *reinterpret_cast<const f32x4*>(lbias + (ch_ok ? ch0 + ct * 4 : 0));
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) {
-                        f32x4 v = acc[ct][pt];
-                        if constexpr (!BWD) {
-                            v += *reinterpret_cast<const f32x4*>(lbias + ch0 + ct * 4);
+            for (int pt = 0; pt < 4; ++pt) {
+                const int i = wave * 4 + pt;                     // wave-uniform
+                const int yy = ty0 - 1 + i;
+                const bool rowin = (unsigned)yy < (unsigned)H;
+                const bool inimg = colin && rowin;
+                const bool own = colown && rowin && i >= 1 && i <= Cfg::OH;
+                const unsigned goff = (unsigned)(yy * a.row + (tx0 - 1) * a.px + lane_c);
 #pragma unroll
-                            for (int jj = 0; jj < 4; ++jj) v[jj] = fmaxf(v[jj], 0.f);        // MSAU_PAIR_RELU_MID
-                        } else {
-                            const unsigned bits = mt[(i * IW + j) * C8 + ((ch0 + ct * 4) >> 3)] >> ((ch0 + ct * 4) & 7);
+                for (int ct = 0; ct < CT; ++ct) {
+                    f32x4 v = acc[ct][pt];
+                    if constexpr (!BWD) {
+                        v += bias[ct];
 #pragma unroll
-                            for (int jj = 0; jj < 4; ++jj) v[jj] = (bits >> jj) & 1u ? v[jj] : 0.f;   // MSAU_PAIR_MASK_MID
-                        }
-                        V4 o;
+                        for (int jj = 0; jj < 4; ++jj) v[jj] = fmaxf(v[jj], 0.f);        // MSAU_PAIR_RELU_MID
+                    } else {
+                        const unsigned bits = mt[ch_ok ? (i * IW + jcol) * C8 + ((ch0 + ct * 4) >> 3) : 0] >> ((ch0 + ct * 4) & 7);
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) o[jj] = (T)(inimg ? v[jj] : 0.f);
-                        *reinterpret_cast<V4*>(rt + (i * XW + j) * PS + (ch0 + ct * 4) * ESZ) = o;
-                        if (inimg && colown && i >= 1 && i <= Cfg::OH)
-                            *reinterpret_cast<V4*>(orow + (unsigned)(lane_c + ct * 4 * ESZ)) = o;
+                        for (int jj = 0; jj < 4; ++jj) v[jj] = (bits >> jj) & 1u ? v[jj] : 0.f;   // MSAU_PAIR_MASK_MID
                     }
+                    V4 o;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) o[jj] = (T)(inimg ? v[jj] : 0.f);
+                    *reinterpret_cast<V4*>(smem + rt_lane + (ch_ok ? i * XW * PS + ct * 4 * ESZ : 0)) = o;
+                    buf_store4(rmid, own ? goff + ct * 4 * ESZ : kOOB, o);
                 }
             }
         }
@@ -271,45 +304,49 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
                     for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = mma8(af, bfrag[pt], acc[ct][pt]);
                 }
             }
-            const int ox = cwt * 16 + lr;
-            if (ch_ok && ox < Cfg::OW && tx0 + ox < W) {
+            const bool colok = ch_ok && jcol < Cfg::OW && tx0 + jcol < W;
+            f32x4 bias[CT];
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt) {
-                    const int oy = wave * 4 + pt;                // wave-uniform
-                    const int yy = ty0 + oy;
-                    if (oy < Cfg::OH && yy < H) {
-                        char* yrow = static_cast<char*>(d.y) + img + (long long)yy * a.row + (long long)tx0 * a.px;
+            for (int ct = 0; ct < CT; ++ct) bias[ct] = *reinterpret_cast<const f32x4*>(lbias + Cfg::C + (ch_ok ? ch0 + ct * 4 : 0));
+            // the residual (forward) / other-path gradient (backward) operand is the input tensor itself: read it back
+            // from the raw LDS input tile, position (oy + 2, ox + 2); lanes without channels read slot 0
+            const int xt_lane = ch_ok ? (2 * XW + jcol + 2) * PS + ch0 * ESZ : 0;
 #pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) {
-                            // the residual (forward) / other-path gradient (backward) operand is the input tensor itself:
-                            // read it back from the raw LDS input tile, position (oy + 2, ox + 2)
-                            const V4 r = *reinterpret_cast<const V4*>(xt + ((oy + 2) * XW + ox + 2) * PS + (ch0 + ct * 4) * ESZ);
-                            f32x4 v = acc[ct][pt];
-                            if constexpr (!BWD) {
-                                v += *reinterpret_cast<const f32x4*>(lbias + Cfg::C + ch0 + ct * 4);
+            for (int pt = 0; pt < 4; ++pt) {
+                const int oy = wave * 4 + pt;                    // wave-uniform
+                const int yy = ty0 + oy;
+                const bool ok = colok && oy < Cfg::OH && yy < H;
+                const unsigned goff = (unsigned)(yy * a.row + tx0 * a.px + lane_c);
 #pragma unroll
-                                for (int jj = 0; jj < 4; ++jj) v[jj] = fmaxf(v[jj] + (float)r[jj], 0.f);      // ADD, RELU_OUT
-                            } else {
-                                const unsigned bits = at[(oy * IW + ox) * C8 + ((ch0 + ct * 4) >> 3)] >> ((ch0 + ct * 4) & 7);
+                for (int ct = 0; ct < CT; ++ct) {
+                    const V4 r = *reinterpret_cast<const V4*>(xt + xt_lane + (ch_ok ? oy * XW * PS + ct * 4 * ESZ : 0));
+                    f32x4 v = acc[ct][pt];
+                    if constexpr (!BWD) {
+                        v += bias[ct];
 #pragma unroll
-                                for (int jj = 0; jj < 4; ++jj) v[jj] = ((bits >> jj) & 1u ? v[jj] : 0.f) + (float)r[jj];   // MASK_A, ADD
-                            }
-                            V4 ov;
+                        for (int jj = 0; jj < 4; ++jj) v[jj] = fmaxf(v[jj] + (float)r[jj], 0.f);      // ADD, RELU_OUT
+                    } else {
+                        const unsigned bits = at[ch_ok ? (oy * IW + jcol) * C8 + ((ch0 + ct * 4) >> 3) : 0] >> ((ch0 + ct * 4) & 7);
 #pragma unroll
-                            for (int jj = 0; jj < 4; ++jj) ov[jj] = (T)v[jj];
-                            *reinterpret_cast<V4*>(yrow + (unsigned)(lane_c + ct * 4 * ESZ)) = ov;
-                        }
+                        for (int jj = 0; jj < 4; ++jj) v[jj] = ((bits >> jj) & 1u ? v[jj] : 0.f) + (float)r[jj];   // MASK_A, ADD
                     }
+                    V4 ov;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) ov[jj] = (T)v[jj];
+                    buf_store4(ry, ok ? goff + ct * 4 * ESZ : kOOB, ov);
                 }
             }
         }
+        __syncthreads();                                       // every read of the LDS tiles is done
+        write_tiles();                                         // needs the prefetch only: vmcnt(stores of this tile)
+        __syncthreads();
     }
 }
 
 template <typename T, int C8, int TW, bool BWD>
 int launch_pair(hipStream_t s, const PairArgs& a0) {
     using Cfg = PairCfg<T, C8, TW, BWD>;
-    static_assert(Cfg::LDS + 256 <= MSAU_LDS_LIMIT, "conv_pair instance does not fit the LDS");
+    static_assert(Cfg::LDS + Cfg::LDS_PAD + 256 <= MSAU_LDS_LIMIT, "conv_pair instance does not fit the LDS");
     PairArgs a = a0;
     a.tiles_x = cdiv(a.d.W, Cfg::OW);
     a.tiles_y = cdiv(a.d.H, Cfg::OH);
@@ -317,14 +354,24 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
     a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
     a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
     static bool attr_set = false;
-    if (!attr_set && Cfg::LDS > 60 * 1024) {
+    if (!attr_set && Cfg::LDS + Cfg::LDS_PAD > 60 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_pair: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    int per_cu = MSAU_LDS_LIMIT / (Cfg::LDS + 256);
-    per_cu = per_cu < 1 ? 1 : (per_cu > 8 / TW ? 8 / TW : per_cu);
+    // persistent grid = what is RESIDENT at once (registers and LDS both count): workgroups beyond that would start
+    // only after the first ones have finished their whole share of tiles and run on a third-empty machine
+    static int per_cu = 0;
+    if (!per_cu) {
+        int n = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD>),
+                                                                     256 * TW, Cfg::LDS + Cfg::LDS_PAD);
+        if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_pair: occupancy query: %s", hipGetErrorString(e));
+        const int lds_cap = MSAU_LDS_LIMIT / (Cfg::LDS + Cfg::LDS_PAD + 256);
+        n = n < lds_cap ? n : lds_cap;
+        per_cu = n < 1 ? 1 : (n > 8 / TW ? 8 / TW : n);
+    }
     int grid = 256 * per_cu;
     if (grid > a.ntiles) grid = a.ntiles;
     static const bool xcd_off = std::getenv("MSAU_XCD") && std::getenv("MSAU_XCD")[0] == '0';
@@ -333,7 +380,7 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
         grid &= ~7;
         a.per_xcd = cdiv(a.ntiles, 8);
     }
-    hipLaunchKernelGGL((conv_pair_kernel<T, C8, TW, BWD>), dim3(grid), dim3(256 * TW), Cfg::LDS, s, a);
+    hipLaunchKernelGGL((conv_pair_kernel<T, C8, TW, BWD>), dim3(grid), dim3(256 * TW), Cfg::LDS + Cfg::LDS_PAD, s, a);
     MSAU_CHECK_LAUNCH("conv_pair_kernel");
     return 0;
 }
