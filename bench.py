@@ -30,8 +30,8 @@ MFMA_BF16_PEAK_TF = 2500.0     # dense bf16
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU")
     ap.add_argument("--height", type=int, default=336)
     ap.add_argument("--width", type=int, default=256)
@@ -43,6 +43,10 @@ def parse():
                          "6.08 vs 5.73 ms/step; the host keeps up with ~450 launches of ~10 us)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurements (cfg 4: 768-channel 2-stage net; cfg 2 in fp32 storage; cfg 2 fed with "
+                         "character-id masks instead of the dense one-hot tensor)")
+    ap.add_argument("--secondary-steps", type=int, default=30)
     ap.add_argument("--cpu-steps", type=int, default=200)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--dump-kernels", default="", help="write the per-kernel HIP-event table to this file")
@@ -86,6 +90,74 @@ def usable_cores() -> int:
     return max(1, min(n, 64))
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the HIP sources + the ABI header: ties a PMC traffic file to the kernels it was measured on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "msau_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "msau_amd", "csrc", "*.h"))
+                    + [os.path.join(ROOT, "include", "msau_hip.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(key):
+    """HBM bytes per launch of `key` from the PMC file of this round -- only if it was measured on exactly these kernel
+    sources (tools/make_traffic.py writes the hash); otherwise (None, reason)"""
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    try:
+        tj = json.load(open(path))
+    except Exception as e:                                   # noqa: BLE001
+        return None, f"no traffic file ({e.__class__.__name__})"
+    if tj.get("kernel_source_hash") != kernel_source_hash():
+        return None, (f"profiles/r02_traffic.json was measured on kernel sources {tj.get('kernel_source_hash')}, this tree is "
+                      f"{kernel_source_hash()}: re-run tools/make_traffic.py")
+    ent = tj.get("kernels", {}).get(key)
+    if ent is None:
+        return None, f"profiles/r02_traffic.json has no entry for {key}"
+    return ent, None
+
+
+def profile_pass(L, eng, plan, x, label, nprof):
+    """per-launch HIP-event timing of `nprof` eager steps with nothing overlapping -> rows (ms, key, count, meta)"""
+    import torch
+    prof = L.Profiler()
+    for _ in range(nprof):
+        # park the device behind a sleeping wave so the whole step queues up: the events then bracket
+        # device execution only (no host launch gap inside a bracket)
+        L.call("msau_spin", torch.cuda.current_stream().cuda_stream, 40000)
+        L.set_profiler(prof)
+        eng.step(x, label)
+        L.set_profiler(None)
+        torch.cuda.synchronize()
+    rows = [(ms, key, cnt, plan.launch_meta.get(key)) for key, (cnt, ms) in prof.summary().items()]
+    rows.sort(reverse=True)
+    return rows
+
+
+def probe_in_place(eng, plan, x, label, keys, steps):
+    """durations of the MAIN-stream launches whose kernel key is in `keys`, measured inside the normal native sequence
+    (side-stream weight gradients running beside them): {key: (launches per step, avg us, algorithmic bytes per launch)}"""
+    import torch
+    order = plan.set_probe_keys(set(keys))
+    plan.read_probe()
+    acc = {}
+    for _ in range(max(steps, 1)):
+        eng.step(x, label)
+        us = plan.read_probe()
+        assert len(us) == len(order), (len(us), len(order))
+        for (key, nbytes), t in zip(order, us):
+            a = acc.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += t
+            a[2] += nbytes
+    plan.set_probe_keys(None)
+    torch.cuda.synchronize()
+    n = max(steps, 1)
+    return {k: (c // n, t / c, b / c) for k, (c, t, b) in acc.items()}
+
+
 def cpu_baseline(args, n_class):
     """The CPU restatement of the reference step (oracle/, validated against the reference's own
     outputs) on this host: fp32, batch-1 loop as in train_chargrid_funsd_msau.py:45-59."""
@@ -123,6 +195,61 @@ def cpu_baseline(args, n_class):
         out["batched"] = {"batch": args.batch, "value": nb * args.batch / dtb, "unit": "tiles/s", "steps": nb, "seconds": round(dtb, 1)}
     except Exception as e:                                   # noqa: BLE001  (e.g. host memory): the batch-1 figure stands
         out["batched"] = {"error": str(e)[:120]}
+    return out
+
+
+def secondary_measurements(args, L, MSAUWrapper, TrainEngine, dev, n_class):
+    """Clearly separate from the headline: same step, other configurations, each its own model.  Every entry: tiles/s over
+    `--secondary-steps` steps (inputs resident, no host sync inside), and the dominant kernel of that configuration with
+    its serialised HIP-event time against the HBM roofline."""
+    import torch
+    out = []
+
+    def run(name, channels, stages, dtype, batch, feed="dense"):
+        kw = dict(scale_space_num=4, res_depth=2, featRoot=8, filter_size=3, pool_size=2, final_act="softmax",
+                  num_blocks=stages, dtype=dtype, seed=0)
+        model = MSAUWrapper(channels, n_class, kw).to(dev)
+        eng = TrainEngine(model, lr=1e-4)
+        x, label = synthetic(batch, channels, args.height, args.width, n_class, 4321, dev)
+        if name.startswith("cfg4"):
+            # BERT-like dense input (SURVEY 8d): N(0,1) vectors at occupied pixels, zeros elsewhere
+            g = torch.Generator(device="cpu").manual_seed(7)
+            occ = (x.sum(1, keepdim=True) > 0).float()
+            x = (torch.randn((batch, channels, args.height, args.width), generator=g).to(dev)) * occ
+        ids = None
+        if feed == "ids":
+            occ = x.sum(1) > 0
+            ids = torch.where(occ, x.argmax(1), torch.full_like(x.argmax(1), -1)).to(torch.int32).contiguous()
+        step = (lambda: eng.step_ids(ids, label)) if feed == "ids" else (lambda: eng.step(x, label))
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.secondary_steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ent = {"name": name, "value": round(batch * args.secondary_steps / dt, 1), "unit": "tiles/s",
+               "ms_per_step": round(1e3 * dt / args.secondary_steps, 3), "dtype": dtype, "batch": batch, "feed": feed,
+               "workload": f"{args.height}x{args.width}x{channels}, {stages}-stage", "loss": round(float(loss), 5)}
+        if feed == "dense" and not args.no_roofline:
+            plan = model._plan_for(x, training=True)
+            rows = profile_pass(L, eng, plan, x, label, 3)
+            ms, key, cnt, meta = next(r for r in rows if r[3] and not r[1].startswith("msau_"))
+            us = 1e3 * ms / cnt
+            gbs = meta[1] / meta[0] / (us * 1e-6) / 1e9
+            ent["dominant_kernel"] = {"kernel": key, "launches_per_step": meta[0], "avg_launch_us_serialised": round(us, 2),
+                                      "alg_MB_per_launch": round(meta[1] / meta[0] / 1e6, 2), "GB/s": round(gbs, 1),
+                                      "frac": round(gbs / HBM_PEAK_GBS, 4), "share_of_step": round(ms / sum(r[0] for r in rows), 3)}
+        out.append(ent)
+        del eng, model, x, label
+        torch.cuda.empty_cache()
+
+    run("cfg4: BERT-embedding chargrid 336x256x768, 2-stage (BASELINE configs[3])", 768, 2, "bf16", args.batch)
+    run("cfg2 in fp32 storage (the parity mode of the same kernels)", args.channels, args.stages, "fp32", args.batch)
+    if hasattr(TrainEngine, "step_ids"):
+        run("cfg2 fed with character-id masks (first conv as a gather; SURVEY 8f N1) -- NOT the headline input", args.channels,
+            args.stages, "bf16", args.batch, feed="ids")
     return out
 
 
@@ -193,32 +320,14 @@ def main():
         # the measuring passes below run on rank 0 only: take the gradient exchange out of the step (a collective that
         # only one rank enters would hang); the other ranks wait at the barrier before the process group is torn down
         eng.sync.active = False
-        # per-launch HIP-event timing of the same step, eagerly, on the launch stream
+        eng.use_graph = False
         plan = model._plan_for(x, training=True)
-        prof = L.Profiler()
-        eng_e = eng
-        eng_e.use_graph = False
         nprof = min(args.steps, 5)
-        for _ in range(nprof):
-            # park the device behind a sleeping wave so the whole step queues up: the events then bracket
-            # device execution only (no host launch gap inside a bracket)
-            L.call("msau_spin", torch.cuda.current_stream().cuda_stream, 40000)
-            L.set_profiler(prof)
-            eng_e.step(x, label)
-            L.set_profiler(None)
-            torch.cuda.synchronize()
-        torch.cuda.synchronize()
-        L.set_profiler(None)
-        summ = prof.summary()
-        rows = []
-        for key, (cnt, ms) in summ.items():
-            meta = plan.launch_meta.get(key)
-            rows.append((ms, key, cnt, meta))
-        rows.sort(reverse=True)
+        rows = profile_pass(L, eng, plan, x, label, nprof)
         total_ms = sum(r[0] for r in rows)
         if args.dump_kernels:
             with open(args.dump_kernels, "w") as f:
-                f.write(f"# HIP-event per-launch timing, {nprof} eager steps, batch {args.batch}, {args.dtype}\n")
+                f.write(f"# HIP-event per-launch timing, {nprof} eager steps, nothing overlapping, batch {args.batch}, {args.dtype}\n")
                 f.write("# kernel, launches, total_ms, avg_us, share, alg_GB/s, alg_TFLOP/s\n")
                 for ms, key, cnt, meta in rows:
                     gbs = tfs = float("nan")
@@ -226,52 +335,49 @@ def main():
                         gbs = meta[1] * nprof / (ms * 1e-3) / 1e9
                         tfs = meta[2] * nprof / (ms * 1e-3) / 1e12
                     f.write(f"{key}, {cnt}, {ms:.3f}, {1e3 * ms / cnt:.1f}, {ms / total_ms:.3f}, {gbs:.0f}, {tfs:.1f}\n")
-        ms, key, cnt, meta = next(r for r in rows if r[3])
+        # dominant kernel = largest share of the step among the conv / norm kernels of the op list
+        ms, key, cnt, meta = next(r for r in rows if r[3] and not r[1].startswith("msau_") and "wgrad" not in r[1])
         n_launch, alg_bytes, alg_flops = meta
         serial_us = 1e3 * ms / cnt
-        # the dominant kernel timed IN PLACE: the same native launch sequence as the timed region (weight gradients
-        # running beside it on the side stream), with a HIP-event pair around each of its launches on its own stream.
-        # This is the duration rocprofv3 --kernel-trace reports for the same command (profiles/), plus the events' own
-        # ~1-2 us; the serialised pass above (nothing overlapping) is quoted next to it.
-        nmark = plan.set_probe(key)
-        assert nmark == n_launch, (nmark, n_launch)
-        plan.read_probe()
-        probe_us = []
-        for _ in range(max(args.steps, 1)):
-            eng.step(x, label)
-            probe_us += plan.read_probe()
-        plan.set_probe(None)
-        torch.cuda.synchronize()
-        # an event pair costs time by itself (the records' barrier packets): measured with empty pairs behind a parked
-        # stream and reported next to the bracketed duration.  rocprofv3's kernel-only duration for the same command
-        # lies between (bracketed - pair) and bracketed; `achieved` uses the bracketed, i.e. conservative, figure.
+        # timed IN PLACE: the same native launch sequence as the timed region (weight gradients running beside it on the
+        # side stream), a HIP-event pair around each launch on its own stream.  This is the duration rocprofv3
+        # --kernel-trace reports for the same command (profiles/), plus the events' own ~1-2 us.  Together with it the
+        # memory-bound norm ops north_star names: LRN forward / backward and the max pool, per channel width.
+        norm_keys = [k for k in plan.launch_meta if k.startswith(("lrn_", "pool_"))]
+        probed = probe_in_place(eng, plan, x, label, [key] + norm_keys, min(args.steps, 30))
+        n_probe, insitu_us, bytes_probe = probed[key]
         import ctypes
         ov = ctypes.c_float(0.0)
         L.call("msau_spin", torch.cuda.current_stream().cuda_stream, 2000)
         L.call("msau_probe_overhead", torch.cuda.current_stream().cuda_stream, 256, ctypes.byref(ov))
-        raw_us = sum(probe_us) / len(probe_us)
-        insitu_us = raw_us
-        achieved = (alg_bytes / n_launch) / (insitu_us * 1e-6) / 1e9
-        traffic, traffic_note = None, None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if key in tj:
-                traffic = tj[key]["hbm_bytes_per_launch"]
-                traffic_note = ("PMC (FETCH_SIZE x2 + WRITE_SIZE) of this kernel's plain forward launch, "
-                                f"{tj[key]['alg_bytes_of_measured_launch']} algorithmic bytes; collected offline by tools/pmc.sh")
-        except Exception:
-            pass
+        achieved = bytes_probe / (insitu_us * 1e-6) / 1e9
+        tr, why = load_traffic(key)
+        serial = {r[1]: 1e3 * r[0] / r[2] for r in rows}
+        norm_ops = {}
+        for k in sorted(norm_keys):
+            if k in probed:
+                c, us, nb = probed[k]
+                norm_ops[k] = {"launches_per_step": c, "avg_launch_us": round(us, 2), "alg_MB_per_launch": round(nb / 1e6, 2),
+                               "GB/s": round(nb / (us * 1e-6) / 1e9, 1), "frac": round(nb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                               "avg_launch_us_serialised": round(serial.get(k, float("nan")), 2)}
+        step_bytes = sum(m[1] for m in plan.launch_meta.values())
         roof = {"bound": "hbm", "kernel": key, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                "traffic_note": (f"PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes) of {tr['launch']}: {tr['hbm_bytes_per_launch']} HBM bytes for "
+                                 f"{tr['alg_bytes_of_measured_launch']} algorithmic (x{tr['hbm_bytes_per_launch'] / tr['alg_bytes_of_measured_launch']:.2f}); "
+                                 f"mangled name {tr.get('mangled', '?')}; tools/make_traffic.py at {tr.get('git_sha', '?')}") if tr else why,
                 "launches_per_step": n_launch, "avg_launch_us": round(insitu_us, 2),
                 "event_pair_us": round(ov.value, 2),
-                "avg_launch_us_serialised": round(serial_us, 2), "timed_launches": len(probe_us),
-                "alg_bytes_per_launch": round(alg_bytes / n_launch),
+                "avg_launch_us_serialised": round(serial_us, 2), "timed_launches": n_probe * min(args.steps, 30),
+                "alg_bytes_per_launch": round(bytes_probe),
                 "share_of_step": round(ms / total_ms, 3),
                 "mfma_frac": round((alg_flops / n_launch) / (insitu_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TF, 4),
-                "whole_step": {"alg_GB": round(sum(m[1] for m in plan.launch_meta.values()) / 1e9, 3),
+                "norm_ops": norm_ops,
+                "launches_per_step_total": int(sum(m[0] for m in plan.launch_meta.values())),
+                "whole_step": {"alg_GB": round(step_bytes / 1e9, 3),
                                "alg_TFLOP": round(sum(m[2] for m in plan.launch_meta.values()) / 1e12, 4),
-                               "hbm_frac": round(sum(m[1] for m in plan.launch_meta.values()) * value / (world * args.batch) / 1e9 / HBM_PEAK_GBS, 4)}}
+                               "hbm_frac": round(step_bytes * value / (world * args.batch) / 1e9 / HBM_PEAK_GBS, 4)}}
         if (args.height, args.width, args.channels, args.stages) == (336, 256, 64, 3):
             # SURVEY.md 8(d) compulsory-traffic model of the whole step (tools/roofline.py re-derives it)
             sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
@@ -279,6 +385,12 @@ def main():
             ach = RF.achieved(RF.CONFIGS["cfg2"], value / world, 2 if args.dtype == "bf16" else 4)
             roof["whole_step"]["compulsory_hbm_frac"] = round(ach["hbm_frac"], 4)
             roof["whole_step"]["compulsory_mfma_frac"] = round(ach["mfma_frac"], 4)
+
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        del eng, model
+        torch.cuda.empty_cache()
+        secondary = secondary_measurements(args, L, MSAUWrapper, TrainEngine, dev, n_class)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -295,7 +407,7 @@ def main():
                                       + (", RCCL all-reduce" if world > 1 else ""),
                           "global_batch": world * args.batch, "parallelism": f"dp{world}",
                           "graph": bool(args.graph), "loss": round(loss_val, 5)},
-               "roofline": roof, "cpu_baseline": cpu}
+               "roofline": roof, "cpu_baseline": cpu, "secondary": secondary}
         print(json.dumps(out), flush=True)
     if world > 1 or os.environ.get("MSAU_FORCE_DIST") == "1":
         import torch.distributed as dist

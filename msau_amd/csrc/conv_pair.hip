@@ -364,13 +364,17 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
     // only after the first ones have finished their whole share of tiles and run on a third-empty machine
     static int per_cu = 0;
     if (!per_cu) {
-        int n = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD>),
-                                                                     256 * TW, Cfg::LDS + Cfg::LDS_PAD);
-        if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_pair: occupancy query: %s", hipGetErrorString(e));
-        const int lds_cap = MSAU_LDS_LIMIT / (Cfg::LDS + Cfg::LDS_PAD + 256);
-        n = n < lds_cap ? n : lds_cap;
-        per_cu = n < 1 ? 1 : (n > 8 / TW ? 8 / TW : n);
+        // (hipOccupancyMaxActiveBlocksPerMultiprocessor budgets 64 KB of LDS per CU, not gfx950's 160 KB: compute it here)
+        hipFuncAttributes fa;
+        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD>));
+        if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_pair: hipFuncGetAttributes: %s", hipGetErrorString(e));
+        const int vgprs = ((fa.numRegs > 0 ? fa.numRegs : 64) + 7) & ~7;
+        int waves_per_simd = 512 / vgprs;                      // 512 VGPRs per SIMD lane, 8 waves at most
+        waves_per_simd = waves_per_simd > 8 ? 8 : waves_per_simd;
+        const int by_regs = waves_per_simd / TW;               // a workgroup puts TW waves on every SIMD
+        const int by_lds = MSAU_LDS_LIMIT / (Cfg::LDS + Cfg::LDS_PAD + 256);
+        const int n = by_regs < by_lds ? by_regs : by_lds;
+        per_cu = n < 1 ? 1 : n;
     }
     int grid = 256 * per_cu;
     if (grid > a.ntiles) grid = a.ntiles;

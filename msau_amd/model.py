@@ -408,8 +408,8 @@ class TrainEngine:
         self._gstream = torch.cuda.Stream(device=flat.device)
 
     # -- pieces (each is a fixed launch sequence on the current stream) --
-    def _fwd_bwd(self, plan: Plan, x, labels):
-        plan.forward(self.model._flat, x, export=False)
+    def _fwd_bwd(self, plan: Plan, x, labels, ids=None):
+        plan.forward(self.model._flat, x, export=False, ids=ids)
         loss = plan.loss_grads(labels)
         if self.sync.active and not self.use_graph:
             # bucket i of GradSync = [end convs, last stage, ..., stage 0]; a stage's bucket is reduced over RCCL as
@@ -474,6 +474,23 @@ class TrainEngine:
             self._allreduce()
             g2.replay()
         cur.wait_stream(gs)
+        return loss
+
+    def step_ids(self, ids: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        """One optimisation step fed with the character-id mask int32 [B,H,W] (-1 or any id outside [0, channels) = empty
+        pixel) instead of the dense one-hot float tensor: what `to_categorical` / the chargrid painter would have produced
+        is painted straight into the NHWC input on the device -- 4 B per pixel cross the boundary instead
+        of 4*C, and the 352 MB NCHW -> NHWC conversion of cfg 2 disappears.  Same kernels after that: bit-identical to
+        `step(one_hot(ids), labels)`.  Eager only."""
+        if self.use_graph:
+            raise RuntimeError("step_ids is an eager path (use_graph=False)")
+        ids = ids.to(dtype=torch.int32).contiguous()
+        B, H, W = ids.shape
+        labels = labels.reshape(B, H, W).contiguous().long()
+        plan = self.model._plan_for_shape(B, H, W, ids.device, True)
+        loss = self._fwd_bwd(plan, None, labels, ids=ids)
+        self._allreduce()
+        self._optim()
         return loss
 
     @property

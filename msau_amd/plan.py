@@ -84,6 +84,9 @@ class Op:
     def finalize(self):
         pass
 
+    def note(self):
+        pass
+
     def fwd(self, s):
         raise NotImplementedError
 
@@ -391,6 +394,8 @@ class ConvOp(Op):
             self.wbytes = (w.B * w.Hin * w.Win * (w.C1 + w.C2) * wg.nchunks // wg.nchunks + w.B * w.Hout * w.Wout * w.Cout) * esz \
                 + w.nslabs * wg.slab_bytes
             P.note_launch(self.wkey, self.wbytes, self.flops)
+            if self.kind != "conv":                      # bias gradient of the transposed conv: one pass over its output gradient
+                P.note_launch("msau_channel_sum", self.out.npix * self.out.Cs * esz, 0.0)
 
     def fwd(self, s):
         if self.pair is not None and self.pair.active:
@@ -400,8 +405,13 @@ class ConvOp(Op):
         L.call("msau_conv2d", s, self.plan.dtype, C.byref(self.fdesc), key=self.fkey)
 
     def fwd_recs(self):
+        rm = self.plan.rec_meta
         if self.pair is not None and self.pair.active:
-            return [(L.OP_CONV_PAIR, self.pair.fdesc)] if self is self.pair.c2 else []
+            if self is not self.pair.c2:
+                return []
+            rm[C.addressof(self.pair.fdesc)] = (self.pair.key, self.pair.fbytes)
+            return [(L.OP_CONV_PAIR, self.pair.fdesc)]
+        rm[C.addressof(self.fdesc)] = (self.fkey, self.fbytes)
         return [(L.OP_CONV2D, self.fdesc)]
 
     def bwd_recs(self):
@@ -416,11 +426,17 @@ class ConvOp(Op):
             P = self.plan
             self._csum = L.CsumArgs(_ptr(self.out.grad), self.out.npix, self.out.Cs, P.slab_ptr(self.csum_off), self.csum_blocks)
             recs.append((L.OP_CHANNEL_SUM | side, self._csum))
+        rm = self.plan.rec_meta
+        rm[C.addressof(self.wdesc)] = (self.wkey, self.wbytes)
         if self.pair is not None and self.pair.active and self.pair.bdesc is not None:
             if self is self.pair.c2:                    # both data gradients in one launch, behind the second conv's wgrad
+                rm[C.addressof(self.pair.bdesc)] = (self.pair.key, self.pair.bbytes)
                 recs.append((L.OP_CONV_PAIR, self.pair.bdesc))
             return recs
-        recs += [(L.OP_CONV2D, dd) for dd in self.ddesc if dd is not None]
+        for si, dd in enumerate(self.ddesc):
+            if dd is not None:
+                rm[C.addressof(dd)] = self.dmeta[si]
+                recs.append((L.OP_CONV2D, dd))
         return recs
 
     def bwd_wgrad(self, s):
@@ -487,7 +503,7 @@ class PairOp:
         esz = 4 if P.dtype == L.F32 else 2
         self.key = f"conv_pair_kernel<{T},C{x0.Cs}>"
         n = P.B * x0.H * x0.W * x0.Cs
-        self.fbytes = 4 * n * esz                       # x0 once, r1 once, out once, residual operand once
+        self.fbytes = 3 * n * esz                       # x0 read once (it is also the residual operand), r1 and out written once
         if P.training and c1.ddesc[0] is not None and c2.ddesc[0] is not None and c1.ddesc[1] is None and c2.ddesc[1] is None \
                 and c1.d_off[0] is not None and c2.d_off[0] is not None:
             d1, d2 = c1.ddesc[0], c2.ddesc[0]
@@ -499,8 +515,7 @@ class PairOp:
                 b.w2, b.b2, b.add, b.mask_a, b.mask_b, b.y = P.pack_ptr(c1.d_off[0]), None, d1.add, d1.mask_a, d1.mask_b, d1.y
                 if L.load().msau_conv_pair_applicable(P.dtype, C.byref(b)):     # MASK_A + ADD of the input tensor only
                     self.bdesc = b
-                nex = sum(1 for fl in (L.CONV_MASK_A, L.CONV_ADD, L.CONV_ACCUM, L.CONV_MASK_B) if d1.flags & fl)
-                self.bbytes = (4 + nex) * n * esz       # g once, r1 mask once, g_r1 once, dx once + epilogue operands
+                self.bbytes = 5 * n * esz               # g (also the ADD operand), r1 mask, x0 mask read once; g_r1, dx written once
         self.active = True
 
     def note(self):
@@ -532,9 +547,22 @@ class LrnOp(Op):
     def writes(self):
         return [self.y]
 
+    def note(self):
+        """algorithmic bytes: forward reads a, writes y; backward reads a and dy, writes da"""
+        P, a = self.plan, self.a
+        esz = 4 if P.dtype == L.F32 else 2
+        T = "f32" if P.dtype == L.F32 else "bf16"
+        n = a.npix * a.Cs * esz
+        self.fkey, self.bkey = f"lrn_fwd<{T},C{a.Cs}>", f"lrn_bwd<{T},C{a.Cs}>"
+        self.fbytes, self.bbytes = 2 * n, 3 * n
+        P.note_launch(self.fkey, self.fbytes, 0.0)
+        if P.training and self.y.grad is not None and a.grad is not None:
+            P.note_launch(self.bkey, self.bbytes, 0.0)
+
     def fwd_recs(self):
         a, y = self.a, self.y
         self._fa = L.LrnArgs(_ptr(a.data), None, _ptr(y.data), a.npix, a.C, a.Cs, a.C, 1e-4, 0.75, 1.0)
+        self.plan.rec_meta[C.addressof(self._fa)] = (self.fkey, self.fbytes)
         return [(L.OP_LRN_FWD, self._fa)]
 
     def bwd_recs(self):
@@ -542,12 +570,13 @@ class LrnOp(Op):
         if y.grad is None or a.grad is None:
             return []
         self._ba = L.LrnArgs(_ptr(a.data), _ptr(y.grad), _ptr(a.grad), a.npix, a.C, a.Cs, a.C, 1e-4, 0.75, 1.0)
+        self.plan.rec_meta[C.addressof(self._ba)] = (self.bkey, self.bbytes)
         # deterministic mode: never beside a side-stream kernel ("one-ulp finding")
         return [(L.OP_LRN_BWD | (L.OP_JOIN if self.plan.deterministic and self.plan.overlap_wgrad else 0), self._ba)]
 
     def fwd(self, s):
         a, y = self.a, self.y
-        L.call("msau_lrn_fwd", s, self.plan.dtype, _ptr(a.data), _ptr(y.data), a.npix, a.C, a.Cs, a.C, 1e-4, 0.75, 1.0)
+        L.call("msau_lrn_fwd", s, self.plan.dtype, _ptr(a.data), _ptr(y.data), a.npix, a.C, a.Cs, a.C, 1e-4, 0.75, 1.0, key=self.fkey)
 
     def bwd(self, s):
         a, y = self.a, self.y
@@ -555,7 +584,7 @@ class LrnOp(Op):
             return
         assert a.n_contrib == 1 and not a.relu_out
         L.call("msau_lrn_bwd", s, self.plan.dtype, _ptr(a.data), _ptr(y.grad), _ptr(a.grad), a.npix, a.C, a.Cs, a.C,
-               1e-4, 0.75, 1.0)
+               1e-4, 0.75, 1.0, key=self.bkey)
 
 
 class PoolOp(Op):
@@ -575,9 +604,25 @@ class PoolOp(Op):
     def writes(self):
         return [self.y]
 
+    def note(self):
+        """forward: x read, y (+ 1-byte argmax) written; backward: dy + argmax read, dx written (+ mask / accumulate reads)"""
+        P, x, y = self.plan, self.x, self.y
+        esz = 4 if P.dtype == L.F32 else 2
+        T = "f32" if P.dtype == L.F32 else "bf16"
+        nx, ny = x.npix * x.Cs, y.npix * y.Cs
+        self.fkey, self.bkey = f"pool_fwd<{T},C{x.Cs}>", f"pool_bwd<{T},C{x.Cs}>"
+        self.fbytes = (nx + ny) * esz + (ny if P.training else 0)
+        P.note_launch(self.fkey, self.fbytes, 0.0)
+        self.bbytes = 0
+        if P.training and y.grad is not None and x.grad is not None:
+            accum, maskb = x.slot_flags(self.slot)
+            self.bbytes = (ny + nx * (1 + int(accum) + int(maskb))) * esz + ny
+            P.note_launch(self.bkey, self.bbytes, 0.0)
+
     def fwd_recs(self):
         x, y = self.x, self.y
         self._fa = L.PoolArgs(_ptr(x.data), _ptr(y.data), _ptr(self.idx), None, self.plan.B, x.H, x.W, x.Cs, 0)
+        self.plan.rec_meta[C.addressof(self._fa)] = (self.fkey, self.fbytes)
         return [(L.OP_POOL_FWD, self._fa)]
 
     def bwd_recs(self):
@@ -587,11 +632,13 @@ class PoolOp(Op):
         accum, maskb = x.slot_flags(self.slot)
         self._ba = L.PoolArgs(_ptr(y.grad), _ptr(x.grad), _ptr(self.idx), _ptr(x.data) if maskb else None,
                               self.plan.B, x.H, x.W, x.Cs, int(accum))
+        self.plan.rec_meta[C.addressof(self._ba)] = (self.bkey, self.bbytes)
         return [(L.OP_POOL_BWD, self._ba)]
 
     def fwd(self, s):
         x, y = self.x, self.y
-        L.call("msau_maxpool2x2_fwd", s, self.plan.dtype, _ptr(x.data), _ptr(y.data), _ptr(self.idx), self.plan.B, x.H, x.W, x.Cs)
+        L.call("msau_maxpool2x2_fwd", s, self.plan.dtype, _ptr(x.data), _ptr(y.data), _ptr(self.idx), self.plan.B, x.H, x.W, x.Cs,
+               key=self.fkey)
 
     def bwd(self, s):
         x, y = self.x, self.y
@@ -599,7 +646,7 @@ class PoolOp(Op):
             return
         accum, maskb = x.slot_flags(self.slot)
         L.call("msau_maxpool2x2_bwd", s, self.plan.dtype, _ptr(y.grad), _ptr(self.idx), _ptr(x.grad),
-               _ptr(x.data) if maskb else None, self.plan.B, x.H, x.W, x.Cs, int(accum))
+               _ptr(x.data) if maskb else None, self.plan.B, x.H, x.W, x.Cs, int(accum), key=self.bkey)
 
 
 class AttnCoreOp(Op):
@@ -628,26 +675,44 @@ class AttnCoreOp(Op):
                           _ptr(self.f.grad), _ptr(self.g.grad), _ptr(self.h.grad), _ptr(self.ws),
                           self.plan.B, self.N, self.f.Cs, self.h.Cs)
 
+    def note(self):
+        """forward: f, g, h, x read, y written (two sweeps: stats, output); backward: f, g, h, dy read, df, dg, dh written.
+        flops: the N x N score matrix (2*N*N*d) is formed twice per sweep pair, h . beta costs 2*N*N*C."""
+        P = self.plan
+        esz = 4 if P.dtype == L.F32 else 2
+        T = "f32" if P.dtype == L.F32 else "bf16"
+        npx = P.B * self.N
+        small, big = npx * self.f.Cs * esz, npx * self.h.Cs * esz
+        self.fkey, self.bkey = f"selfattn_fwd<{T}>", f"selfattn_bwd<{T}>"
+        self.fbytes = 2 * small + 3 * big
+        ffl = 2.0 * P.B * self.N * self.N * (self.f.C + self.h.C)
+        P.note_launch(self.fkey, self.fbytes, ffl)
+        self.bbytes = 4 * small + 4 * big
+        if P.training and self.y.grad is not None:
+            P.note_launch(self.bkey, self.bbytes, 2.0 * ffl)
+
     def fwd_recs(self):
         self._fa = self._args(False)
+        self.plan.rec_meta[C.addressof(self._fa)] = (self.fkey, self.fbytes)
         return [(L.OP_ATTN_FWD, self._fa)]
 
     def bwd_recs(self):
         if self.y.grad is None:
             return []
         self._ba = self._args(True)
+        self.plan.rec_meta[C.addressof(self._ba)] = (self.bkey, self.bbytes)
         return [(L.OP_ATTN_BWD, self._ba)]
 
     def fwd(self, s):
         L.call("msau_selfattn_fwd", s, self.plan.dtype, _ptr(self.f.data), _ptr(self.g.data), _ptr(self.h.data),
-               _ptr(self.x.data), _ptr(self.y.data), _ptr(self.stats), self.plan.B, self.N, self.f.Cs, self.h.Cs)
+               _ptr(self.x.data), _ptr(self.y.data), _ptr(self.stats), self.plan.B, self.N, self.f.Cs, self.h.Cs, key=self.fkey)
 
     def bwd(self, s):
         if self.y.grad is None:
             return
         L.call("msau_selfattn_bwd", s, self.plan.dtype, _ptr(self.f.data), _ptr(self.g.data), _ptr(self.h.data),
                _ptr(self.y.grad), _ptr(self.stats), _ptr(self.f.grad), _ptr(self.g.grad), _ptr(self.h.grad),
-               _ptr(self.ws), self.plan.B, self.N, self.f.Cs, self.h.Cs)
+               _ptr(self.ws), self.plan.B, self.N, self.f.Cs, self.h.Cs, key=self.bkey)
 
 
 class Plan:
@@ -671,6 +736,7 @@ class Plan:
         self._pack_max = 1
         self._unpack_max = 1
         self.launch_meta: Dict[str, Tuple[int, float, float]] = {}
+        self.rec_meta: Dict[int, Tuple[str, float]] = {}       # address of a launch record's args -> (kernel key, bytes)
         self._cur_stage = 0
         # The weight gradients form no dependency chain (each reads a finished out.grad and writes its own slabs),
         # so they run on a side stream beside the data-gradient chain.  Measured 2026-10-03 with the lean kernels:
@@ -853,6 +919,10 @@ class Plan:
         for pr in self.pairs:
             pr.bind()
             pr.note()
+        for op in self.ops:
+            if not isinstance(op, ConvOp):
+                op.note()
+        self._note_boundary()
         self._fwd_seq = self._make_seq([r for op in self.ops for r in op.fwd_recs()])
         self.pack_table = self._upload(self._pack_entries, L.PackEntry) if self._pack_entries else None
         self.unpack_table = self._upload(self._unpack_entries, L.UnpackEntry) if self._unpack_entries else None
@@ -935,6 +1005,44 @@ class Plan:
         for a in self.acts:                       # anything no op touches (custom builders)
             if a.data is None:
                 take(a)
+
+    def _note_boundary(self):
+        """launches outside the op list: parameter packing, NCHW fp32 -> NHWC conversion of the API input, masked CE (+ label
+        counting), slab reduction, clip + Adam -- so that `launch_meta` sums to the whole step"""
+        esz = 4 if self.dtype == L.F32 else 2
+        a = self.x_in
+        self.in_bytes = self.B * a.C * a.H * a.W * 4 + a.npix * a.Cs * esz
+        self.note_launch("msau_nchw_to_nhwc", self.in_bytes, 0.0)
+        nparam = sum(int(math.prod(shp)) for shp in self.pshape.values())
+        self.note_launch("msau_pack_params", nparam * 4 + self._pack_bytes, 0.0)
+        if self.training:
+            HW = self.H * self.W
+            lg = self.logits
+            nl = 2 if self.aux is not None else 1
+            self.note_launch("msau_label_counts", self.B * HW * 8, 0.0)
+            self.ce_bytes = self.B * HW * (8 + nl * 2 * lg.Cs * esz)
+            self.note_launch("msau_masked_ce_multi" if lg.Cs <= 16 else "msau_masked_ce", self.ce_bytes, 0.0)
+            self.reduce_bytes = self._slab_elems * 4 + nparam * 4
+            self.note_launch("msau_wgrad_reduce", self.reduce_bytes, 0.0)
+            self.note_launch("msau_clip_adam_step", nparam * 4 * 8, 0.0)       # g twice, p, m, v read; p, m, v written
+
+    def set_probe_keys(self, keys) -> List[Tuple[str, float]]:
+        """Mark every MAIN-stream launch whose kernel key is in `keys` (None: unmark all) with MSAU_OP_PROBE in the forward
+        and backward sequences.  Returns [(key, algorithmic bytes)] of the marked launches in the order `read_probe`
+        reports their durations (sequence order; side-stream launches are not probed: they are released in batches)."""
+        order = []
+        for seq in (self._fwd_seq, self._bwd_seq):
+            if seq is None:
+                continue
+            arr, cnt, _ = seq
+            for i in range(cnt):
+                meta = self.rec_meta.get(arr[i].args)
+                if keys is not None and meta is not None and meta[0] in keys and not (arr[i].kind & L.OP_SIDE):
+                    arr[i].kind |= L.OP_PROBE
+                    order.append(meta)
+                else:
+                    arr[i].kind &= ~L.OP_PROBE
+        return order
 
     def set_probe(self, key: Optional[str]) -> int:
         """Mark (or with None: unmark) every conv launch whose kernel symbol is `key` with MSAU_OP_PROBE in the forward
@@ -1033,10 +1141,15 @@ class Plan:
                    self.head_argmax.data_ptr(), lg.npix, lg.C, lg.Cs)
         return self.head_probs, self.head_argmax
 
-    def forward(self, flat_params: torch.Tensor, x_nchw: torch.Tensor, export: bool = True):
+    def forward(self, flat_params: torch.Tensor, x_nchw: Optional[torch.Tensor], export: bool = True,
+                ids: Optional[torch.Tensor] = None):
+        """`ids` (int32 [B,H,W] character ids, -1 = empty) instead of `x_nchw`: the one-hot grid is painted on the device"""
         s = self._stream()
         self.pack(flat_params)
-        self.load_input(x_nchw)
+        if ids is not None:
+            self.load_ids(ids)
+        else:
+            self.load_input(x_nchw)
         if L._profiler is None:
             self._run_seq(self._fwd_seq, s)          # one C call enqueues the whole forward sweep
         else:

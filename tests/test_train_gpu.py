@@ -279,3 +279,29 @@ def test_device_dense_rasteriser_matches_cpu_painter(dtype, tmp_path):
         assert torch.equal(grid[0, :, :, :C].float().cpu(), want.float()), i   # bit exact in the storage type
         assert float(grid[0, :, :, C:].abs().max()) == 0.0 if grid.shape[3] > C else True
         assert torch.equal(labels[0].cpu(), it["label"][0].long()), i
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_training_from_id_masks_equals_dense_one_hot_input(dtype):
+    """TrainEngine.step_ids (N1: only the character-id mask crosses the boundary; the one-hot grid is painted on the device)
+    against TrainEngine.step on the dense float tensor of the same ids: every bit of loss, gradients and updated
+    parameters.  Includes ids outside the charset (painted as empty pixels, like unknown characters in the reference's
+    `transform_from_charset`, funsd_preprocessing_word_level.py:50-57)."""
+    g, cfg, sd, x, label = load_net_case("net_cfg2_336x256x64")
+    C = cfg["channels"]
+    gen = torch.Generator().manual_seed(5)
+    ids = torch.randint(-1, C + 2, (2, 336, 256), generator=gen, dtype=torch.int32)      # -1, C, C+1: empty
+    ids[torch.rand(ids.shape, generator=gen) < 0.6] = -1
+    valid = (ids >= 0) & (ids < C)
+    dense = torch.zeros(2, C, 336, 256)
+    dense.scatter_(1, ids.clamp(0, C - 1).long()[:, None], valid[:, None].float())
+    lab = torch.randint(1, cfg["n_class"], ids.shape, generator=gen) * valid.long()
+    res = []
+    for feed in ("dense", "ids"):
+        m = _model(cfg, sd, dtype, deterministic=True)
+        eng = TrainEngine(m)
+        for _ in range(2):
+            loss = eng.step(dense.cuda(), lab.cuda()) if feed == "dense" else eng.step_ids(ids.cuda(), lab.cuda())
+        torch.cuda.synchronize()
+        res.append((float(loss), eng.flat_grad.clone(), m.flat_parameters.clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])

@@ -13,6 +13,7 @@ import torch
 from msau_amd import _lib as L
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+only = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # channel count to run (0: all)
 dev = torch.device("cuda")
 s = torch.cuda.current_stream().cuda_stream
 B = 16
@@ -33,6 +34,8 @@ def timed(fn):
 
 
 for (H, W, Cc) in ((336, 256, 8), (168, 128, 16)):
+    if only and Cc != only:
+        continue
     n = B * H * W * Cc
     t = lambda: (torch.randn(B, H, W, Cc, device=dev) * 0.5).to(torch.bfloat16)
     x, r1, out, g, gr1, gx = t(), t(), t(), t(), t(), t()
