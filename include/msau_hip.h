@@ -40,7 +40,7 @@ int msau_version(void);
 /* sizeof() of the structs below as the library was compiled, for bindings that mirror them (a mirror that is too short
  * makes the library read past it): which = 0 msau_conv_desc, 1 msau_wgrad_desc, 2 msau_pack_entry, 3 msau_unpack_entry,
  * 4 msau_op, 5 msau_lrn_args, 6 msau_pool_args, 7 msau_attn_args, 8 msau_csum_args, 9 msau_reduce_args,
- * 10 msau_conv_pack_geom, 11 msau_wgrad_geom, 12 msau_conv_pair_desc; -1 for anything else. */
+ * 10 msau_conv_pack_geom, 11 msau_wgrad_geom, 12 msau_conv_pair_desc, 13 msau_box_args; -1 for anything else. */
 int msau_sizeof(int which);
 
 /* ------------------------------------------------------------------------------------------
@@ -333,6 +333,50 @@ int msau_raster_dense(void* stream, int dtype, const int32_t* boxes, const int32
                       void* grid_nhwc, int B, int H, int W, int C, int Cs);
 
 /* ------------------------------------------------------------------------------------------
+ * Box convolution for the model/model_box.py variant (MultiBoxConvBlock, model_box.py:9-59: BoxConv2d(c, 3, 28, 28)
+ * from the third-party package `box_convolution`, then a 1x1 conv).  PARITY UNPINNED: that package is absent and the
+ * reference holds no fixtures for it; the arithmetic follows the published definition (Burkov & Lempitsky, NeurIPS
+ * 2018) and is checked against oracle/box_oracle.py only.  Pixels are unit squares, zero outside the image:
+ *   out[b,y,x,c*F+f] = 1/A * integral over rows [y+hmin, y+hmax+1) x columns [x+wmin, x+wmax+1) of in[b,.,.,c],
+ *   A = (hmax-hmin+1)*(wmax-wmin+1), (hmin,hmax,wmin,wmax)[c][f] = stored parameter * max box size (real-valued).
+ *   msau_box_integral  : NHWC `dtype` input -> fp32 integral image, channel-planar [B][C][H+1][W+1]
+ *   msau_box_params    : stored parameters (four [C][F] tensors inside the flat fp32 parameter buffer, element offsets)
+ *                        -> boxes in pixels fp32 [4][C][F], kept valid (|edge| <= max size, max >= min), and the
+ *                        reflected boxes the input gradient uses
+ *   msau_box_filter    : the box filter read from an integral image; sum_filters = 1: out[c] = sum over the F filters
+ *                        (input gradient = msau_box_filter on the integral image of the output gradient with the
+ *                        reflected boxes); accumulate = 1: added to `out`
+ *   msau_box_param_grad: d loss / d stored parameters, written (not accumulated) into the flat fp32 gradient buffer;
+ *                        ws: msau_box_pgrad_ws_floats() floats of scratch (per-workgroup partials, ordered final sum)
+ * ------------------------------------------------------------------------------------------ */
+int msau_box_integral(void* stream, int dtype, const void* in_nhwc, float* ii, int B, int H, int W, int C, int Cs, int relu_in);
+int msau_box_params(void* stream, const float* flat_params, int64_t off_hmin, int64_t off_hmax, int64_t off_wmin, int64_t off_wmax,
+                    int C, int F, float max_h, float max_w, float* params_fwd, float* params_refl);
+/* sum_filters = 0: ii has C planes, out[c*F+f].  sum_filters = 1 (input gradient): ii has C*F planes (plane c*F+f is
+ * filtered with box c*F+f), out[c] = sum over f.  Epilogue as msau_conv2d: v *= (mask_a > 0); v += add; v += out
+ * (accumulate); v *= (mask_b > 0); the three operands share out's shape and may be NULL. */
+int msau_box_filter(void* stream, int dtype, const float* ii, const float* params, void* out_nhwc, int B, int H, int W, int C, int F,
+                    int Cs_out, int sum_filters, int accumulate, const void* mask_a, const void* add, const void* mask_b);
+int64_t msau_box_pgrad_ws_floats(int B, int H, int W, int C, int F);
+int msau_box_param_grad(void* stream, int dtype, const float* ii, const float* params, const void* gout_nhwc, float* ws, float* flat_grads,
+                        int64_t off_hmin, int64_t off_hmax, int64_t off_wmin, int64_t off_wmax, int B, int H, int W, int C, int F,
+                        int Cs_out, float max_h, float max_w);
+
+/* one box conv inside a launch sequence (MSAU_OP_BOX_FWD / MSAU_OP_BOX_BWD):
+ *   forward : ii = integral(ReLU?(in)); out = box_filter(ii, params_fwd)
+ *   backward: box-parameter gradient (ii, gout) -> flat_grads; ii_g = integral(gout); gin = epilogue(box_filter(ii_g, params_refl, sum)) */
+typedef struct {
+    const void* in; float* ii; const float* params_fwd; const float* params_refl; void* out;
+    const void* gout; void* gin; float* ii_g; float* ws; float* flat_grads;
+    const void* mask_a; const void* add; const void* mask_b;
+    int64_t off_hmin, off_hmax, off_wmin, off_wmax;
+    int32_t B, H, W, C, F, Cs_in, Cs_out, relu_in, accumulate;
+    float max_h, max_w;
+} msau_box_args;
+int msau_box_fwd(void* stream, int dtype, const msau_box_args* a);
+int msau_box_bwd(void* stream, int dtype, const msau_box_args* a);
+
+/* ------------------------------------------------------------------------------------------
  * Launch-sequence executor: one call enqueues a whole pre-built list of the launches above (the static
  * plan of a forward or backward sweep), so the host cost per launch is a switch, not a Python/ctypes
  * round trip.  `args` points to the msau_*_args / descriptor struct of the op's kind; all pointers
@@ -349,7 +393,9 @@ enum {
     MSAU_OP_ATTN_BWD = 8,    /* args: msau_attn_args          */
     MSAU_OP_CHANNEL_SUM = 9, /* args: msau_csum_args          */
     MSAU_OP_WGRAD_REDUCE = 10, /* args: msau_reduce_args      */
-    MSAU_OP_CONV_PAIR = 11   /* args: msau_conv_pair_desc     */
+    MSAU_OP_CONV_PAIR = 11,  /* args: msau_conv_pair_desc     */
+    MSAU_OP_BOX_FWD = 12,    /* args: msau_box_args           */
+    MSAU_OP_BOX_BWD = 13     /* args: msau_box_args           */
 };
 typedef struct { int32_t kind; int32_t dtype; const void* args; } msau_op;
 typedef struct { const void* a; const void* dy; void* out; int64_t npix; int32_t C, Cs, n; float alpha, beta, k; } msau_lrn_args;

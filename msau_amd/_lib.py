@@ -33,6 +33,14 @@ class ConvPairDesc(C.Structure):
 PAIR_RELU_IN, PAIR_RELU_MID, PAIR_MASK_MID = 1, 2, 4
 
 
+class BoxArgs(C.Structure):
+    _fields_ = [(n, vp) for n in ("in_", "ii", "params_fwd", "params_refl", "out", "gout", "gin", "ii_g", "ws", "flat_grads",
+                                  "mask_a", "add", "mask_b")] + \
+               [(n, i64) for n in ("off_hmin", "off_hmax", "off_wmin", "off_wmax")] + \
+               [(n, i32) for n in ("B", "H", "W", "C", "F", "Cs_in", "Cs_out", "relu_in", "accumulate")] + \
+               [("max_h", f32), ("max_w", f32)]
+
+
 class ConvPackGeom(C.Structure):
     _fields_ = [("cch", i32), ("nchunks", i32), ("kchunk", i32), ("rows", i32), ("bytes", i64)]
 
@@ -94,6 +102,7 @@ OP_PROBE = 0x200
 OP_JOIN = 0x800
 OP_WGRAD_REDUCE = 10
 OP_CONV_PAIR = 11
+OP_BOX_FWD, OP_BOX_BWD = 12, 13
 OP_CONV2D, OP_WGRAD, OP_LRN_FWD, OP_LRN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_CHANNEL_SUM = range(1, 10)
 
 _SIGNATURES = {
@@ -131,6 +140,13 @@ _SIGNATURES = {
     "msau_raster_onehot": (C.c_int, [vp, C.c_int, vp, vp, vp] + [C.c_int] * 5),
     "msau_raster_labels": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "msau_raster_dense": (C.c_int, [vp, C.c_int, vp, vp, vp, vp] + [C.c_int] * 5),
+    "msau_box_integral": (C.c_int, [vp, C.c_int, vp, vp] + [C.c_int] * 6),
+    "msau_box_params": (C.c_int, [vp, vp, i64, i64, i64, i64, C.c_int, C.c_int, f32, f32, vp, vp]),
+    "msau_box_filter": (C.c_int, [vp, C.c_int, vp, vp, vp] + [C.c_int] * 8 + [vp, vp, vp]),
+    "msau_box_fwd": (C.c_int, [vp, C.c_int, C.POINTER(BoxArgs)]),
+    "msau_box_bwd": (C.c_int, [vp, C.c_int, C.POINTER(BoxArgs)]),
+    "msau_box_pgrad_ws_floats": (i64, [C.c_int] * 5),
+    "msau_box_param_grad": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, i64, i64, i64, i64] + [C.c_int] * 6 + [f32, f32]),
     "msau_run_ops": (C.c_int, [vp, C.POINTER(Op), C.c_int]),
     "msau_run_ops_overlap": (C.c_int, [vp, vp, C.POINTER(Op), C.c_int, C.c_int]),
     "msau_spin": (C.c_int, [vp, C.c_int]),
@@ -146,7 +162,7 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 # ctypes mirrors in the order of msau_sizeof(which): load() refuses a library whose structs have another size
 ABI_STRUCTS = (ConvDesc, WgradDesc, PackEntry, UnpackEntry, Op, LrnArgs, PoolArgs, AttnArgs, CsumArgs, ReduceArgs,
-               ConvPackGeom, WgradGeom, ConvPairDesc)
+               ConvPackGeom, WgradGeom, ConvPairDesc, BoxArgs)
 
 
 class MsauHipError(RuntimeError):

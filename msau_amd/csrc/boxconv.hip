@@ -25,7 +25,7 @@ namespace {
 
 // ---- integral image, pass A: vertical running sums, NHWC T -> planar fp32 [B][C][H+1][W+1] (row 0 / column 0 zero)
 template <typename T>
-__global__ __launch_bounds__(256) void box_integral_cols_kernel(const T* __restrict__ in, float* __restrict__ ii, int H, int W, int Cs, int C) {
+__global__ __launch_bounds__(256) void box_integral_cols_kernel(const T* __restrict__ in, float* __restrict__ ii, int H, int W, int Cs, int C, int relu_in) {
     // block = 64 columns x all channels of image b; a row of the tile is one contiguous 64*Cs run in NHWC
     extern __shared__ float tile[];                         // [C][65]
     const int b = blockIdx.y, x0 = blockIdx.x * 64;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void box_integral_cols_kernel(const T* __restr
         const T* row = in + (((int64_t)b * H + y) * W + x0) * Cs;
         for (int i = threadIdx.x; i < nx * Cs; i += 256) {
             const int xx = i / Cs, c = i - xx * Cs;
-            if (c < C) tile[c * 65 + xx] = (float)row[i];
+            if (c < C) tile[c * 65 + xx] = relu_in ? fmaxf((float)row[i], 0.f) : (float)row[i];
         }
         __syncthreads();
         for (int i = threadIdx.x; i < C * nx; i += 256) {
@@ -84,10 +84,6 @@ __global__ __launch_bounds__(256) void box_integral_rows_kernel(float* __restric
     }
 }
 
-struct BoxGeom {                                            // one (channel, filter) box at output row y: all wave-uniform
-    float r1, r2, wmin, wmax1, inv_area;
-};
-
 __device__ __forceinline__ float lerp_ii(const float* __restrict__ plane, int W1, int i, float fi, int j, float fj, int H, int W) {
     // bilinear interpolation of II at (i + fi, j + fj), i in [0, H], j in [0, W]; taps beyond the last row / column have
     // weight 0 there (fi = 0 when i == H), so clamp the index instead of branching
@@ -110,7 +106,8 @@ __device__ __forceinline__ void split(float v, float hi, int& i, float& f) {
 // gradient the caller passes the reflected boxes).  SUMF: out[c] = sum_f (input gradient), else out[c*F + f].
 template <typename T, bool SUMF>
 __global__ __launch_bounds__(256) void box_filter_kernel(const float* __restrict__ ii, const float* __restrict__ params, T* __restrict__ out,
-                                                         int H, int W, int C, int F, int Cs_out, int accumulate) {
+                                                         int H, int W, int C, int F, int Cs_out, int accumulate,
+                                                         const T* __restrict__ mask_a, const T* __restrict__ add, const T* __restrict__ mask_b) {
     extern __shared__ float stile[];                        // [64][NOUT + 1]
     const int NOUT = SUMF ? C : C * F;
     const int b = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * 64;
@@ -120,10 +117,11 @@ __global__ __launch_bounds__(256) void box_filter_kernel(const float* __restrict
     const int64_t plane = (int64_t)(H + 1) * W1;
     const int CF = C * F;
     for (int c = wave; c < C; c += 4) {
-        const float* pl = ii + ((int64_t)b * C + c) * plane;
         float sumf = 0.f;
         for (int f = 0; f < F; ++f) {
             const int p = c * F + f;
+            // forward: the integral image of input channel c; input gradient (SUMF): of output-gradient channel c*F + f
+            const float* pl = ii + ((int64_t)b * (SUMF ? CF : C) + (SUMF ? p : c)) * plane;
             const float hmin = params[p], hmax = params[CF + p], wmin = params[2 * CF + p], wmax = params[3 * CF + p];
             const float inv_area = 1.f / ((hmax - hmin + 1.f) * (wmax - wmin + 1.f));
             int i1, i2, j1, j2;
@@ -144,10 +142,15 @@ __global__ __launch_bounds__(256) void box_filter_kernel(const float* __restrict
     // coalesced NHWC store (padded channels written as zero)
     const int nx = min(64, W - x0);
     T* orow = out + (((int64_t)b * H + y) * W + x0) * Cs_out;
+    // epilogue in the order of msau_conv2d: v *= (mask_a > 0); v += add; v += old (accumulate); v *= (mask_b > 0)
+    const int64_t rowoff = (((int64_t)b * H + y) * W + x0) * Cs_out;
     for (int i = threadIdx.x; i < nx * Cs_out; i += 256) {
         const int xx = i / Cs_out, ch = i - xx * Cs_out;
         float v = ch < NOUT ? stile[xx * (NOUT + 1) + ch] : 0.f;
+        if (mask_a) v = (float)mask_a[rowoff + i] > 0.f ? v : 0.f;
+        if (add) v += (float)add[rowoff + i];
         if (accumulate) v += (float)orow[i];
+        if (mask_b) v = (float)mask_b[rowoff + i] > 0.f ? v : 0.f;
         orow[i] = (T)v;
     }
 }
@@ -269,7 +272,7 @@ __global__ void box_params_kernel(const float* __restrict__ flat, int64_t off0, 
 
 }  // namespace
 
-extern "C" int msau_box_integral(void* stream, int dtype, const void* in, float* ii, int B, int H, int W, int C, int Cs) {
+extern "C" int msau_box_integral(void* stream, int dtype, const void* in, float* ii, int B, int H, int W, int C, int Cs, int relu_in) {
     MSAU_CHECK_ARG(in && ii && B > 0 && H > 0 && W > 0 && C > 0 && C <= Cs && Cs % 8 == 0 && C <= 512, "box_integral: bad args");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t lds = (size_t)C * (65 + 64) * sizeof(float);
@@ -277,10 +280,10 @@ extern "C" int msau_box_integral(void* stream, int dtype, const void* in, float*
     dim3 grid(cdiv(W, 64), B);
     if (dtype == MSAU_F32) {
         if (lds > 60 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&box_integral_cols_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
-        hipLaunchKernelGGL(box_integral_cols_kernel<float>, grid, dim3(256), lds, s, static_cast<const float*>(in), ii, H, W, Cs, C);
+        hipLaunchKernelGGL(box_integral_cols_kernel<float>, grid, dim3(256), lds, s, static_cast<const float*>(in), ii, H, W, Cs, C, relu_in);
     } else if (dtype == MSAU_BF16) {
         if (lds > 60 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&box_integral_cols_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
-        hipLaunchKernelGGL(box_integral_cols_kernel<bf16_t>, grid, dim3(256), lds, s, static_cast<const bf16_t*>(in), ii, H, W, Cs, C);
+        hipLaunchKernelGGL(box_integral_cols_kernel<bf16_t>, grid, dim3(256), lds, s, static_cast<const bf16_t*>(in), ii, H, W, Cs, C, relu_in);
     } else return msau_set_error(MSAU_ERR_ARG, "box_integral: bad dtype");
     MSAU_CHECK_LAUNCH("box_integral_cols");
     const int64_t nrows = (int64_t)B * C * (H + 1);
@@ -300,7 +303,7 @@ extern "C" int msau_box_params(void* stream, const float* flat_params, int64_t o
 }
 
 extern "C" int msau_box_filter(void* stream, int dtype, const float* ii, const float* params, void* out, int B, int H, int W, int C, int F,
-                               int Cs_out, int sum_filters, int accumulate) {
+                               int Cs_out, int sum_filters, int accumulate, const void* mask_a, const void* add, const void* mask_b) {
     MSAU_CHECK_ARG(ii && params && out && B > 0 && H > 0 && W > 0 && C > 0 && F > 0 && Cs_out % 8 == 0, "box_filter: bad args");
     const int nout = sum_filters ? C : C * F;
     MSAU_CHECK_ARG(nout <= Cs_out, "box_filter: %d output channels do not fit the stored %d", nout, Cs_out);
@@ -308,7 +311,8 @@ extern "C" int msau_box_filter(void* stream, int dtype, const float* ii, const f
     const size_t lds = (size_t)64 * (nout + 1) * sizeof(float);
     MSAU_CHECK_ARG(lds <= 60 * 1024, "box_filter: too many output channels (%d)", nout);
     dim3 grid(cdiv(W, 64), H, B);
-#define BOXF(T, S) hipLaunchKernelGGL((box_filter_kernel<T, S>), grid, dim3(256), lds, s, ii, params, static_cast<T*>(out), H, W, C, F, Cs_out, accumulate)
+#define BOXF(T, S) hipLaunchKernelGGL((box_filter_kernel<T, S>), grid, dim3(256), lds, s, ii, params, static_cast<T*>(out), H, W, C, F, Cs_out, accumulate, \
+                                   static_cast<const T*>(mask_a), static_cast<const T*>(add), static_cast<const T*>(mask_b))
     if (dtype == MSAU_F32) { if (sum_filters) BOXF(float, true); else BOXF(float, false); }
     else if (dtype == MSAU_BF16) { if (sum_filters) BOXF(bf16_t, true); else BOXF(bf16_t, false); }
     else return msau_set_error(MSAU_ERR_ARG, "box_filter: bad dtype");
@@ -340,4 +344,25 @@ extern "C" int msau_box_param_grad(void* stream, int dtype, const float* ii, con
     hipLaunchKernelGGL(box_pgrad_reduce_kernel, dim3(4 * CF), dim3(256), 0, s, ws, nblk, CF, flat_grads, off_hmin, off_hmax, off_wmin, off_wmax, max_h, max_w);
     MSAU_CHECK_LAUNCH("box_pgrad_reduce");
     return 0;
+}
+
+// ---- launch-sequence records (msau_run_ops): one box conv forward / backward sweep step
+extern "C" int msau_box_fwd(void* stream, int dtype, const msau_box_args* a) {
+    MSAU_CHECK_ARG(a && a->in && a->ii && a->params_fwd && a->out, "box_fwd: null pointer");
+    int rc = msau_box_integral(stream, dtype, a->in, a->ii, a->B, a->H, a->W, a->C, a->Cs_in, a->relu_in);
+    if (rc) return rc;
+    return msau_box_filter(stream, dtype, a->ii, a->params_fwd, a->out, a->B, a->H, a->W, a->C, a->F, a->Cs_out, 0, 0, nullptr, nullptr, nullptr);
+}
+
+extern "C" int msau_box_bwd(void* stream, int dtype, const msau_box_args* a) {
+    MSAU_CHECK_ARG(a && a->ii && a->params_fwd && a->params_refl && a->gout && a->ws && a->flat_grads && a->ii_g, "box_bwd: null pointer");
+    // (1) box parameters: needs the forward integral image (kept) and the output gradient
+    int rc = msau_box_param_grad(stream, dtype, a->ii, a->params_fwd, a->gout, a->ws, a->flat_grads, a->off_hmin, a->off_hmax, a->off_wmin,
+                                 a->off_wmax, a->B, a->H, a->W, a->C, a->F, a->Cs_out, a->max_h, a->max_w);
+    if (rc || !a->gin) return rc;
+    // (2) input: the reflected boxes over the integral image of the output gradient, summed over the filters
+    rc = msau_box_integral(stream, dtype, a->gout, a->ii_g, a->B, a->H, a->W, a->C * a->F, a->Cs_out, 0);
+    if (rc) return rc;
+    return msau_box_filter(stream, dtype, a->ii_g, a->params_refl, a->gin, a->B, a->H, a->W, a->C, a->F, a->Cs_in, 1, a->accumulate,
+                           a->mask_a, a->add, a->mask_b);
 }

@@ -12,7 +12,8 @@
 namespace {
 
 struct ConvGeom {
-    int esz, taps, cch, nchunks, kchunk, rows, CT, ngroups;   // ngroups = kchunk / 8
+    int esz, taps, cch, nchunks, kchunk, rows, CT, ngroups;   // ngroups = kchunk / 8; rows / CT are those of ONE slice
+    int nslices;                                              // output-channel slices of <= 128 rows (Cout > 128)
 };
 
 __host__ __device__ inline int pix_stride_bytes(int cch, int esz) {
@@ -44,11 +45,16 @@ int conv_geom(int dtype, int C1, int C2, int Cout, int KH, int KW, int dil, int 
     MSAU_CHECK_ARG(Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 8 == 0, "conv: channels must be multiples of 8 (%d,%d)", Cin, Cout);
     MSAU_CHECK_ARG(KH >= 1 && KW >= 1 && KH <= 7 && KW <= 7 && dil >= 1, "conv: bad kernel %dx%d dil %d", KH, KW, dil);
     MSAU_CHECK_ARG((stride == 1 || stride == 2) && (ups == 1 || ups == 2) && !(stride == 2 && ups == 2), "conv: bad stride/ups");
-    MSAU_CHECK_ARG(Cout <= 128, "conv: Cout %d > 128 unsupported", Cout);
+    MSAU_CHECK_ARG(Cout <= 1024, "conv: Cout %d > 1024 unsupported", Cout);
     ConvGeom g;
     g.esz = dtype == MSAU_F32 ? 4 : 2;
     g.taps = KH * KW;
-    int ct = cdiv(Cout, 16);
+    // more than 128 output channels (8 accumulator tiles per wave): the launch is cut into slices of 128 channels, each
+    // with its own 128-row sub-image [slice][chunk][row][k]; msau_conv2d runs one generic launch per slice, writing its
+    // channels into the full-width output (the 256-channel levels of the reference's constructor defaults; the 3c-wide
+    // data gradient of the box variant's 1x1 convs)
+    g.nslices = Cout > 128 ? cdiv(Cout, 128) : 1;
+    int ct = cdiv(g.nslices > 1 ? 128 : Cout, 16);
     g.CT = ct <= 1 ? 1 : ct <= 2 ? 2 : ct <= 4 ? 4 : 8;
     g.rows = g.CT * 16;
     int best = 0;
@@ -83,6 +89,7 @@ int conv_geom(int dtype, int C1, int C2, int Cout, int KH, int KW, int dil, int 
 
 struct ConvArgs {
     msau_conv_desc d;
+    int ystride;                                 // channels per pixel of the output tensor (>= d.Cout when the launch is a slice)
     int cch, nchunks, kchunk, ngroups;
     int TIH, TIW, PS, WS;
     int in_bytes, w_bytes;
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
     for (int pt = 0; pt < PT; ++pt) {
         const int oy = oy0 + wave * PT + pt, ox = ox0 + lr;
         if (oy >= d.Hout || ox >= d.Wout) continue;
-        const size_t pbase = (((size_t)b * d.Hout + oy) * d.Wout + ox) * Cout;
+        const size_t pbase = (((size_t)b * d.Hout + oy) * d.Wout + ox) * a.ystride;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int co = lg * (CT * 4) + ct * 4;
@@ -282,8 +289,8 @@ extern "C" int msau_conv_pack_geometry(int dtype, int C1, int C2, int Cout, int 
     ConvGeom g;
     int rc = conv_geom(dtype, C1, C2, Cout, KH, KW, dil, stride, ups, &g);
     if (rc) return rc;
-    out->cch = g.cch; out->nchunks = g.nchunks; out->kchunk = g.kchunk; out->rows = g.rows;
-    out->bytes = (int64_t)g.nchunks * g.rows * g.kchunk * g.esz;
+    out->cch = g.cch; out->nchunks = g.nchunks; out->kchunk = g.kchunk; out->rows = g.rows * g.nslices;
+    out->bytes = (int64_t)g.nslices * g.nchunks * g.rows * g.kchunk * g.esz;
     return 0;
 }
 
@@ -346,15 +353,32 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
             return msau_set_error(MSAU_ERR_ARG, "conv2d: MSAU_CONV_DOUT is not implemented for this launch (see "
                                   "msau_conv2d_launch_info info[7]); issue one launch per output instead");
     }
-    rc = msau_conv_lean_try(static_cast<hipStream_t>(stream), dtype, d, g.kchunk, g.nchunks, g.CT);
-    if (rc != 0) return rc < 0 ? rc : 0;
+    if (g.nslices == 1) {
+        rc = msau_conv_lean_try(static_cast<hipStream_t>(stream), dtype, d, g.kchunk, g.nchunks, g.CT);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     if (d->flags & MSAU_CONV_DOUT) return msau_set_error(MSAU_ERR_ARG, "conv2d: DOUT launch was not taken by a lean instance");
-    ConvArgs a;
-    a.d = *d;
-    a.cch = g.cch; a.nchunks = g.nchunks; a.kchunk = g.kchunk; a.ngroups = g.ngroups;
-    a.TIH = t.TIH; a.TIW = t.TIW; a.PS = t.PS; a.WS = t.WS; a.in_bytes = t.in_bytes; a.w_bytes = t.w_bytes;
-    a.tiles_x = cdiv(d->Wout, 16); a.tiles_y = cdiv(d->Hout, 4 * PT);
+    MSAU_CHECK_ARG(g.nslices == 1 || !(d->flags & MSAU_CONV_HEAD), "conv2d: HEAD with more than 128 output channels");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == MSAU_F32) return launch_conv_ct<float>(s, a, g.CT, PT, (int)nb, t.total);
-    return launch_conv_ct<bf16_t>(s, a, g.CT, PT, (int)nb, t.total);
+    for (int sl = 0; sl < g.nslices; ++sl) {
+        ConvArgs a;
+        a.d = *d;
+        a.ystride = d->Cout;
+        if (g.nslices > 1) {                                  // this slice's rows / channels [128*sl, 128*sl + n)
+            const size_t co0 = (size_t)sl * 128, esz = g.esz;
+            a.d.Cout = d->Cout - (int)co0 < 128 ? d->Cout - (int)co0 : 128;
+            a.d.wpack = static_cast<const char*>(d->wpack) + (size_t)sl * g.nchunks * g.rows * g.kchunk * esz;
+            if (d->bias) a.d.bias = d->bias + co0;
+            a.d.y = static_cast<char*>(d->y) + co0 * esz;
+            if (d->add) a.d.add = static_cast<const char*>(d->add) + co0 * esz;
+            if (d->mask_a) a.d.mask_a = static_cast<const char*>(d->mask_a) + co0 * esz;
+            if (d->mask_b) a.d.mask_b = static_cast<const char*>(d->mask_b) + co0 * esz;
+        }
+        a.cch = g.cch; a.nchunks = g.nchunks; a.kchunk = g.kchunk; a.ngroups = g.ngroups;
+        a.TIH = t.TIH; a.TIW = t.TIW; a.PS = t.PS; a.WS = t.WS; a.in_bytes = t.in_bytes; a.w_bytes = t.w_bytes;
+        a.tiles_x = cdiv(d->Wout, 16); a.tiles_y = cdiv(d->Hout, 4 * PT);
+        rc = dtype == MSAU_F32 ? launch_conv_ct<float>(s, a, g.CT, PT, (int)nb, t.total) : launch_conv_ct<bf16_t>(s, a, g.CT, PT, (int)nb, t.total);
+        if (rc) return rc;
+    }
+    return 0;
 }

@@ -32,6 +32,7 @@ extern "C" int msau_sizeof(int which) {
         case 10: return (int)sizeof(msau_conv_pack_geom);
         case 11: return (int)sizeof(msau_wgrad_geom);
         case 12: return (int)sizeof(msau_conv_pair_desc);
+        case 13: return (int)sizeof(msau_box_args);
         default: return -1;
     }
 }
@@ -56,16 +57,19 @@ __global__ void pack_kernel(const float* __restrict__ params, unsigned char* __r
         return;
     }
     const int taps = e.KH * e.KW;
-    const int CT = e.rows_pad >> 4;
+    // more than 128 rows: slices of 128 rows, image [slice][chunk][row][k], the row permutation is per slice (conv.hip)
+    const int srows = e.rows_pad > 128 ? 128 : e.rows_pad;
+    const int CT = srows >> 4;
     const int64_t total = (int64_t)e.nchunks * e.rows_pad * e.kchunk;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int k = (int)(i % e.kchunk);
         int64_t r = i / e.kchunk;
-        int slot = (int)(r % e.rows_pad);
-        int chunk = (int)(r / e.rows_pad);
+        int slot = (int)(r % srows);
+        int chunk = (int)((r / srows) % e.nchunks);
+        int slice = (int)(r / ((int64_t)srows * e.nchunks));
         // row slot (ct*16 + 4q + j)  <->  output channel q*CT*4 + ct*4 + j   (epilogue layout of conv.hip)
         int ct = slot >> 4, q = (slot >> 2) & 3, j = slot & 3;
-        int row = q * (CT * 4) + ct * 4 + j;
+        int row = slice * 128 + q * (CT * 4) + ct * 4 + j;
         float v = 0.f;
         if (row < e.rows_real && k < taps * e.cch) {
             int tap = k / e.cch, c = k - tap * e.cch;

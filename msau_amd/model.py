@@ -37,6 +37,48 @@ def param_shapes(cfg: dict) -> "OrderedDict[str, Tuple[int, ...]]":
         out[prefix + ".weight"] = (co, ci, kk, kk)
         out[prefix + ".bias"] = (co,)
 
+    if cfg.get("variant") == "box":
+        # model/model_box.py: the residual 3x3 blocks are MultiBoxConvBlocks (:9-59): num_box_convs x [BoxConv2d with four
+        # [c, F] parameters x_min / x_max / y_min / y_max, then a 1x1 conv F*c -> c]; everything else as the plain net
+        n, Fn = cfg["num_box_convs"], cfg["num_box_per_channels"]
+
+        def block(prefix, c):
+            for i in range(n):
+                for nm in ("x_min", "x_max", "y_min", "y_max"):
+                    out[f"{prefix}.conv_list.{2 * i}.{nm}"] = (c, Fn)
+                conv(f"{prefix}.conv_list.{2 * i + 1}.custom_conv", c, Fn * c, 1)
+
+        for b in range(nb):
+            cin = cfg["channels"] if b == 0 else cfg["n_class"]
+            pd = f"msau_net.blocks.{b}.downsamplingblock"
+            pu = f"msau_net.blocks.{b}.upsamplingblock"
+            for l in range(S):
+                block(f"{pd}.conv_box_list.{l}", Fr * 2 ** l)
+            last = cin
+            for l in range(S):
+                conv(f"{pd}.conv1s.{l}.conv", Fr * 2 ** l, last, k)
+                last = Fr * 2 ** l
+            if b > 0:
+                for l in range(S):
+                    conv(f"{pd}.conv1_1s.{l}.custom_conv", Fr * 2 ** l, 2 * Fr * 2 ** l, 1)
+            Cb = Fr * 2 ** (S - 1)
+            for nm, co in (("f", Cb // 8), ("g", Cb // 8), ("h", Cb)):
+                conv(f"{pd}.layer_attentions.attention_block.{nm}.conv", co, Cb, 1)
+            for l in range(S - 1):
+                conv(f"{pu}.conv1s.{l}.custom_conv", Fr * 2 ** l, 2 * Fr * 2 ** l, k)
+            if b > 0:
+                for l in range(S - 1):
+                    conv(f"{pu}.conv1_1s.{l}.custom_conv", Fr * 2 ** l, 2 * Fr * 2 ** l, 1)
+            for l in range(S - 1):
+                c = Fr * 2 ** l
+                out[f"{pu}.deconvs.{l}.conv.weight"] = (2 * c, c, k, k)
+                out[f"{pu}.deconvs.{l}.conv.bias"] = (c,)
+            for l in range(S - 1):
+                block(f"{pu}.conv_box_list.{l}", Fr * 2 ** l)
+        for b in range(nb):
+            conv(f"msau_net.end_convs.{b}.custom_conv", cfg["n_class"], Fr, 4)
+        return out
+
     for b in range(nb):
         cin = cfg["channels"] if b == 0 else cfg["n_class"]
         pd = f"msau_net.blocks.{b}.downsamplingblock"
@@ -202,6 +244,7 @@ class MSAUWrapper(nn.Module):
         self.cfg = dict(channels=channels, n_class=n_class, scale_space_num=self.scale_space_num,
                         res_depth=self.res_depth, featRoot=self.featRoot, filter_size=self.filter_size,
                         pool_size=self.pool_size, num_blocks=self.num_blocks)
+        self.cfg.update(self._variant_cfg(kw))
         for opt in ("reuse_activations", "overlap_wgrad", "overlap_max_pix", "deterministic"):      # execution options of the plan
             if opt in kw:
                 self.cfg[opt] = kw[opt]
@@ -218,10 +261,23 @@ class MSAUWrapper(nn.Module):
         gen = torch.Generator().manual_seed(int(kw.get("seed", torch.initial_seed() % (2 ** 31))))
         self._named = []
         self.msau_net = _Node()
+        boxes: Dict[tuple, tuple] = {}
         for k, shp in shapes.items():
             n = int(math.prod(shp))
-            wshp = shapes[k[:-4] + "weight"] if k.endswith(".bias") else shp
-            self._flat[self._poff[k]:self._poff[k] + n] = _init_param(k, shp, gen, wshp[1] * wshp[2] * wshp[3]).reshape(-1)
+            leaf = k.rsplit(".", 1)[1]
+            if leaf in ("x_min", "x_max", "y_min", "y_max"):
+                # BoxConv2d boxes in units of the max box size: a random centre in the middle half, a random half extent of
+                # 1/28 .. 1/4 (the third-party package's own initialiser is unavailable: unpinned, oracle/box_oracle.py)
+                axis = (k.rsplit(".", 1)[0], leaf[0])
+                if axis not in boxes:
+                    centre = (torch.rand(shp, generator=gen) - 0.5) * 0.5
+                    half = 1.0 / 28 + torch.rand(shp, generator=gen) * (0.25 - 1.0 / 28)
+                    boxes[axis] = (centre - half, centre + half)
+                val = boxes[axis][0 if leaf.endswith("min") else 1]
+            else:
+                wshp = shapes[k[:-4] + "weight"] if k.endswith(".bias") else shp
+                val = _init_param(k, shp, gen, wshp[1] * wshp[2] * wshp[3])
+            self._flat[self._poff[k]:self._poff[k] + n] = val.reshape(-1)
             p = nn.Parameter(self._flat[self._poff[k]:self._poff[k] + n].view(shp))
             self._named.append((k, p))
             node = self
@@ -239,6 +295,10 @@ class MSAUWrapper(nn.Module):
         self._plans: "OrderedDict[tuple, Plan]" = OrderedDict()
         self.max_cached_plans = 4               # LRU bounds: number of plans and bytes of their activation buffers
         self.max_plan_bytes = 64 << 30
+
+    def _variant_cfg(self, kw: dict) -> dict:
+        """extra plan / parameter configuration of a network variant (BMSAUWrapper: the box-convolution blocks)"""
+        return {}
 
     # ---- flat parameter storage ---------------------------------------------------------------
     def _rebind(self):

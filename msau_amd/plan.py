@@ -532,6 +532,103 @@ class PairOp:
             P.note_launch(self.key, self.bbytes, c1.flops + c2.flops)
 
 
+class BoxOp(Op):
+    """BoxConv2d(c, F, max, max) of the model_box.py variant (model/model_box.py:30-33; csrc/boxconv.hip): c -> c*F channels,
+    normalised box integrals read from a fp32 integral image.  PARITY UNPINNED (third-party op, see oracle/box_oracle.py).
+    The forward integral image is kept for the backward (box-parameter gradient); the integral image of the output
+    gradient is a scratch buffer shared by all box ops of the plan."""
+
+    def __init__(self, plan, name, x: Act, y: Act, pname: str, relu_in: bool):
+        self.plan, self.name, self.x, self.y, self.pname, self.relu_in = plan, name, x, y, pname, relu_in
+        self.F = plan.cfg["num_box_per_channels"]
+        assert y.C == x.C * self.F and x.C == x.Cs
+        self.slot = x.register() if x.needs_grad else None
+        self.bwd_add: Optional[Act] = None           # d(x) += g(block output): the block's residual add (first box op only)
+        self.stage = plan._cur_stage
+        plan.ops.append(self)
+        plan.box_ops.append(self)
+
+    def reads(self):
+        return [self.x]
+
+    def writes(self):
+        return [self.y]
+
+    def finalize(self):
+        P, x = self.plan, self.x
+        n = P.B * x.C * (x.H + 1) * (x.W + 1)
+        self.ii = torch.zeros((n,), dtype=torch.float32, device=P.device) if P.training else None
+        P.box_scratch = max(P.box_scratch, n * (self.F if P.training else 1))
+        self.params = torch.zeros((2, 4, x.C * self.F), dtype=torch.float32, device=P.device)       # [fwd | reflected]
+        self.ws = None
+        if P.training and self.y.grad is not None:
+            self.ws = torch.zeros((int(L.load().msau_box_pgrad_ws_floats(P.B, x.H, x.W, x.C, self.F)),), dtype=torch.float32, device=P.device)
+
+    def note(self):
+        P, x, y = self.plan, self.x, self.y
+        esz = 4 if P.dtype == L.F32 else 2
+        T = "f32" if P.dtype == L.F32 else "bf16"
+        nii = P.B * x.C * (x.H + 1) * (x.W + 1) * 4
+        self.fkey, self.bkey = f"box_fwd<{T},C{x.C}>", f"box_bwd<{T},C{x.C}>"
+        # forward: x read, II written + scanned in place (3 passes) + gathered once, y written
+        self.fbytes = x.npix * x.Cs * esz + 4 * nii + y.npix * y.Cs * esz
+        P.note_launch(self.fkey, self.fbytes, 0.0)
+        self.bbytes = 0
+        if self.ws is not None:
+            # backward: g(y) read twice (parameter gradient, integral), II read, II of g(y) (F x larger) written / scanned / gathered, g(x) written
+            self.bbytes = 2 * y.npix * y.Cs * esz + nii + 4 * self.F * nii + x.npix * x.Cs * esz
+            P.note_launch(self.bkey, self.bbytes, 0.0)
+
+    def _args(self):
+        P, x, y = self.plan, self.x, self.y
+        a = L.BoxArgs()
+        a.in_, a.ii = _ptr(x.data), _ptr(self.ii) if self.ii is not None else _ptr(P.box_ii_g)
+        a.params_fwd, a.params_refl = self.params[0].data_ptr(), self.params[1].data_ptr()
+        a.out = _ptr(y.data)
+        a.B, a.H, a.W, a.C, a.F, a.Cs_in, a.Cs_out = P.B, x.H, x.W, x.C, self.F, x.Cs, y.Cs
+        a.relu_in = int(self.relu_in)
+        mb = float(P.cfg["max_box_sizes"])
+        a.max_h = a.max_w = mb
+        offs = [P.poff[f"{self.pname}.{nm}"] for nm in ("x_min", "x_max", "y_min", "y_max")]
+        a.off_hmin, a.off_hmax, a.off_wmin, a.off_wmax = offs
+        return a
+
+    def fwd_recs(self):
+        self._fa = self._args()
+        self.plan.rec_meta[C.addressof(self._fa)] = (self.fkey, self.fbytes)
+        return [(L.OP_BOX_FWD, self._fa)]
+
+    def bwd_recs(self):
+        P, x, y = self.plan, self.x, self.y
+        if self.ws is None:
+            return []
+        a = self._args()
+        a.gout, a.ii_g, a.ws = _ptr(y.grad), _ptr(P.box_ii_g), _ptr(self.ws)
+        a.gin = None
+        if x.grad is not None and self.slot is not None:
+            accum, maskb = x.slot_flags(self.slot)
+            a.gin, a.accumulate = _ptr(x.grad), int(accum)
+            a.mask_a = _ptr(x.data) if self.relu_in else None
+            a.add = _ptr(self.bwd_add.grad) if self.bwd_add is not None else None
+            a.mask_b = _ptr(x.data) if maskb else None
+        self._ba = a
+        P._box_bwd_args.append(a)
+        P.rec_meta[C.addressof(a)] = (self.bkey, self.bbytes)
+        return [(L.OP_BOX_BWD, a)]
+
+    def fwd(self, s):
+        L.call("msau_box_fwd", s, self.plan.dtype, C.byref(self._fa), key=self.fkey)
+
+    def bwd(self, s):
+        if self.ws is not None:
+            L.call("msau_box_bwd", s, self.plan.dtype, C.byref(self._ba), key=self.bkey)
+
+    def load_params(self, s, flat_params: torch.Tensor):
+        a = self._fa
+        L.call("msau_box_params", s, flat_params.data_ptr(), a.off_hmin, a.off_hmax, a.off_wmin, a.off_wmax, a.C, a.F, a.max_h, a.max_w,
+               self.params[0].data_ptr(), self.params[1].data_ptr())
+
+
 class LrnOp(Op):
     """LocalResponseNorm(size=C) after the dilated conv: layers.py:145,161-162."""
 
@@ -728,6 +825,10 @@ class Plan:
         self.acts: List[Act] = []
         self.ops: List[Op] = []
         self.pairs: List[PairOp] = []
+        self.box_ops: List["BoxOp"] = []
+        self.box_scratch = 0
+        self.box_ii_g = None
+        self._box_bwd_args: list = []
         self._pack_bytes = 0
         self._slab_elems = 0
         self._pack_entries: List[L.PackEntry] = []
@@ -811,8 +912,26 @@ class Plan:
             PairOp(self, first, op)             # one launch per sweep when an instance takes the shape (bind() decides)
         return r_in
 
+    def _box_block(self, x0: Act, prefix: str, tag: str) -> Act:
+        """MultiBoxConvBlock: model/model_box.py:51-59 -- ReLU, then num_box_convs x [BoxConv2d(c -> F*c) -> conv1x1(F*c -> c)]
+        (ReLU after every 1x1 but the last), residual add, ReLU."""
+        n, Fn = self.cfg["num_box_convs"], self.cfg["num_box_per_channels"]
+        r_in, first = x0, None
+        for i in range(n):
+            bx = Act(self, f"{tag}.box{i}", x0.H, x0.W, x0.C * Fn)
+            bop = BoxOp(self, f"{tag}.box{i}", r_in, bx, f"{prefix}.conv_list.{2 * i}", relu_in=(i == 0))
+            first = first or bop
+            o = Act(self, f"{tag}.bres{i}", x0.H, x0.W, x0.C, relu_out=True)
+            ConvOp(self, f"{tag}.bres{i}", bx, None, f"{prefix}.conv_list.{2 * i + 1}.custom_conv.weight",
+                   f"{prefix}.conv_list.{2 * i + 1}.custom_conv.bias", o, 1, relu_out=True, fwd_add=(x0 if i == n - 1 else None))
+            r_in = o
+        first.bwd_add = r_in
+        return r_in
+
     def _build_net(self):
         cfg = self.cfg
+        box = cfg.get("variant") == "box"
+        block = (lambda x0, pre, tag: self._box_block(x0, pre.replace(".conv_res_list.", ".conv_box_list."), tag)) if box else self._res_block
         S, Fr, k, nb = cfg["scale_space_num"], cfg["featRoot"], cfg["filter_size"], cfg.get("num_blocks", 3)
         ncls = cfg["n_class"]
         assert cfg["pool_size"] == 2
@@ -835,7 +954,7 @@ class Plan:
                        dil=2 ** l)
                 x0 = Act(self, t + ".lrn", a.H, a.W, c)
                 LrnOp(self, t + ".lrn", a, x0)
-                x1 = self._res_block(x0, f"{pd}.conv_res_list.{l}", t)
+                x1 = block(x0, f"{pd}.conv_res_list.{l}", t)
                 if coupled:                                               # model.py:143-148
                     x2 = Act(self, t + ".cpl", a.H, a.W, c, relu_out=True)
                     ConvOp(self, t + ".cpl", prev_dw[l], x1, f"{pd}.conv1_1s.{l}.custom_conv.weight",
@@ -872,7 +991,7 @@ class Plan:
                 xm = Act(self, t + ".merge", skip.H, skip.W, c)
                 ConvOp(self, t + ".merge", skip, d, f"{pu}.conv1s.{l}.custom_conv.weight",
                        f"{pu}.conv1s.{l}.custom_conv.bias", xm, k)
-                x1 = self._res_block(xm, f"{pu}.conv_res_list.{l}", t)
+                x1 = block(xm, f"{pu}.conv_res_list.{l}", t)
                 if coupled:
                     x2 = Act(self, t + ".cpl", skip.H, skip.W, c, relu_out=True)
                     ConvOp(self, t + ".cpl", prev_up[l], x1, f"{pu}.conv1_1s.{l}.custom_conv.weight",
@@ -908,6 +1027,8 @@ class Plan:
             a.alloc_grad()
         for op in self.ops:
             op.finalize()
+        if self.box_ops:
+            self.box_ii_g = torch.zeros((max(self.box_scratch, 1),), dtype=torch.float32, device=self.device)
         self.pack_arena = torch.zeros(max(self._pack_bytes, 256), dtype=torch.uint8, device=self.device)
         for op in self.ops:
             if isinstance(op, ConvOp):
@@ -1110,6 +1231,8 @@ class Plan:
             return
         L.call("msau_pack_params", self._stream(), flat_params.data_ptr(), self.pack_arena.data_ptr(),
                self.pack_table.data_ptr(), len(self._pack_entries), self._pack_max)
+        for bop in self.box_ops:                     # stored box parameters -> valid boxes in pixels (+ reflected)
+            bop.load_params(self._stream(), flat_params)
 
     def load_input(self, x_nchw: torch.Tensor):
         assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and tuple(x_nchw.shape) == \
@@ -1212,6 +1335,8 @@ class Plan:
         stage's all-reduce bucket there."""
         s = self._stream()
         if L._profiler is not None:                      # per-launch timing path (bench roofline pass)
+            for ba in self._box_bwd_args:
+                ba.flat_grads = flat_grads.data_ptr()
             for op in reversed(self.ops):
                 op.bwd(s)
             if self.unpack_table is not None:
@@ -1220,6 +1345,8 @@ class Plan:
             return
         for ra in self._reduce_args:
             ra.flat_grads = flat_grads.data_ptr()
+        for ba in self._box_bwd_args:
+            ba.flat_grads = flat_grads.data_ptr()
         arr, n, _ = self._bwd_seq
         if not self.overlap_wgrad:
             L.call("msau_run_ops", s, arr, n)

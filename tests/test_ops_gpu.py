@@ -383,3 +383,22 @@ def test_masked_ce_more_than_16_classes(dtype):
     assert abs(float(loss) - float(ref)) < max(tol, 1e-5) * abs(float(ref)) + 1e-6
     assert float((d[..., :C].float() - x.grad).abs().max()) < tol * float(x.grad.abs().max()) + 1e-7
     assert float(d[..., C:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("k,cin,cout", [(1, 192, 64), (3, 192, 64), (1, 136, 8)])
+def test_data_gradient_wider_than_128_channels(dtype, k, cin, cout):
+    """a conv whose INPUT has more than 128 channels: its data gradient is a launch with > 128 output channels, cut into
+    128-channel slices by msau_conv2d (the 1x1 convs 3c -> c of the box variant at c = 64; the reference's 256-channel
+    levels); includes a remainder slice (136 = 128 + 8)"""
+    torch.manual_seed(9)
+    x = torch.randn(2, cin, 10, 19)
+    p = {"w": 0.05 * torch.randn(cout, cin, k, k), "b": 0.1 * torch.randn(cout)}
+    gy = torch.randn(2, cout, 10, 19)
+    leaves = {kk: v.clone().requires_grad_(True) for kk, v in p.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = O.conv_same(xr, leaves["w"], leaves["b"]); yr.backward(gy)
+    y, _, dx, grads = run_graph(_conv_builder(cout, k, False), p, x, gy, dtype)
+    tol, bf = TOL[dtype], dtype == L.BF16
+    assert err(y, yr.detach(), bf) < tol and err(dx, xr.grad, bf) < tol
+    assert err(grads["w"], leaves["w"].grad, bf) < tol and err(grads["b"], leaves["b"].grad, bf) < tol
