@@ -205,17 +205,22 @@ def secondary_measurements(args, L, MSAUWrapper, TrainEngine, dev, n_class):
     import torch
     out = []
 
-    def run(name, channels, stages, dtype, batch, feed="dense"):
+    def run(name, channels, stages, dtype, batch, feed="dense", box=False, hw=None):
+        H, W = hw or (args.height, args.width)
         kw = dict(scale_space_num=4, res_depth=2, featRoot=8, filter_size=3, pool_size=2, final_act="softmax",
                   num_blocks=stages, dtype=dtype, seed=0)
-        model = MSAUWrapper(channels, n_class, kw).to(dev)
+        if box:
+            from msau_amd import BMSAUWrapper
+            model = BMSAUWrapper(channels, n_class, kw).to(dev)        # reference defaults: 3 box convs, 3 boxes per channel, max 28
+        else:
+            model = MSAUWrapper(channels, n_class, kw).to(dev)
         eng = TrainEngine(model, lr=1e-4)
-        x, label = synthetic(batch, channels, args.height, args.width, n_class, 4321, dev)
+        x, label = synthetic(batch, channels, H, W, n_class, 4321, dev)
         if name.startswith("cfg4"):
             # BERT-like dense input: N(0,1) vectors at occupied pixels, zeros elsewhere
             g = torch.Generator(device="cpu").manual_seed(7)
             occ = (x.sum(1, keepdim=True) > 0).float()
-            x = (torch.randn((batch, channels, args.height, args.width), generator=g).to(dev)) * occ
+            x = (torch.randn((batch, channels, H, W), generator=g).to(dev)) * occ
         ids = None
         if feed == "ids":
             occ = x.sum(1) > 0
@@ -231,7 +236,8 @@ def secondary_measurements(args, L, MSAUWrapper, TrainEngine, dev, n_class):
         dt = time.perf_counter() - t0
         ent = {"name": name, "value": round(batch * args.secondary_steps / dt, 1), "unit": "tiles/s",
                "ms_per_step": round(1e3 * dt / args.secondary_steps, 3), "dtype": dtype, "batch": batch, "feed": feed,
-               "workload": f"{args.height}x{args.width}x{channels}, {stages}-stage", "loss": round(float(loss), 5)}
+               "workload": f"{H}x{W}x{channels}, {stages}-stage" + (", box-convolution blocks (parity unpinned)" if box else ""),
+               "loss": round(float(loss), 5)}
         if feed == "dense" and not args.no_roofline:
             plan = model._plan_for(x, training=True)
             rows = profile_pass(L, eng, plan, x, label, 3)
@@ -247,6 +253,8 @@ def secondary_measurements(args, L, MSAUWrapper, TrainEngine, dev, n_class):
 
     run("cfg4: BERT-embedding chargrid 336x256x768, 2-stage (BASELINE configs[3])", 768, 2, "bf16", args.batch)
     run("cfg2 in fp32 storage (the parity mode of the same kernels)", args.channels, args.stages, "fp32", args.batch)
+    run("cfg5: model_box variant 512x384x64, 3-stage (BASELINE configs[4]; BoxConv2d is third-party: self-consistent only)", 64, 3,
+        "bf16", args.batch, box=True, hw=(512, 384))
     if hasattr(TrainEngine, "step_ids"):
         run("cfg2 fed with character-id masks (first conv as a gather; SURVEY 8f N1) -- NOT the headline input", args.channels,
             args.stages, "bf16", args.batch, feed="ids")

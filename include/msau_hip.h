@@ -349,7 +349,8 @@ int msau_raster_dense(void* stream, int dtype, const int32_t* boxes, const int32
  *   msau_box_param_grad: d loss / d stored parameters, written (not accumulated) into the flat fp32 gradient buffer;
  *                        ws: msau_box_pgrad_ws_floats() floats of scratch (per-workgroup partials, ordered final sum)
  * ------------------------------------------------------------------------------------------ */
-int msau_box_integral(void* stream, int dtype, const void* in_nhwc, float* ii, int B, int H, int W, int C, int Cs, int relu_in);
+int64_t msau_box_integral_ws_floats(int B, int H, int W, int C);      /* scratch of msau_box_integral (row-segment column sums) */
+int msau_box_integral(void* stream, int dtype, const void* in_nhwc, float* ii, float* ws, int B, int H, int W, int C, int Cs, int relu_in);
 int msau_box_params(void* stream, const float* flat_params, int64_t off_hmin, int64_t off_hmax, int64_t off_wmin, int64_t off_wmax,
                     int C, int F, float max_h, float max_w, float* params_fwd, float* params_refl);
 /* sum_filters = 0: ii has C planes, out[c*F+f].  sum_filters = 1 (input gradient): ii has C*F planes (plane c*F+f is
@@ -367,7 +368,7 @@ int msau_box_param_grad(void* stream, int dtype, const float* ii, const float* p
  *   backward: box-parameter gradient (ii, gout) -> flat_grads; ii_g = integral(gout); gin = epilogue(box_filter(ii_g, params_refl, sum)) */
 typedef struct {
     const void* in; float* ii; const float* params_fwd; const float* params_refl; void* out;
-    const void* gout; void* gin; float* ii_g; float* ws; float* flat_grads;
+    const void* gout; void* gin; float* ii_g; float* ws; float* flat_grads; float* ws_ii;
     const void* mask_a; const void* add; const void* mask_b;
     int64_t off_hmin, off_hmax, off_wmin, off_wmax;
     int32_t B, H, W, C, F, Cs_in, Cs_out, relu_in, accumulate;

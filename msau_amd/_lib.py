@@ -34,7 +34,7 @@ PAIR_RELU_IN, PAIR_RELU_MID, PAIR_MASK_MID = 1, 2, 4
 
 
 class BoxArgs(C.Structure):
-    _fields_ = [(n, vp) for n in ("in_", "ii", "params_fwd", "params_refl", "out", "gout", "gin", "ii_g", "ws", "flat_grads",
+    _fields_ = [(n, vp) for n in ("in_", "ii", "params_fwd", "params_refl", "out", "gout", "gin", "ii_g", "ws", "flat_grads", "ws_ii",
                                   "mask_a", "add", "mask_b")] + \
                [(n, i64) for n in ("off_hmin", "off_hmax", "off_wmin", "off_wmax")] + \
                [(n, i32) for n in ("B", "H", "W", "C", "F", "Cs_in", "Cs_out", "relu_in", "accumulate")] + \
@@ -140,7 +140,8 @@ _SIGNATURES = {
     "msau_raster_onehot": (C.c_int, [vp, C.c_int, vp, vp, vp] + [C.c_int] * 5),
     "msau_raster_labels": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "msau_raster_dense": (C.c_int, [vp, C.c_int, vp, vp, vp, vp] + [C.c_int] * 5),
-    "msau_box_integral": (C.c_int, [vp, C.c_int, vp, vp] + [C.c_int] * 6),
+    "msau_box_integral_ws_floats": (i64, [C.c_int] * 4),
+    "msau_box_integral": (C.c_int, [vp, C.c_int, vp, vp, vp] + [C.c_int] * 6),
     "msau_box_params": (C.c_int, [vp, vp, i64, i64, i64, i64, C.c_int, C.c_int, f32, f32, vp, vp]),
     "msau_box_filter": (C.c_int, [vp, C.c_int, vp, vp, vp] + [C.c_int] * 8 + [vp, vp, vp]),
     "msau_box_fwd": (C.c_int, [vp, C.c_int, C.POINTER(BoxArgs)]),

@@ -23,30 +23,63 @@
 
 namespace {
 
-// ---- integral image, pass A: vertical running sums, NHWC T -> planar fp32 [B][C][H+1][W+1] (row 0 / column 0 zero)
+// ---- integral image, pass A: vertical running sums, NHWC T -> planar fp32 [B][C][H+1][W+1] (row 0 / column 0 zero).
+// A block owns 64 columns x all channels x one SEGMENT of rows (kSegRows): a single block per column strip would walk
+// all H rows serially (96 blocks for a 512 x 384 image on 256 CUs).  The segment's starting sums come from a first
+// kernel that only adds up each segment's column totals (the bf16 input is small; reading it twice is cheap).
+constexpr int kSegRows = 32;
+
 template <typename T>
-__global__ __launch_bounds__(256) void box_integral_cols_kernel(const T* __restrict__ in, float* __restrict__ ii, int H, int W, int Cs, int C, int relu_in) {
-    // block = 64 columns x all channels of image b; a row of the tile is one contiguous 64*Cs run in NHWC
-    extern __shared__ float tile[];                         // [C][65]
-    const int b = blockIdx.y, x0 = blockIdx.x * 64;
+__global__ __launch_bounds__(256) void box_segment_sums_kernel(const T* __restrict__ in, float* __restrict__ segsum, int H, int W, int Cs, int C,
+                                                               int relu_in) {
+    // segsum[b][seg][c][x] = sum over the rows of the segment; thread = (x, c) pairs of a 64-column strip
+    const int b = blockIdx.y, seg = blockIdx.z, x0 = blockIdx.x * 64;
     const int nx = min(64, W - x0);
+    const int y0 = seg * kSegRows, y1 = min(H, y0 + kSegRows);
+    const int nseg = gridDim.z;
+    for (int i = threadIdx.x; i < nx * Cs; i += 256) {
+        const int xx = i / Cs, c = i - xx * Cs;
+        if (c >= C) continue;
+        float acc = 0.f;
+        for (int y = y0; y < y1; ++y) {
+            const float v = (float)in[(((int64_t)b * H + y) * W + x0) * Cs + i];
+            acc += relu_in ? fmaxf(v, 0.f) : v;
+        }
+        segsum[(((int64_t)b * nseg + seg) * C + c) * W + x0 + xx] = acc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void box_integral_cols_kernel(const T* __restrict__ in, const float* __restrict__ segsum, float* __restrict__ ii,
+                                                                int H, int W, int Cs, int C, int relu_in) {
+    extern __shared__ float tile[];                         // [C][65] row tile, then [C][64] running sums
+    const int b = blockIdx.y, seg = blockIdx.z, x0 = blockIdx.x * 64;
+    const int nseg = gridDim.z;
+    const int nx = min(64, W - x0);
+    const int y0 = seg * kSegRows, y1 = min(H, y0 + kSegRows);
     const int64_t plane = (int64_t)(H + 1) * (W + 1);
     float* out_b = ii + (int64_t)b * C * plane;
-    // running sums live in LDS too: acc[C][64]
     float* acc = tile + C * 65;
-    for (int i = threadIdx.x; i < C * 64; i += 256) acc[i] = 0.f;
-    // row 0 of II and column 0 are zero
-    for (int i = threadIdx.x; i < C * nx; i += 256) {
-        const int c = i / nx, xx = i - c * nx;
-        out_b[(int64_t)c * plane + x0 + xx + 1] = 0.f;
+    for (int i = threadIdx.x; i < C * 64; i += 256) {
+        const int c = i >> 6, xx = i & 63;
+        float a = 0.f;
+        if (xx < nx)
+            for (int s2 = 0; s2 < seg; ++s2) a += segsum[(((int64_t)b * nseg + s2) * C + c) * W + x0 + xx];      // fixed order
+        acc[i] = a;
     }
-    if (x0 == 0)
-        for (int i = threadIdx.x; i < C * (H + 1); i += 256) {
-            const int c = i / (H + 1), y = i - c * (H + 1);
-            out_b[(int64_t)c * plane + (int64_t)y * (W + 1)] = 0.f;
+    if (seg == 0) {                                          // row 0 and column 0 of II are zero
+        for (int i = threadIdx.x; i < C * nx; i += 256) {
+            const int c = i / nx, xx = i - c * nx;
+            out_b[(int64_t)c * plane + x0 + xx + 1] = 0.f;
         }
+        if (x0 == 0)
+            for (int i = threadIdx.x; i < C * (H + 1); i += 256) {
+                const int c = i / (H + 1), y = i - c * (H + 1);
+                out_b[(int64_t)c * plane + (int64_t)y * (W + 1)] = 0.f;
+            }
+    }
     __syncthreads();
-    for (int y = 0; y < H; ++y) {
+    for (int y = y0; y < y1; ++y) {
         const T* row = in + (((int64_t)b * H + y) * W + x0) * Cs;
         for (int i = threadIdx.x; i < nx * Cs; i += 256) {
             const int xx = i / Cs, c = i - xx * Cs;
@@ -197,29 +230,33 @@ __global__ __launch_bounds__(256) void box_pgrad_kernel(const float* __restrict_
             split(r2, (float)H, i2, fi2);
             split(c1, (float)W, j1, fj1);
             split(c2, (float)W, j2, fj2);
-            const float F22 = lerp_ii(pl, W1, i2, fi2, j2, fj2, H, W), F12 = lerp_ii(pl, W1, i1, fi1, j2, fj2, H, W);
-            const float F21 = lerp_ii(pl, W1, i2, fi2, j1, fj1, H, W), F11 = lerp_ii(pl, W1, i1, fi1, j1, fj1, H, W);
+            // the 4 x 4 integral-image values around the four corners, loaded once: the box integral AND the four edge
+            // (line) integrals are combinations of them
+            const int rr[4] = {i1, min(i1 + 1, H), i2, min(i2 + 1, H)};
+            const int cc[4] = {j1, min(j1 + 1, W), j2, min(j2 + 1, W)};
+            float v[4][4];
+#pragma unroll
+            for (int a2 = 0; a2 < 4; ++a2)
+#pragma unroll
+                for (int b2 = 0; b2 < 4; ++b2) v[a2][b2] = pl[(int64_t)rr[a2] * W1 + cc[b2]];
+            float A[4], Bc[4], dA[4], dB[4];                    // per row: value at column c1 / c2, column derivative there
+#pragma unroll
+            for (int a2 = 0; a2 < 4; ++a2) {
+                dA[a2] = v[a2][1] - v[a2][0];
+                dB[a2] = v[a2][3] - v[a2][2];
+                A[a2] = v[a2][0] + fj1 * dA[a2];
+                Bc[a2] = v[a2][2] + fj2 * dB[a2];
+            }
+            const float F11 = A[0] + fi1 * (A[1] - A[0]), F21 = A[2] + fi2 * (A[3] - A[2]);
+            const float F12 = Bc[0] + fi1 * (Bc[1] - Bc[0]), F22 = Bc[2] + fi2 * (Bc[3] - Bc[2]);
             const float O = (F22 - F12 - F21 + F11) * inv_area;
-            // line integrals: the image row an edge sits in is floor(edge) when that lies inside [0, H) -- i.e. the
-            // derivative of the clamped, piecewise-bilinear II: d/dr lerp = (row i+1) - (row i) at column position
-            auto drow = [&](float r, int i, int j, float fj) -> float {        // d F(r, col) / d r
-                if (!(r > 0.f && r < (float)H)) return 0.f;
-                const int jj1 = min(j + 1, W);
-                const float a = pl[(int64_t)i * W1 + j], bq = pl[(int64_t)i * W1 + jj1];
-                const float cq = pl[(int64_t)(i + 1) * W1 + j], d = pl[(int64_t)(i + 1) * W1 + jj1];
-                return (cq + fj * (d - cq)) - (a + fj * (bq - a));
-            };
-            auto dcol = [&](float cc, int j, int i, float fi) -> float {       // d F(row, cc) / d cc
-                if (!(cc > 0.f && cc < (float)W)) return 0.f;
-                const int ii1 = min(i + 1, H);
-                const float a = pl[(int64_t)i * W1 + j], bq = pl[(int64_t)i * W1 + j + 1];
-                const float cq = pl[(int64_t)ii1 * W1 + j], d = pl[(int64_t)ii1 * W1 + j + 1];
-                return (bq + fi * (d - bq)) - (a + fi * (cq - a));
-            };
-            const float dS_hmax = drow(r2, i2, j2, fj2) - drow(r2, i2, j1, fj1);
-            const float dS_hmin = -(drow(r1, i1, j2, fj2) - drow(r1, i1, j1, fj1));
-            const float dS_wmax = dcol(c2, j2, i2, fi2) - dcol(c2, j2, i1, fi1);
-            const float dS_wmin = -(dcol(c1, j1, i2, fi2) - dcol(c1, j1, i1, fi1));
+            // an edge that is clamped to the image border does not move the integral
+            const bool r1in = r1 > 0.f && r1 < (float)H, r2in = r2 > 0.f && r2 < (float)H;
+            const bool c1in = c1 > 0.f && c1 < (float)W, c2in = c2 > 0.f && c2 < (float)W;
+            const float dS_hmax = r2in ? (Bc[3] - Bc[2]) - (A[3] - A[2]) : 0.f;              // row integral along the bottom edge
+            const float dS_hmin = r1in ? -((Bc[1] - Bc[0]) - (A[1] - A[0])) : 0.f;
+            const float dS_wmax = c2in ? (dB[2] + fi2 * (dB[3] - dB[2])) - (dB[0] + fi1 * (dB[1] - dB[0])) : 0.f;   // column integral, right edge
+            const float dS_wmin = c1in ? -((dA[2] + fi2 * (dA[3] - dA[2])) - (dA[0] + fi1 * (dA[1] - dA[0]))) : 0.f;
             float d4[4];
             d4[0] = g * (dS_hmin + O * ww) * inv_area;          // dA/dhmin = -ww
             d4[1] = g * (dS_hmax - O * ww) * inv_area;
@@ -272,18 +309,24 @@ __global__ void box_params_kernel(const float* __restrict__ flat, int64_t off0, 
 
 }  // namespace
 
-extern "C" int msau_box_integral(void* stream, int dtype, const void* in, float* ii, int B, int H, int W, int C, int Cs, int relu_in) {
-    MSAU_CHECK_ARG(in && ii && B > 0 && H > 0 && W > 0 && C > 0 && C <= Cs && Cs % 8 == 0 && C <= 512, "box_integral: bad args");
+extern "C" int64_t msau_box_integral_ws_floats(int B, int H, int W, int C) { return (int64_t)B * cdiv(H, kSegRows) * C * W; }
+
+extern "C" int msau_box_integral(void* stream, int dtype, const void* in, float* ii, float* ws, int B, int H, int W, int C, int Cs, int relu_in) {
+    MSAU_CHECK_ARG(in && ii && ws && B > 0 && H > 0 && W > 0 && C > 0 && C <= Cs && Cs % 8 == 0 && C <= 512, "box_integral: bad args");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t lds = (size_t)C * (65 + 64) * sizeof(float);
     MSAU_CHECK_ARG(lds <= 150 * 1024, "box_integral: %d channels exceed the LDS tile", C);
-    dim3 grid(cdiv(W, 64), B);
+    const int nseg = cdiv(H, kSegRows);
+    MSAU_CHECK_ARG(nseg <= 65535 && B <= 65535, "box_integral: image too tall / batch too large");
+    dim3 grid(cdiv(W, 64), B, nseg);
     if (dtype == MSAU_F32) {
+        hipLaunchKernelGGL(box_segment_sums_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(in), ws, H, W, Cs, C, relu_in);
         if (lds > 60 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&box_integral_cols_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
-        hipLaunchKernelGGL(box_integral_cols_kernel<float>, grid, dim3(256), lds, s, static_cast<const float*>(in), ii, H, W, Cs, C, relu_in);
+        hipLaunchKernelGGL(box_integral_cols_kernel<float>, grid, dim3(256), lds, s, static_cast<const float*>(in), ws, ii, H, W, Cs, C, relu_in);
     } else if (dtype == MSAU_BF16) {
+        hipLaunchKernelGGL(box_segment_sums_kernel<bf16_t>, grid, dim3(256), 0, s, static_cast<const bf16_t*>(in), ws, H, W, Cs, C, relu_in);
         if (lds > 60 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&box_integral_cols_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
-        hipLaunchKernelGGL(box_integral_cols_kernel<bf16_t>, grid, dim3(256), lds, s, static_cast<const bf16_t*>(in), ii, H, W, Cs, C, relu_in);
+        hipLaunchKernelGGL(box_integral_cols_kernel<bf16_t>, grid, dim3(256), lds, s, static_cast<const bf16_t*>(in), ws, ii, H, W, Cs, C, relu_in);
     } else return msau_set_error(MSAU_ERR_ARG, "box_integral: bad dtype");
     MSAU_CHECK_LAUNCH("box_integral_cols");
     const int64_t nrows = (int64_t)B * C * (H + 1);
@@ -348,8 +391,8 @@ extern "C" int msau_box_param_grad(void* stream, int dtype, const float* ii, con
 
 // ---- launch-sequence records (msau_run_ops): one box conv forward / backward sweep step
 extern "C" int msau_box_fwd(void* stream, int dtype, const msau_box_args* a) {
-    MSAU_CHECK_ARG(a && a->in && a->ii && a->params_fwd && a->out, "box_fwd: null pointer");
-    int rc = msau_box_integral(stream, dtype, a->in, a->ii, a->B, a->H, a->W, a->C, a->Cs_in, a->relu_in);
+    MSAU_CHECK_ARG(a && a->in && a->ii && a->ws_ii && a->params_fwd && a->out, "box_fwd: null pointer");
+    int rc = msau_box_integral(stream, dtype, a->in, a->ii, a->ws_ii, a->B, a->H, a->W, a->C, a->Cs_in, a->relu_in);
     if (rc) return rc;
     return msau_box_filter(stream, dtype, a->ii, a->params_fwd, a->out, a->B, a->H, a->W, a->C, a->F, a->Cs_out, 0, 0, nullptr, nullptr, nullptr);
 }
@@ -361,7 +404,7 @@ extern "C" int msau_box_bwd(void* stream, int dtype, const msau_box_args* a) {
                                  a->off_wmax, a->B, a->H, a->W, a->C, a->F, a->Cs_out, a->max_h, a->max_w);
     if (rc || !a->gin) return rc;
     // (2) input: the reflected boxes over the integral image of the output gradient, summed over the filters
-    rc = msau_box_integral(stream, dtype, a->gout, a->ii_g, a->B, a->H, a->W, a->C * a->F, a->Cs_out, 0);
+    rc = msau_box_integral(stream, dtype, a->gout, a->ii_g, a->ws_ii, a->B, a->H, a->W, a->C * a->F, a->Cs_out, 0);
     if (rc) return rc;
     return msau_box_filter(stream, dtype, a->ii_g, a->params_refl, a->gin, a->B, a->H, a->W, a->C, a->F, a->Cs_in, 1, a->accumulate,
                            a->mask_a, a->add, a->mask_b);

@@ -559,6 +559,7 @@ class BoxOp(Op):
         n = P.B * x.C * (x.H + 1) * (x.W + 1)
         self.ii = torch.zeros((n,), dtype=torch.float32, device=P.device) if P.training else None
         P.box_scratch = max(P.box_scratch, n * (self.F if P.training else 1))
+        P.box_ws_ii = max(P.box_ws_ii, int(L.load().msau_box_integral_ws_floats(P.B, x.H, x.W, x.C * (self.F if P.training else 1))))
         self.params = torch.zeros((2, 4, x.C * self.F), dtype=torch.float32, device=P.device)       # [fwd | reflected]
         self.ws = None
         if P.training and self.y.grad is not None:
@@ -584,7 +585,7 @@ class BoxOp(Op):
         a = L.BoxArgs()
         a.in_, a.ii = _ptr(x.data), _ptr(self.ii) if self.ii is not None else _ptr(P.box_ii_g)
         a.params_fwd, a.params_refl = self.params[0].data_ptr(), self.params[1].data_ptr()
-        a.out = _ptr(y.data)
+        a.out, a.ws_ii = _ptr(y.data), _ptr(P.box_ws)
         a.B, a.H, a.W, a.C, a.F, a.Cs_in, a.Cs_out = P.B, x.H, x.W, x.C, self.F, x.Cs, y.Cs
         a.relu_in = int(self.relu_in)
         mb = float(P.cfg["max_box_sizes"])
@@ -827,6 +828,8 @@ class Plan:
         self.pairs: List[PairOp] = []
         self.box_ops: List["BoxOp"] = []
         self.box_scratch = 0
+        self.box_ws_ii = 0
+        self.box_ws = None
         self.box_ii_g = None
         self._box_bwd_args: list = []
         self._pack_bytes = 0
@@ -1029,6 +1032,7 @@ class Plan:
             op.finalize()
         if self.box_ops:
             self.box_ii_g = torch.zeros((max(self.box_scratch, 1),), dtype=torch.float32, device=self.device)
+            self.box_ws = torch.zeros((max(self.box_ws_ii, 1),), dtype=torch.float32, device=self.device)
         self.pack_arena = torch.zeros(max(self._pack_bytes, 256), dtype=torch.uint8, device=self.device)
         for op in self.ops:
             if isinstance(op, ConvOp):

@@ -55,7 +55,8 @@ def test_box_filter_and_gradients_match_the_restatement(B, C, F, H, W, maxb):
     ii = torch.zeros(B * C * (H + 1) * (W + 1), device="cuda")
     Cs_out = -(-CF // 8) * 8
     out = torch.zeros(B, H, W, Cs_out, device="cuda")
-    L.call("msau_box_integral", s, L.F32, xd.data_ptr(), ii.data_ptr(), B, H, W, C, xd.shape[3], 1)
+    wsi = torch.zeros(int(L.load().msau_box_integral_ws_floats(B, H, W, CF)), device="cuda")
+    L.call("msau_box_integral", s, L.F32, xd.data_ptr(), ii.data_ptr(), wsi.data_ptr(), B, H, W, C, xd.shape[3], 1)
     # the integral image itself: II[i][j] = sum relu(x)[0..i) x [0..j)
     ref_ii = torch.zeros(B, C, H + 1, W + 1, dtype=torch.float64)
     ref_ii[:, :, 1:, 1:] = torch.relu(x).double().cumsum(2).cumsum(3)
@@ -67,7 +68,7 @@ def test_box_filter_and_gradients_match_the_restatement(B, C, F, H, W, maxb):
     gyd = _nhwc(gy, Cs_out)
     iig = torch.zeros(B * CF * (H + 1) * (W + 1), device="cuda")
     gx = torch.zeros_like(xd)
-    L.call("msau_box_integral", s, L.F32, gyd.data_ptr(), iig.data_ptr(), B, H, W, CF, Cs_out, 0)
+    L.call("msau_box_integral", s, L.F32, gyd.data_ptr(), iig.data_ptr(), wsi.data_ptr(), B, H, W, CF, Cs_out, 0)
     L.call("msau_box_filter", s, L.F32, iig.data_ptr(), params[1].data_ptr(), gx.data_ptr(), B, H, W, C, F, xd.shape[3], 1, 0,
            xd.data_ptr(), None, None)
     assert rel_err(gx[..., :C].permute(0, 3, 1, 2).cpu(), xr.grad) < 2e-4
