@@ -8,8 +8,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmsau_hip.so")
 SOURCES = ["pack.hip", "conv.hip", "conv_lean.hip", "conv_pair.hip", "conv_wgrad.hip", "wgrad_lean.hip", "elementwise.hip", "attention.hip", "attention_mfma.hip", "raster.hip", "boxconv.hip", "sequence.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"] + os.environ.get("MSAU_EXTRA_HIPCC_FLAGS", "").split() + [
          "-ffp-contract=fast"]
+
+
+# Per-source device flags.  elementwise.hip is compiled WITHOUT packed-fp32 instructions (v_pk_add_f32 / v_pk_mul_f32 /
+# v_pk_fma_f32): with them, the level-0 LRN backward (lrn_fast_kernel<bf16,1,BWD>: chains of v_pk_add_f32 with op_sel, i.e.
+# operands taken from the other half of a register pair) occasionally returned a wrong adjoint window sum for a 16-lane
+# group when a weight-gradient kernel of the side stream shared the device -- same inputs, different bits, in 25-40 % of
+# fresh processes.  Found 2026-10-04 with tools/det_check.py (interleaved A/B on one box: 9 of 24 processes deviated with
+# packed ops, 0 of 24 without); neither the IEEE division, nor the library sqrt sequences, nor the transcendental unit
+# (a VALU-only Newton variant deviated just the same) were the cause.  DESIGN.md section 2.  The host pass of hipcc prints
+# "'-packed-fp32-ops' is not a recognized feature" for it: harmless, the flag is for the gfx950 pass.
+EXTRA_FLAGS = {"elementwise.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
 
 
 def _stale(target, deps):
@@ -21,19 +32,25 @@ def _stale(target, deps):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, "msau_common.h"), os.path.join(HERE, "..", "include", "msau_hip.h")]
+    # this file is a dependency too: it holds the compile flags
+    headers = [os.path.join(CSRC, "msau_common.h"), os.path.join(HERE, "..", "include", "msau_hip.h"), os.path.abspath(__file__)]
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        err = "\n".join(ln for ln in r.stderr.splitlines() if "is not a recognized feature for this target" not in ln)
+        if err.strip():
+            print(err, file=sys.stderr, flush=True)
+        if r.returncode:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:

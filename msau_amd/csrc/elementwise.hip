@@ -2,6 +2,7 @@
 // 2x2 max pool, masked cross entropy, clip+Adam.  All vectorised 16 B per lane along the
 // channel (NHWC) dimension; accumulation in fp32.
 #include "msau_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -114,9 +115,20 @@ __device__ __forceinline__ float pow_neg_beta(float d, float beta, bool beta075)
     return __expf(-beta * __logf(d));
 }
 
+// d^-1/2 without the transcendental unit: bit-trick seed + three Newton steps (relative error < 1e-7 for d in [1e-3, 1e6]).
+// Used by the LRN kernels when MSAU_LRN_VALU=1: the experiment that tells whether the run-to-run differences of the
+// level-0 LRN backward come from v_rsq_f32 / v_sqrt_f32 or from somewhere else.
+__device__ __forceinline__ float rsqrt_valu(float d) {
+    float y = __builtin_bit_cast(float, 0x5f3759dfu - (__builtin_bit_cast(unsigned, d) >> 1));
+    const float h = 0.5f * d;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) y = y * (1.5f - h * y * y);
+    return y;
+}
+
 template <typename T, int G, bool BWD>
 __global__ void lrn_fast_kernel(const T* __restrict__ a, const T* __restrict__ dy, T* __restrict__ out,
-                                int64_t npix, float alpha_over_n, float beta, float k, bool beta075) {
+                                int64_t npix, float alpha_over_n, float beta, float k, int powmode) {
     const int64_t total = npix * G;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     // all lanes of a G-group run the same number of iterations (total % G == 0, stride % G == 0)
@@ -162,7 +174,8 @@ __global__ void lrn_fast_kernel(const T* __restrict__ a, const T* __restrict__ d
             const float d = k + alpha_over_n * win[j];
             // raw v_rsq_f32 / v_sqrt_f32 (1 ulp each, d >= k > 0: no denormal or range fix-ups needed) instead of the
             // library forms, whose correction sequences are a dozen VCC-dependent instructions per call
-            if (beta075) { const float r = __builtin_amdgcn_rsqf(d); dnb[j] = r * __builtin_amdgcn_sqrtf(r); invd[j] = r * r; }
+            if (powmode == 1) { const float r = __builtin_amdgcn_rsqf(d); dnb[j] = r * __builtin_amdgcn_sqrtf(r); invd[j] = r * r; }
+            else if (powmode == 2) { const float r = rsqrt_valu(d); dnb[j] = r * (r * rsqrt_valu(r)); invd[j] = r * r; }   // sqrt(r) = r * r^-1/2
             else { dnb[j] = __expf(-beta * __logf(d)); invd[j] = __builtin_amdgcn_rcpf(d); }
         }
         typename Vec8<T>::type ov;
@@ -256,6 +269,8 @@ int lrn_dispatch(hipStream_t s, const void* a, const void* dy, void* out, int64_
     MSAU_CHECK_ARG(npix > 0 && C > 0 && C <= Cs && Cs % 8 == 0 && Cs <= 128 && n >= 1, "lrn: bad dims C=%d Cs=%d n=%d", C, Cs, n);
     const float aon = alpha / (float)n;
     const bool b075 = beta == 0.75f;
+    static const bool valu_only = std::getenv("MSAU_LRN_VALU") && std::getenv("MSAU_LRN_VALU")[0] == '1';
+    const int powmode = b075 ? (valu_only ? 2 : 1) : 0;
     const T* ap = static_cast<const T*>(a);
     const T* gp = static_cast<const T*>(dy);
     T* op = static_cast<T*>(out);
@@ -264,11 +279,11 @@ int lrn_dispatch(hipStream_t s, const void* a, const void* dy, void* out, int64_
     if (fast) {
         int grid = grid_for(npix * G);
         switch (G) {
-            case 1: hipLaunchKernelGGL((lrn_fast_kernel<T, 1, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, b075); break;
-            case 2: hipLaunchKernelGGL((lrn_fast_kernel<T, 2, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, b075); break;
-            case 4: hipLaunchKernelGGL((lrn_fast_kernel<T, 4, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, b075); break;
-            case 8: hipLaunchKernelGGL((lrn_fast_kernel<T, 8, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, b075); break;
-            default: hipLaunchKernelGGL((lrn_fast_kernel<T, 16, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, b075); break;
+            case 1: hipLaunchKernelGGL((lrn_fast_kernel<T, 1, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
+            case 2: hipLaunchKernelGGL((lrn_fast_kernel<T, 2, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
+            case 4: hipLaunchKernelGGL((lrn_fast_kernel<T, 4, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
+            case 8: hipLaunchKernelGGL((lrn_fast_kernel<T, 8, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
+            default: hipLaunchKernelGGL((lrn_fast_kernel<T, 16, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
         }
     } else {
         hipLaunchKernelGGL((lrn_generic_kernel<T, BWD>), dim3(grid_for(npix)), dim3(kThreads), 0, s, ap, gp, op, npix, C, Cs, n, aon, beta, k, b075);

@@ -669,8 +669,11 @@ class LrnOp(Op):
             return []
         self._ba = L.LrnArgs(_ptr(a.data), _ptr(y.grad), _ptr(a.grad), a.npix, a.C, a.Cs, a.C, 1e-4, 0.75, 1.0)
         self.plan.rec_meta[C.addressof(self._ba)] = (self.bkey, self.bbytes)
-        # deterministic mode: never beside a side-stream kernel ("one-ulp finding")
-        return [(L.OP_LRN_BWD | (L.OP_JOIN if self.plan.deterministic and self.plan.overlap_wgrad else 0), self._ba)]
+        # (round 1 tagged this launch MSAU_OP_JOIN in deterministic mode: its results varied from run to run beside a
+        # side-stream kernel.  Root cause found in round 2 -- packed-fp32 instructions, msau_amd/build.py -- so the join,
+        # and its 4 % cost, are gone; MSAU_LRN_JOIN=1 brings it back for experiments.)
+        join = L.OP_JOIN if (os.environ.get("MSAU_LRN_JOIN") == "1" and self.plan.overlap_wgrad) else 0
+        return [(L.OP_LRN_BWD | join, self._ba)]
 
     def fwd(self, s):
         a, y = self.a, self.y
