@@ -230,6 +230,148 @@ int attn_bwd_t(hipStream_t s, const void* f, const void* g, const void* h, const
     return launch_pass<T, DS, CS, MODE_BWD_DF>(s, fp, gp, hp, dyp, stats, ws, static_cast<T*>(df), B, N);
 }
 
+// ---- any (Ds, Cs): one workgroup per score row / column, run-time channel counts.  O(N^2 (Ds + Cs)) like the tiled
+// kernels but without their register / LDS tiling -- the path for widths that have no instance (the 256-channel bottleneck
+// of the reference's constructor defaults, where N is a handful of positions).  Same two-pass softmax arithmetic.
+constexpr int kAnyChunk = 2048;            // score-vector chunk held in LDS
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_any_stats_kernel(const T* __restrict__ f, const T* __restrict__ g, float* __restrict__ stats, int N, int Ds) {
+    __shared__ float red[256];
+    const int b = blockIdx.y, i = blockIdx.x;
+    const T* gi = g + ((size_t)b * N + i) * Ds;
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        const T* fj = f + ((size_t)b * N + j) * Ds;
+        float sc = 0.f;
+        for (int d = 0; d < Ds; ++d) sc += (float)gi[d] * (float)fj[d];
+        m = fmaxf(m, sc);
+    }
+    red[threadIdx.x] = m; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    m = red[0]; __syncthreads();
+    float Z = 0.f;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        const T* fj = f + ((size_t)b * N + j) * Ds;
+        float sc = 0.f;
+        for (int d = 0; d < Ds; ++d) sc += (float)gi[d] * (float)fj[d];
+        Z += __expf(sc - m);
+    }
+    red[threadIdx.x] = Z; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) { stats[((size_t)b * N + i) * 2] = m; stats[((size_t)b * N + i) * 2 + 1] = red[0]; }
+}
+
+// MODE 0: y[j] = x[j] + sum_i beta[i,j] h[i]      (block = column j)
+// MODE 1: dh[i] = sum_j beta[i,j] dy[j], delta[i] = h[i] . dh[i]   (block = row i)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void attn_any_mix_kernel(const T* __restrict__ f, const T* __restrict__ g, const T* __restrict__ h,
+                                                           const T* __restrict__ xdy, const float* __restrict__ stats, float* __restrict__ delta,
+                                                           T* __restrict__ out, int N, int Ds, int Cs) {
+    __shared__ float beta[kAnyChunk];
+    __shared__ float red[256];
+    const int b = blockIdx.y, me = blockIdx.x;
+    const size_t base = (size_t)b * N;
+    const T* mine = (MODE == 0 ? f : g) + (base + me) * Ds;          // f_j (column) or g_i (row)
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};                             // channels tid, tid + 256, ... (Cs <= 1024)
+    for (int o0 = 0; o0 < N; o0 += kAnyChunk) {
+        const int no = min(kAnyChunk, N - o0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < no; t += 256) {
+            const int o = o0 + t;
+            const int row = MODE == 0 ? o : me;                       // softmax row of this score
+            const T* other = (MODE == 0 ? g : f) + (base + o) * Ds;
+            float sc = 0.f;
+            for (int d = 0; d < Ds; ++d) sc += (float)mine[d] * (float)other[d];
+            beta[t] = __expf(sc - stats[(base + row) * 2]) / stats[(base + row) * 2 + 1];
+        }
+        __syncthreads();
+        const T* src = MODE == 0 ? h : xdy;                            // h[i] or dy[j]
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = threadIdx.x + 256 * k;
+            if (c < Cs) {
+                float a = acc[k];
+                for (int t = 0; t < no; ++t) a += beta[t] * (float)src[(base + o0 + t) * Cs + c];
+                acc[k] = a;
+            }
+        }
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        if (c < Cs) {
+            if (MODE == 0) out[(base + me) * Cs + c] = (T)((float)xdy[(base + me) * Cs + c] + acc[k]);
+            else { out[(base + me) * Cs + c] = (T)acc[k]; dot += (float)h[(base + me) * Cs + c] * acc[k]; }
+        }
+    }
+    if (MODE == 1) {
+        red[threadIdx.x] = dot; __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) delta[base + me] = red[0];
+    }
+}
+
+// MODE 2: dg[i] = sum_j dS[i,j] f[j]   (block = row i)      MODE 3: df[j] = sum_i dS[i,j] g[i]   (block = column j)
+//   dS[i,j] = beta[i,j] (h[i] . dy[j] - delta[i])
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void attn_any_dscore_kernel(const T* __restrict__ f, const T* __restrict__ g, const T* __restrict__ h,
+                                                              const T* __restrict__ dy, const float* __restrict__ stats, const float* __restrict__ delta,
+                                                              T* __restrict__ out, int N, int Ds, int Cs) {
+    __shared__ float ds[kAnyChunk];
+    const int b = blockIdx.y, me = blockIdx.x;
+    const size_t base = (size_t)b * N;
+    const T* mine = (MODE == 2 ? g : f) + (base + me) * Ds;
+    const T* hv = (MODE == 2 ? h : dy) + (base + me) * Cs;            // h[i] (row) or dy[j] (column)
+    float acc = 0.f;                                                  // output channel tid (Ds <= 256)
+    for (int o0 = 0; o0 < N; o0 += kAnyChunk) {
+        const int no = min(kAnyChunk, N - o0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < no; t += 256) {
+            const int o = o0 + t;
+            const int row = MODE == 2 ? me : o;
+            const T* other = (MODE == 2 ? f : g) + (base + o) * Ds;
+            const T* ov = (MODE == 2 ? dy : h) + (base + o) * Cs;
+            float sc = 0.f, hd = 0.f;
+            for (int d = 0; d < Ds; ++d) sc += (float)mine[d] * (float)other[d];
+            for (int c = 0; c < Cs; ++c) hd += (float)hv[c] * (float)ov[c];
+            const float bt = __expf(sc - stats[(base + row) * 2]) / stats[(base + row) * 2 + 1];
+            ds[t] = bt * (hd - delta[base + row]);
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < Ds) {
+            const T* src = (MODE == 2 ? f : g);
+            for (int t = 0; t < no; ++t) acc += ds[t] * (float)src[(base + o0 + t) * Ds + threadIdx.x];
+        }
+    }
+    if ((int)threadIdx.x < Ds) out[(base + me) * Ds + threadIdx.x] = (T)acc;
+}
+
+template <typename T>
+int attn_any_fwd(hipStream_t s, const void* f, const void* g, const void* h, const void* x, void* y, float* stats, int B, int N, int Ds, int Cs) {
+    MSAU_CHECK_ARG(Ds % 8 == 0 && Cs % 8 == 0 && Ds <= 256 && Cs <= 1024 && N <= 65535 && B <= 65535, "selfattn: unsupported (Ds,Cs,N)=(%d,%d,%d)", Ds, Cs, N);
+    const T* fp = static_cast<const T*>(f); const T* gp = static_cast<const T*>(g);
+    hipLaunchKernelGGL(attn_any_stats_kernel<T>, dim3(N, B), dim3(256), 0, s, fp, gp, stats, N, Ds);
+    hipLaunchKernelGGL((attn_any_mix_kernel<T, 0>), dim3(N, B), dim3(256), 0, s, fp, gp, static_cast<const T*>(h), static_cast<const T*>(x), stats,
+                       nullptr, static_cast<T*>(y), N, Ds, Cs);
+    MSAU_CHECK_LAUNCH("attn_any_fwd");
+    return 0;
+}
+
+template <typename T>
+int attn_any_bwd(hipStream_t s, const void* f, const void* g, const void* h, const void* dy, const float* stats, void* df, void* dg, void* dh,
+                 float* ws, int B, int N, int Ds, int Cs) {
+    MSAU_CHECK_ARG(Ds % 8 == 0 && Cs % 8 == 0 && Ds <= 256 && Cs <= 1024 && N <= 65535 && B <= 65535, "selfattn: unsupported (Ds,Cs,N)=(%d,%d,%d)", Ds, Cs, N);
+    const T* fp = static_cast<const T*>(f); const T* gp = static_cast<const T*>(g);
+    const T* hp = static_cast<const T*>(h); const T* dyp = static_cast<const T*>(dy);
+    hipLaunchKernelGGL((attn_any_mix_kernel<T, 1>), dim3(N, B), dim3(256), 0, s, fp, gp, hp, dyp, stats, ws, static_cast<T*>(dh), N, Ds, Cs);
+    hipLaunchKernelGGL((attn_any_dscore_kernel<T, 2>), dim3(N, B), dim3(256), 0, s, fp, gp, hp, dyp, stats, ws, static_cast<T*>(dg), N, Ds, Cs);
+    hipLaunchKernelGGL((attn_any_dscore_kernel<T, 3>), dim3(N, B), dim3(256), 0, s, fp, gp, hp, dyp, stats, ws, static_cast<T*>(df), N, Ds, Cs);
+    MSAU_CHECK_LAUNCH("attn_any_bwd");
+    return 0;
+}
+
 #define ATTN_DISPATCH(FN, ...)                                                                      \
     do {                                                                                            \
         if (Ds == 8 && Cs == 8) return FN<T, 8, 8>(__VA_ARGS__);                                    \
@@ -237,18 +379,19 @@ int attn_bwd_t(hipStream_t s, const void* f, const void* g, const void* h, const
         if (Ds == 8 && Cs == 32) return FN<T, 8, 32>(__VA_ARGS__);                                  \
         if (Ds == 8 && Cs == 64) return FN<T, 8, 64>(__VA_ARGS__);                                  \
         if (Ds == 16 && Cs == 128) return FN<T, 16, 128>(__VA_ARGS__);                              \
-        return msau_set_error(MSAU_ERR_ARG, "selfattn: unsupported (Ds,Cs)=(%d,%d)", Ds, Cs);       \
     } while (0)
 
 template <typename T>
 int attn_fwd_d(hipStream_t s, const void* f, const void* g, const void* h, const void* x, void* y, float* stats,
                int B, int N, int Ds, int Cs) {
     ATTN_DISPATCH(attn_fwd_t, s, f, g, h, x, y, stats, B, N);
+    return attn_any_fwd<T>(s, f, g, h, x, y, stats, B, N, Ds, Cs);
 }
 template <typename T>
 int attn_bwd_d(hipStream_t s, const void* f, const void* g, const void* h, const void* dy, const float* stats,
                void* df, void* dg, void* dh, float* ws, int B, int N, int Ds, int Cs) {
     ATTN_DISPATCH(attn_bwd_t, s, f, g, h, dy, stats, df, dg, dh, ws, B, N);
+    return attn_any_bwd<T>(s, f, g, h, dy, stats, df, dg, dh, ws, B, N, Ds, Cs);
 }
 
 }  // namespace

@@ -24,11 +24,14 @@ __host__ __device__ inline int pix_stride_bytes(int cch, int esz) {
 
 struct TileGeom { int TH, TIH, TIW, PS, WS, in_bytes, w_bytes, tab_bytes, total; };
 
-inline TileGeom tile_geom(const ConvGeom& g, int PT, int KH, int KW, int dil, int stride) {
+inline bool conv_compact(int KH, int KW, int dil, int stride, int ups) { return stride == 1 && ups == 1 && dil >= 16 && KH * KW > 1; }
+
+inline TileGeom tile_geom(const ConvGeom& g, int PT, int KH, int KW, int dil, int stride, int ups = 1) {
     TileGeom t;
     t.TH = 4 * PT;
     t.TIH = (t.TH - 1) * stride + (KH - 1) * dil + 1;
     t.TIW = 15 * stride + (KW - 1) * dil + 1;
+    if (conv_compact(KH, KW, dil, stride, ups)) { t.TIH = KH * KW * t.TH; t.TIW = 16; }     // one TH x 16 block per tap
     t.PS = pix_stride_bytes(g.cch, g.esz);
     t.WS = g.kchunk * g.esz + 16;
     t.in_bytes = roundup(t.TIH * t.TIW * t.PS, 16);
@@ -65,7 +68,7 @@ int conv_geom(int dtype, int C1, int C2, int Cout, int KH, int KW, int dil, int 
         g.cch = 64;
         g.kchunk = roundup(g.taps * 64, 32);
         g.ngroups = g.kchunk / 8;
-        if (tile_geom(g, 1, KH, KW, dil, stride).total <= 150 * 1024) best = 64;
+        if (tile_geom(g, 1, KH, KW, dil, stride, ups).total <= 150 * 1024) best = 64;
     }
     for (int pass = 0; pass < 2 && !best; ++pass) {
         for (int c = (Cin < 128 ? Cin : 128); c >= 8; c -= 8) {
@@ -74,7 +77,7 @@ int conv_geom(int dtype, int C1, int C2, int Cout, int KH, int KW, int dil, int 
             g.cch = c;
             g.kchunk = roundup(g.taps * c, 32);
             g.ngroups = g.kchunk / 8;
-            TileGeom t = tile_geom(g, pass == 0 ? 4 : 1, KH, KW, dil, stride);
+            TileGeom t = tile_geom(g, pass == 0 ? 4 : 1, KH, KW, dil, stride, ups);
             if (t.total <= (pass == 0 ? 72 * 1024 : 150 * 1024)) { best = c; break; }
         }
     }
@@ -90,6 +93,8 @@ int conv_geom(int dtype, int C1, int C2, int Cout, int KH, int KW, int dil, int 
 struct ConvArgs {
     msau_conv_desc d;
     int ystride;                                 // channels per pixel of the output tensor (>= d.Cout when the launch is a slice)
+    int compact;                                 // 1: large dilation -- the LDS tile holds one TH x 16 pixel block per TAP instead of
+                                                 //    the (mostly unused) halo rectangle: TIH = taps * TH, TIW = 16
     int cch, nchunks, kchunk, ngroups;
     int TIH, TIW, PS, WS;
     int in_bytes, w_bytes;
@@ -126,6 +131,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
             int tap = G / cg_per_chunk, cg = G - tap * cg_per_chunk;
             int ky = tap / d.KW, kx = tap - ky * d.KW;
             off = ((ky * d.dil) * a.TIW + kx * d.dil) * a.PS + cg * 8 * (int)sizeof(T);
+            if (a.compact) off = (tap * TH * 16) * a.PS + cg * 8 * (int)sizeof(T);
         }
         koff_tab[G] = off;
     }
@@ -159,6 +165,12 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
             int pix = idx / cg_per_chunk, cg = idx - pix * cg_per_chunk;
             int iy = pix / a.TIW, ix = pix - iy * a.TIW;
             int vy = vy0 + iy, vx = vx0 + ix;
+            if (a.compact) {                                   // pix = (tap, row in tile, column): gather that tap's pixel
+                const int tap = iy / TH, py = iy - tap * TH;
+                const int ky = tap / d.KW, kx = tap - ky * d.KW;
+                vy = vy0 + py + ky * d.dil;
+                vx = vx0 + ix + kx * d.dil;
+            }
             bool ok = vy >= 0 && vx >= 0;
             int ry = vy, rx = vx;
             if (d.ups == 2) { ok = ok && !((vy | vx) & 1); ry = vy >> 1; rx = vx >> 1; }
@@ -319,8 +331,8 @@ static int conv_plan(int dtype, const msau_conv_desc* d, ConvGeom* gout, TileGeo
     int PT = 4;
     auto ntiles = [&](int pt) { return (int64_t)d->B * cdiv(d->Hout, 4 * pt) * cdiv(d->Wout, 16); };
     if (ntiles(4) < 512) PT = ntiles(2) >= 384 ? 2 : 1;
-    TileGeom t = tile_geom(g, PT, d->KH, d->KW, d->dil, d->stride);
-    while (t.total > 150 * 1024 && PT > 1) { PT >>= 1; t = tile_geom(g, PT, d->KH, d->KW, d->dil, d->stride); }
+    TileGeom t = tile_geom(g, PT, d->KH, d->KW, d->dil, d->stride, d->ups);
+    while (t.total > 150 * 1024 && PT > 1) { PT >>= 1; t = tile_geom(g, PT, d->KH, d->KW, d->dil, d->stride, d->ups); }
     if (t.total > 150 * 1024) return msau_set_error(MSAU_ERR_LDS, "conv2d: tile needs %d B of LDS", t.total);
     int64_t nb = ntiles(PT);
     MSAU_CHECK_ARG(nb < (1ll << 31), "conv2d: grid too large");
@@ -364,6 +376,7 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
         ConvArgs a;
         a.d = *d;
         a.ystride = d->Cout;
+        a.compact = conv_compact(d->KH, d->KW, d->dil, d->stride, d->ups);
         if (g.nslices > 1) {                                  // this slice's rows / channels [128*sl, 128*sl + n)
             const size_t co0 = (size_t)sl * 128, esz = g.esz;
             a.d.Cout = d->Cout - (int)co0 < 128 ? d->Cout - (int)co0 : 128;

@@ -16,7 +16,7 @@
 namespace {
 
 struct WGeom {
-    int esz, taps, cch, nchunks, kreal, kextc, NKT, NKW, CTN;
+    int esz, taps, cch, nchunks, kreal, kextc, NKT, NKW, CTN, compact, slice;
     int TIH, TIW, PSx, PSg, x_bytes, g_bytes, tab_bytes, total;
 };
 
@@ -29,15 +29,20 @@ inline int pix_stride(int c, int esz) {
 int wgrad_geom(int dtype, const msau_wgrad_desc* d, WGeom* out) {
     MSAU_CHECK_ARG(dtype == MSAU_F32 || dtype == MSAU_BF16, "wgrad: bad dtype");
     const int Cin = d->C1 + d->C2;
-    MSAU_CHECK_ARG(Cin > 0 && Cin % 8 == 0 && d->Cout > 0 && d->Cout % 8 == 0 && d->Cout <= 128, "wgrad: bad channels");
+    MSAU_CHECK_ARG(Cin > 0 && Cin % 8 == 0 && d->Cout > 0 && d->Cout % 8 == 0 && d->Cout <= 1024, "wgrad: bad channels");
     MSAU_CHECK_ARG(d->KH >= 1 && d->KW >= 1 && d->KH <= 7 && d->KW <= 7 && d->dil >= 1 && (d->stride == 1 || d->stride == 2), "wgrad: bad kernel");
     WGeom g;
     g.esz = dtype == MSAU_F32 ? 4 : 2;
     g.taps = d->KH * d->KW;
-    g.CTN = cdiv(d->Cout, 16);
+    // wide outputs are launched in slices: 128 channels (bf16) / 64 (fp32: the 256-pixel gradient tile in LDS is 4 bytes wide)
+    g.compact = d->stride == 1 && d->dil >= 16 && g.taps > 1;  // large dilation: one 16 x 16 block per tap (see conv.hip)
+    g.slice = g.esz == 4 ? (g.compact ? 32 : 64) : 128;        // (fp32 + per-tap blocks: 9 x 256 input pixels leave room for 32)
+    const int cout_s = d->Cout > g.slice ? g.slice : d->Cout;
+    g.CTN = cdiv(cout_s, 16);
     g.TIH = 15 * d->stride + (d->KH - 1) * d->dil + 1;
     g.TIW = 15 * d->stride + (d->KW - 1) * d->dil + 1;
-    g.PSg = pix_stride(d->Cout, g.esz);
+    if (g.compact) { g.TIH = g.taps * 16; g.TIW = 16; }
+    g.PSg = pix_stride(cout_s, g.esz);
     g.g_bytes = roundup(256 * g.PSg, 16);
     int best = 0;
     for (int c = (Cin < 64 ? Cin : 64); c >= 8; c -= 8) {
@@ -67,7 +72,9 @@ int wgrad_geom(int dtype, const msau_wgrad_desc* d, WGeom* out) {
 }
 
 struct WArgs {
-    msau_wgrad_desc d;
+    msau_wgrad_desc d;                           // d.Cout = channels of THIS slice
+    int g_stride, co0, cout_total;               // channels per pixel of g, first channel of the slice, slab rows per chunk
+    int compact;
     int cch, nchunks, kreal, kextc, NKT;
     int TIH, TIW, PSx, PSg, x_bytes, g_bytes, tab_bytes;
     int tiles_x, tiles_y, ntiles;
@@ -98,6 +105,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
             int tap = k / a.cch, c = k - tap * a.cch;
             int ky = tap / d.KW, kx = tap - ky * d.KW;
             off = ((ky * d.dil) * a.TIW + kx * d.dil) * a.PSx + c * (int)sizeof(T);
+            if (a.compact) off = (tap * 256) * a.PSx + c * (int)sizeof(T);
         } else if (k == a.kreal) {
             off = TAB_ABS | ones_off;                                         // column kreal = ones (bias)
         } else {
@@ -132,6 +140,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
             int pix = idx / cg_per_chunk, cg = idx - pix * cg_per_chunk;
             int iy = pix / a.TIW, ix = pix - iy * a.TIW;
             int ry = vy0 + iy, rx = vx0 + ix;
+            if (a.compact) {                                   // pix = (tap, row, column) of that tap's 16 x 16 block
+                const int tap = iy >> 4, py = iy & 15;
+                const int ky = tap / d.KW, kx = tap - ky * d.KW;
+                ry = vy0 + py + ky * d.dil;
+                rx = vx0 + ix + kx * d.dil;
+            }
             V8 v = zero8<T>();
             if (ry >= 0 && rx >= 0 && ry < d.Hin && rx < d.Win) {
                 int cs = chunk * a.cch + cg * 8;
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
             int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
             V8 v = zero8<T>();                                   // pixels outside the image contribute 0
             if (oy < d.Hout && ox < d.Wout)
-                v = load8<T>(gp + (((size_t)b * d.Hout + oy) * d.Wout + ox) * d.Cout + cg * 8);
+                v = load8<T>(gp + (((size_t)b * d.Hout + oy) * d.Wout + ox) * a.g_stride + a.co0 + cg * 8);
             *reinterpret_cast<V8*>(lds_g + m * a.PSg + cg * 8 * (int)sizeof(T)) = v;
         }
         __syncthreads();
@@ -223,7 +237,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
     }
 
     // ---- write this workgroup's slab: slabs[blockIdx.x][chunk][co][k]
-    float* slab = d.slabs + ((size_t)blockIdx.x * a.nchunks + chunk) * d.Cout * a.kextc;
+    float* slab = d.slabs + (((size_t)blockIdx.x * a.nchunks + chunk) * a.cout_total + a.co0) * a.kextc;
 #pragma unroll
     for (int i = 0; i < NKW; ++i) {
         const int nkt = wave + 4 * i;
@@ -306,21 +320,29 @@ extern "C" int msau_conv2d_wgrad(void* stream, int dtype, const msau_wgrad_desc*
     WGeom g;
     int rc = wgrad_geom(dtype, d, &g);
     if (rc) return rc;
-    WArgs a;
-    a.d = *d;
-    a.cch = g.cch; a.nchunks = g.nchunks; a.kreal = g.kreal; a.kextc = g.kextc; a.NKT = g.NKT;
-    a.TIH = g.TIH; a.TIW = g.TIW; a.PSx = g.PSx; a.PSg = g.PSg;
-    a.x_bytes = g.x_bytes; a.g_bytes = g.g_bytes; a.tab_bytes = g.tab_bytes;
-    a.tiles_x = cdiv(d->Wout, 16); a.tiles_y = cdiv(d->Hout, 16);
-    a.ntiles = d->B * a.tiles_x * a.tiles_y;
-    MSAU_CHECK_ARG(d->nslabs >= 1 && d->nslabs <= a.ntiles, "wgrad: nslabs %d not in [1,%d]", d->nslabs, a.ntiles);
-    rc = msau_wgrad_lean_try(static_cast<hipStream_t>(stream), dtype, d, g.cch, g.nchunks, g.kextc);
-    if (rc != 0) return rc < 0 ? rc : 0;
+    const int tiles_x = cdiv(d->Wout, 16), tiles_y = cdiv(d->Hout, 16), ntiles = d->B * tiles_x * tiles_y;
+    MSAU_CHECK_ARG(d->nslabs >= 1 && d->nslabs <= ntiles, "wgrad: nslabs %d not in [1,%d]", d->nslabs, ntiles);
+    if (d->Cout <= g.slice) {
+        rc = msau_wgrad_lean_try(static_cast<hipStream_t>(stream), dtype, d, g.cch, g.nchunks, g.kextc);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     // CTN as instantiated (3 -> 4)
     int CTN = g.CTN == 3 ? 4 : (g.CTN > 4 ? 8 : g.CTN);
     MSAU_CHECK_ARG(!(CTN == 8 && g.NKW > 5), "wgrad: Cout %d with K %d unsupported", d->Cout, g.kextc);
     dim3 grid(d->nslabs, g.nchunks);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == MSAU_F32) return launch_wgrad_ct<float>(s, a, CTN, g.NKW, grid, g.total);
-    return launch_wgrad_ct<bf16_t>(s, a, CTN, g.NKW, grid, g.total);
+    // wide outputs: one launch per slice; every slice writes its rows of the same slabs
+    for (int co0 = 0; co0 < d->Cout; co0 += g.slice) {
+        WArgs a;
+        a.d = *d;
+        a.d.Cout = d->Cout - co0 < g.slice ? d->Cout - co0 : g.slice;
+        a.g_stride = d->Cout; a.co0 = co0; a.cout_total = d->Cout; a.compact = g.compact;
+        a.cch = g.cch; a.nchunks = g.nchunks; a.kreal = g.kreal; a.kextc = g.kextc; a.NKT = g.NKT;
+        a.TIH = g.TIH; a.TIW = g.TIW; a.PSx = g.PSx; a.PSg = g.PSg;
+        a.x_bytes = g.x_bytes; a.g_bytes = g.g_bytes; a.tab_bytes = g.tab_bytes;
+        a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.ntiles = ntiles;
+        rc = dtype == MSAU_F32 ? launch_wgrad_ct<float>(s, a, CTN, g.NKW, grid, g.total) : launch_wgrad_ct<bf16_t>(s, a, CTN, g.NKW, grid, g.total);
+        if (rc) return rc;
+    }
+    return 0;
 }

@@ -266,7 +266,7 @@ template <typename T, bool BWD>
 int lrn_dispatch(hipStream_t s, const void* a, const void* dy, void* out, int64_t npix, int C, int Cs, int n,
                  float alpha, float beta, float k) {
     MSAU_CHECK_ARG(a && out && (!BWD || dy), "lrn: null pointer");
-    MSAU_CHECK_ARG(npix > 0 && C > 0 && C <= Cs && Cs % 8 == 0 && Cs <= 128 && n >= 1, "lrn: bad dims C=%d Cs=%d n=%d", C, Cs, n);
+    MSAU_CHECK_ARG(npix > 0 && C > 0 && C <= Cs && Cs % 8 == 0 && Cs <= 256 && n >= 1, "lrn: bad dims C=%d Cs=%d n=%d", C, Cs, n);
     const float aon = alpha / (float)n;
     const bool b075 = beta == 0.75f;
     static const bool valu_only = std::getenv("MSAU_LRN_VALU") && std::getenv("MSAU_LRN_VALU")[0] == '1';
@@ -275,7 +275,8 @@ int lrn_dispatch(hipStream_t s, const void* a, const void* dy, void* out, int64_
     const T* gp = static_cast<const T*>(dy);
     T* op = static_cast<T*>(out);
     const int G = Cs / 8;
-    const bool fast = (C == Cs) && (n == C) && ((G & (G - 1)) == 0) && G <= 16;
+    const bool fast = (C == Cs) && (n == C) && ((G & (G - 1)) == 0) && G <= 32;
+    MSAU_CHECK_ARG(fast || Cs <= 128, "lrn: the generic path holds at most 128 channels per thread (C=%d n=%d)", C, n);
     if (fast) {
         int grid = grid_for(npix * G);
         switch (G) {
@@ -283,7 +284,8 @@ int lrn_dispatch(hipStream_t s, const void* a, const void* dy, void* out, int64_
             case 2: hipLaunchKernelGGL((lrn_fast_kernel<T, 2, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
             case 4: hipLaunchKernelGGL((lrn_fast_kernel<T, 4, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
             case 8: hipLaunchKernelGGL((lrn_fast_kernel<T, 8, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
-            default: hipLaunchKernelGGL((lrn_fast_kernel<T, 16, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
+            case 16: hipLaunchKernelGGL((lrn_fast_kernel<T, 16, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
+            default: hipLaunchKernelGGL((lrn_fast_kernel<T, 32, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
         }
     } else {
         hipLaunchKernelGGL((lrn_generic_kernel<T, BWD>), dim3(grid_for(npix)), dim3(kThreads), 0, s, ap, gp, op, npix, C, Cs, n, aon, beta, k, b075);
@@ -872,7 +874,7 @@ extern "C" int msau_softmax_ce(void* stream, int dtype, const void* logits, cons
 }
 
 extern "C" int msau_channel_sum(void* stream, int dtype, const void* g, int64_t npix, int Cs, float* partials, int nblk) {
-    MSAU_CHECK_ARG(g && partials && npix > 0 && Cs % 8 == 0 && Cs <= 128 && nblk > 0, "channel_sum: bad args");
+    MSAU_CHECK_ARG(g && partials && npix > 0 && Cs % 8 == 0 && Cs <= 256 && nblk > 0, "channel_sum: bad args");
     MSAU_CHECK_ARG(kThreads % (Cs / 8) == 0, "channel_sum: Cs/8 must divide %d", kThreads);
     hipStream_t s = static_cast<hipStream_t>(stream);
     size_t lds = kThreads * 8 * sizeof(float);

@@ -234,13 +234,10 @@ class MSAUWrapper(nn.Module):
         if self.pool_size != 2 or self.filter_size % 2 != 1:
             raise NotImplementedError("pool_size must be 2 and filter_size odd")
         widest = self.featRoot * 2 ** (self.scale_space_num - 1)
-        if widest > 128:
-            # the conv / wgrad kernels hold at most 8 x 16 output channels per workgroup (include/msau_hip.h); the
-            # reference's constructor defaults (6 scales -> 256 channels, dilation 32) are beyond that, the configurations
-            # it actually trains (train_chargrid_funsd_msau.py:211-214: 4 scales, 64 channels) are not
-            raise NotImplementedError(f"featRoot * 2^(scale_space_num-1) = {widest} channels: the HIP kernels support up to "
-                                      "128 (pass scale_space_num / featRoot explicitly, e.g. 4 and 8 as the reference's "
-                                      "training script does)")
+        if widest > 256:
+            # 256 = the reference's constructor defaults (6 scales from 8 channels, dilation 32: model/model.py:406-408); the
+            # attention kernels are instantiated up to (32, 256) and the LRN fast path up to 256 channels
+            raise NotImplementedError(f"featRoot * 2^(scale_space_num-1) = {widest} channels: the HIP kernels support up to 256")
         self.cfg = dict(channels=channels, n_class=n_class, scale_space_num=self.scale_space_num,
                         res_depth=self.res_depth, featRoot=self.featRoot, filter_size=self.filter_size,
                         pool_size=self.pool_size, num_blocks=self.num_blocks)

@@ -191,6 +191,8 @@ if __name__ == "__main__" and os.environ.get("MSAU_GOLDEN_NET", "1") == "1" and 
     net_golden("net_2stage_c24_dense_24x40", dict(base, channels=24, num_blocks=2), 1, 24, 40, seed=14, dense=True)
     # res_depth 3 / scale_space_num 3 (wrapper defaults differ from the train script)
     net_golden("net_r3_s3_c8_21x35", dict(base, channels=8, res_depth=3, scale_space_num=3), 1, 21, 35, seed=15)
+    # the reference's CONSTRUCTOR DEFAULTS (model/model.py:406-408): 6 scales -> 256 channels, dilation up to 32, res_depth 3
+    net_golden("net_defaults_s6_r3_c8_70x96", dict(base, channels=8, scale_space_num=6, res_depth=3), 1, 70, 96, seed=17)
     # cfg 2 geometry checksum: 336x256x64, 3 stages, forward + loss + grads summaries
     net_golden("net_cfg2_336x256x64", dict(base, channels=64), 1, 336, 256, seed=16)
 

@@ -68,6 +68,7 @@ def test_two_rank_engine_equals_single_process_global_batch():
         loss = eng.step(x.cuda(), label.cuda())
     ref = m.flat_parameters.cpu()
     assert torch.equal(got[0][2], got[1][2])                               # replicas stay bit-identical
-    # two Adam steps of lr 1e-4 move a weight by <= 2e-4: the sharded run must agree to summation-order noise
-    assert float((got[0][2] - ref).abs().max()) < 2e-6
+    # two Adam steps of lr 1e-4 move a weight by <= 2e-4: the sharded run must agree to summation-order noise (Adam's
+    # g / sqrt(v) turns a relative gradient difference into the same relative step difference: 5 % of a step is the bar)
+    assert float((got[0][2] - ref).abs().max()) < 1e-5
     assert abs(0.5 * (got[0][1] + got[1][1]) - float(loss)) < 1e-5 * abs(float(loss))   # mean of local losses

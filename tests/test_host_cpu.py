@@ -150,11 +150,14 @@ def test_roofline_tool_known_answers():
     assert sum(int(np.prod(s)) for s in param_shapes(cfg).values()) == w["params"]
 
 
-def test_unsupported_width_fails_at_construction():
-    """the reference's constructor defaults (6 scales -> 256 channels) are outside the kernels' envelope: loud and early"""
-    with pytest.raises(NotImplementedError, match="support up to 128"):
-        MSAUWrapper(4, 3)
-    MSAUWrapper(4, 3, dict(scale_space_num=5, featRoot=8))          # 128 channels: inside
+def test_constructor_defaults_are_the_references_and_construct():
+    """the reference's constructor defaults (model/model.py:406-408: 6 scales -> 256 channels, res_depth 3, featRoot 8) are
+    inside the kernels' envelope since round 2; beyond 256 channels it fails loud and early"""
+    m = MSAUWrapper(4, 3)
+    assert (m.scale_space_num, m.res_depth, m.featRoot) == (6, 3, 8)
+    assert tuple(m.state_dict()["msau_net.blocks.0.downsamplingblock.conv1s.5.conv.weight"].shape) == (256, 128, 3, 3)
+    with pytest.raises(NotImplementedError, match="support up to 256"):
+        MSAUWrapper(4, 3, dict(scale_space_num=7))
 
 
 def test_abi_struct_mirrors_have_the_librarys_sizes():

@@ -402,3 +402,41 @@ def test_data_gradient_wider_than_128_channels(dtype, k, cin, cout):
     tol, bf = TOL[dtype], dtype == L.BF16
     assert err(y, yr.detach(), bf) < tol and err(dx, xr.grad, bf) < tol
     assert err(grads["w"], leaves["w"].grad, bf) < tol and err(grads["b"], leaves["b"].grad, bf) < tol
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cin,cout,k,dil,hw", [(64, 192, 1, 1, (10, 19)), (128, 256, 3, 32, (11, 8)), (64, 128, 3, 16, (21, 40)),
+                                                (256, 256, 3, 1, (6, 9))])
+def test_wide_outputs_and_large_dilations(dtype, cin, cout, k, dil, hw):
+    """the 256-channel levels of the reference's constructor defaults (model/model.py:406-408: 6 scales, dilation 2^l up to 32):
+    more than 128 OUTPUT channels (forward and weight gradient in channel slices) and dilations whose halo rectangle would
+    not fit the LDS (the tile then holds one block per tap)"""
+    torch.manual_seed(11)
+    H, W = hw
+    x = torch.randn(2, cin, H, W)
+    p = {"w": 0.05 * torch.randn(cout, cin, k, k), "b": 0.1 * torch.randn(cout)}
+    gy = torch.randn(2, cout, H, W)
+    leaves = {kk: v.clone().requires_grad_(True) for kk, v in p.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = O.conv_same(xr, leaves["w"], leaves["b"], dilation=dil); yr.backward(gy)
+    y, _, dx, grads = run_graph(_conv_builder(cout, k, False, dil=dil), p, x, gy, dtype)
+    tol, bf = TOL[dtype], dtype == L.BF16
+    assert err(y, yr.detach(), bf) < tol and err(dx, xr.grad, bf) < tol
+    assert err(grads["w"], leaves["w"].grad, bf) < tol and err(grads["b"], leaves["b"].grad, bf) < tol
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_lrn_and_attention_at_256_channels(dtype):
+    torch.manual_seed(12)
+    x = 5.0 * torch.randn(2, 256, 5, 7)
+    gy = torch.randn(2, 256, 5, 7)
+    xr = x.clone().requires_grad_(True)
+    yr = O.lrn(xr, 256); yr.backward(gy)
+
+    def build(plan):
+        y = Act(plan, "y", plan.x_in.H, plan.x_in.W, 256)
+        LrnOp(plan, "l", plan.x_in, y)
+        plan.logits = y
+    y, _, dx, _ = run_graph(build, {}, x, gy, dtype)
+    bf = dtype == L.BF16
+    assert err(y, yr.detach(), bf) < TOL[dtype] and err(dx, xr.grad, bf) < TOL[dtype]
