@@ -143,6 +143,12 @@ extern "C" int msau_run_ops_overlap(void* stream, void* side_stream, const msau_
             if (rc) return rc;
             if (any_side) { rc = join_side(); if (rc) return rc; }
         }
+        if ((o.kind & 0xff) == MSAU_OP_WGRAD && !pending.empty()) {
+            // a weight gradient kept on the main stream (the net's first conv: the tail of the sweep, ~100 us): release the
+            // held-back side launches first so that they run beside it instead of after it
+            int rc = flush();
+            if (rc) return rc;
+        }
         int rc = run_one(stream, o, i);
         if (rc) return rc;
     }

@@ -30,7 +30,14 @@ struct WLeanCfg {
     static constexpr int CTN = (CO8 + 1) / 2;
     static constexpr int X_BYTES = ((TI * TI * PSX + 15) / 16) * 16;
     static constexpr int G_BYTES = 256 * PSG;
-    static constexpr int LDS = X_BYTES + G_BYTES + 64;
+    // PS ("pixel split"): with few accumulator tiles every wave keeps ALL of them and takes a quarter of the tile's pixels,
+    // instead of a quarter of the k-tiles and all the pixels.  The k-tile split leaves waves idle whenever NKT is not a
+    // multiple of 4 (8 -> 8 channels 3x3: 5 k-tiles, wave 0 does 2 and sets the pace; 1x1: 1 k-tile, three waves idle)
+    // and makes every wave read the same g fragments.  The four partial sums meet once, in LDS, after the last tile.
+    static constexpr bool PS = ESZ == 2 && NKT * CTN <= 20;
+    static constexpr int RED_BYTES = PS ? 4 * NKT * CTN * 1024 : 0;
+    static constexpr int TILE_BYTES = X_BYTES + G_BYTES + 64;
+    static constexpr int LDS = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
 };
 
 template <typename T, int C8, int CO8, int KS, int DIL = 1, int STRIDE = 1>
@@ -62,11 +69,12 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanArgs a) {
     if (tid < 8) reinterpret_cast<T*>(smem + ONES)[tid] = (T)(tid == 0 ? 1.0f : 0.0f);
 
     // column-group byte offsets (relative to the pixel's slot in lds_x) for the k-tiles this wave owns
-    constexpr int NB = sizeof(T) == 2 ? 1 : 1;
-    int coloff[NKW];
+    constexpr bool PS = Cfg::PS;
+    constexpr int NACC = PS ? NKT : NKW;                            // accumulator k-tiles per wave
+    int coloff[NACC];
 #pragma unroll
-    for (int i = 0; i < NKW; ++i) {
-        const int nkt = wave + 4 * i;
+    for (int i = 0; i < NACC; ++i) {
+        const int nkt = PS ? i : wave + 4 * i;
         const int k = nkt * 16 + (sizeof(T) == 2 ? (li & 3) * 4 : (li >> 2) * 4);     // first k of the lane's 4-column group
         int off;
         if (k < Cfg::KREAL) {
@@ -78,11 +86,10 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanArgs a) {
         if (sizeof(T) == 4) off += (li & 3) * 4;
         coloff[i] = off;
     }
-    (void)NB;
 
-    f32x4 acc[NKW][CTN];
+    f32x4 acc[NACC][CTN];
 #pragma unroll
-    for (int i = 0; i < NKW; ++i)
+    for (int i = 0; i < NACC; ++i)
 #pragma unroll
         for (int ct = 0; ct < CTN; ++ct) acc[i][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -156,7 +163,35 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanArgs a) {
         __syncthreads();
         if (PIPE && tile + (int)gridDim.x < a.ntiles) issue_loads(tile + gridDim.x);
 
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (PS) {
+            const int q = li >> 2, p = li & 3;
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int blk = wave * 2 + bb;                         // this wave's 32-pixel blocks
+                const int row = blk * 2 + (lg >> 1), col = (lg & 1) * 8 + q;
+                const unsigned char* ga = lds_g + (row * 16 + col) * PSG + 4 * p * 2;
+                bf16x8 afrag[CTN];
+#pragma unroll
+                for (int ct = 0; ct < CTN; ++ct) {
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(ga + ct * 32));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(ga + 4 * PSG + ct * 32));
+                    afrag[ct] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                const int pb0 = (row * STRIDE * TI + col * STRIDE) * PSX;
+#pragma unroll
+                for (int i = 0; i < NKT; ++i) {
+                    const int e = coloff[i];
+                    const int o0 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + e;
+                    const int o1 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + 4 * STRIDE * PSX + e;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o0));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o1));
+                    bf16x8 bfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int ct = 0; ct < CTN; ++ct)
+                        acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[ct], bfrag, acc[i][ct], 0, 0, 0);
+                }
+            }
+        } else if constexpr (sizeof(T) == 2) {
             const int q = li >> 2, p = li & 3;
 #pragma unroll
             for (int blk = 0; blk < 8; ++blk) {
@@ -208,6 +243,33 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanArgs a) {
     }
 
     float* slab = d.slabs + ((size_t)blockIdx.x * a.nchunks + chunk) * d.Cout * a.kextc;
+    if constexpr (PS) {
+        // the four waves' partial sums -> LDS; wave w then adds up k-tiles w, w + 4, ... in the fixed order wave 0..3
+        __syncthreads();                                              // the last tile's fragment reads are done
+        f32x4* red = reinterpret_cast<f32x4*>(smem);                  // [wave][k-tile][ct][lane]
+#pragma unroll
+        for (int i = 0; i < NKT; ++i)
+#pragma unroll
+            for (int ct = 0; ct < CTN; ++ct) red[((wave * NKT + i) * CTN + ct) * 64 + lane] = acc[i][ct];
+        __syncthreads();
+#pragma unroll
+        for (int ii = 0; ii < NKW; ++ii) {
+            const int nkt = wave + 4 * ii;
+            if (nkt >= NKT) continue;
+#pragma unroll
+            for (int ct = 0; ct < CTN; ++ct) {
+                f32x4 v = red[((0 * NKT + nkt) * CTN + ct) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) v += red[((w * NKT + nkt) * CTN + ct) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int co = ct * 16 + lg * 4 + j;
+                    if (co < d.Cout) slab[(size_t)co * a.kextc + nkt * 16 + li] = v[j];
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NKW; ++i) {
         const int nkt = wave + 4 * i;

@@ -1,49 +1,74 @@
-#!/usr/bin/env python3
-"""Per-step timeline from a `rocprofv3 --kernel-trace --output-format csv` run of bench.py: for one steady-state step
-(between two Adam launches) the busy time of every hardware queue, the main queue's time by kernel family, and the idle
-gaps between its dependent launches (the launch-latency floor of DESIGN.md section 5).
-
-    rocprofv3 --kernel-trace --output-format csv -d out -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
-    python tools/timeline.py out/*/*kernel_trace.csv [step index]
-"""
+"""Timeline view of a rocprofv3 kernel trace (rocpd sqlite): for the steady-state steps, per HIP queue busy time and
+idle gaps, and the per-step critical list of the main queue (kernel, duration, gap before it).
+    python tools/timeline.py gpurun_out/x/prof/run_results.db [--step-kernel clip_adam] [--list]"""
+import argparse
 import collections
-import csv
-import sys
-
-FAMILIES = (("conv_lean", "conv_lean"), ("conv_kernel", "conv_generic"), ("wgrad", "wgrad"), ("unpack", "slab reduce"), ("attn", "attention"),
-            ("lrn", "lrn"), ("pool", "pool"), ("nchw", "layout"), ("nhwc", "layout"), ("masked_ce", "loss"), ("label_count", "loss"),
-            ("ordered_sum", "loss"), ("adam", "adam"), ("sqsum", "adam"), ("pack_kernel", "pack"), ("channel_sum", "channel_sum"))
+import re
+import sqlite3
+import subprocess
 
 
-def family(name):
-    for key, fam in FAMILIES:
-        if key in name:
-            return fam
-    return name.split("(")[0][-32:]
+_DEM = {}
+
+
+def short(name):
+    if name not in _DEM:
+        d = name
+        if name.startswith("_Z"):
+            d = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
+        d = d.replace("(anonymous namespace)::", "").replace("__hip_bfloat16", "bf16").replace("__bf16", "bf16")
+        d = re.sub(r"^void ", "", d)
+        d = re.sub(r"\(.*$", "", d)
+        d = d.replace("false", "0").replace("true", "1")
+        _DEM[name] = d[:90]
+    return _DEM[name]
 
 
 def main():
-    rows = list(csv.DictReader(open(sys.argv[1])))
-    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"] and "prep" not in r["Kernel_Name"]]
-    k = int(sys.argv[2]) if len(sys.argv) > 2 else len(adam) // 2
-    seg = rows[adam[k] + 1: adam[k + 1] + 1]
-    t0, t1 = int(seg[0]["Start_Timestamp"]), int(seg[-1]["End_Timestamp"])
-    print(f"step {k}: {(t1 - t0) / 1e3:.0f} us, {len(seg)} kernels")
-    queues = collections.defaultdict(list)
-    for r in seg:
-        queues[r["Queue_Id"]].append(r)
-    for q, rs in sorted(queues.items(), key=lambda kv: -len(kv[1])):
-        busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs)
-        print(f"  queue {q}: {len(rs)} kernels, busy {busy / 1e3:.0f} us, from {(int(rs[0]['Start_Timestamp']) - t0) / 1e3:.0f} to "
-              f"{(int(rs[-1]['End_Timestamp']) - t0) / 1e3:.0f} us")
-    main_q = max(queues.values(), key=len)
-    fam = collections.defaultdict(float)
-    for r in main_q:
-        fam[family(r["Kernel_Name"])] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    gaps = [(int(y["Start_Timestamp"]) - int(x["End_Timestamp"])) / 1e3 for x, y in zip(main_q, main_q[1:])]
-    print("  main queue by family (us):", {k_: round(v) for k_, v in sorted(fam.items(), key=lambda kv: -kv[1])})
-    print(f"  main queue idle between launches: {sum(gaps):.0f} us over {len(gaps)} boundaries; largest {max(gaps):.0f} us")
+    ap = argparse.ArgumentParser()
+    ap.add_argument("db")
+    ap.add_argument("--step-kernel", default="adam_kernel(")
+    ap.add_argument("--nsteps", type=int, default=30)
+    ap.add_argument("--list", action="store_true")
+    ap.add_argument("--skip", type=int, default=10)
+    a = ap.parse_args()
+    c = sqlite3.connect(a.db)
+    rows = c.execute("select name, queue_id, start, end from kernels order by start").fetchall()
+    marks = [i for i, r in enumerate(rows) if a.step_kernel in r[0]]
+    marks = marks[a.skip:a.skip + a.nsteps + 1]
+    nsteps = len(marks) - 1
+    lo, hi = marks[0], marks[-1]
+    sel = rows[lo + 1:hi + 1]
+    t0, t1 = rows[lo][3], rows[hi][3]
+    print(f"{nsteps} steps, {1e-6 * (t1 - t0) / nsteps:.3f} ms/step, {len(sel) / nsteps:.1f} launches/step")
+    byq = collections.defaultdict(list)
+    for r in sel:
+        byq[r[1]].append(r)
+    for q, rs in sorted(byq.items()):
+        busy = sum(r[3] - r[2] for r in rs)
+        gaps = [rs[i + 1][2] - rs[i][3] for i in range(len(rs) - 1)]
+        pos = [g for g in gaps if g > 0]
+        print(f"queue {q}: {len(rs) / nsteps:.1f} launches/step, busy {1e-6 * busy / nsteps:.3f} ms/step, "
+              f"gaps {1e-6 * sum(pos) / nsteps:.3f} ms/step (median {sorted(pos)[len(pos) // 2] / 1e3:.2f} us)")
+        agg = collections.defaultdict(lambda: [0, 0, 0])
+        prev_end = None
+        for r in rs:
+            k = agg[short(r[0])]
+            k[0] += 1; k[1] += r[3] - r[2]
+            if prev_end is not None:
+                k[2] += max(0, r[2] - prev_end)
+            prev_end = r[3]
+        print(f"  {'kernel':90s} {'n/step':>7s} {'avg us':>8s} {'us/step':>8s} {'gap-before us/step':>10s}")
+        for name, (n, t, g) in sorted(agg.items(), key=lambda kv: -kv[1][1] - kv[1][2]):
+            print(f"  {name:90s} {n / nsteps:7.1f} {t / n / 1e3:8.2f} {t / nsteps / 1e3:8.1f} {g / nsteps / 1e3:10.1f}")
+    if a.list:
+        s0 = rows[marks[-2]][3]
+        step = rows[marks[-2] + 1:marks[-1] + 1]
+        ends = {}
+        for r in step:
+            gap = (r[2] - ends[r[1]]) / 1e3 if r[1] in ends else 0.0
+            ends[r[1]] = r[3]
+            print(f"q{r[1]} t={1e-3 * (r[2] - s0):9.1f} dur={1e-3 * (r[3] - r[2]):7.2f} gap={gap:7.2f}  {short(r[0])}")
 
 
 if __name__ == "__main__":
