@@ -14,6 +14,9 @@ struct WLeanArgs {
 };
 
 #define WL_ABS 0x40000000
+#ifndef MSAU_WPS_MAX
+#define MSAU_WPS_MAX 10
+#endif
 
 typedef __attribute__((address_space(3))) bf16x4* lds_v4;
 
@@ -34,7 +37,7 @@ struct WLeanCfg {
     // instead of a quarter of the k-tiles and all the pixels.  The k-tile split leaves waves idle whenever NKT is not a
     // multiple of 4 (8 -> 8 channels 3x3: 5 k-tiles, wave 0 does 2 and sets the pace; 1x1: 1 k-tile, three waves idle)
     // and makes every wave read the same g fragments.  The four partial sums meet once, in LDS, after the last tile.
-    static constexpr bool PS = ESZ == 2 && NKT * CTN <= 20;
+    static constexpr bool PS = ESZ == 2 && NKT * CTN <= MSAU_WPS_MAX;
     static constexpr int RED_BYTES = PS ? 4 * NKT * CTN * 1024 : 0;
     static constexpr int TILE_BYTES = X_BYTES + G_BYTES + 64;
     static constexpr int LDS = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
