@@ -73,6 +73,15 @@ enum {
                                    each [B][Hout][Wout][Cout/2]; `flags` / add / mask_b apply to y, `flags2` (ACCUM and
                                    MASK_B only) / mask_b2 to y2.  Single-source 1x1 / 3x3 convs with C1 == Cout/2 in
                                    {8, 16, 32}; msau_conv2d_launch_info: info[7] & 2 when the launch can take it. */
+    MSAU_CONV_LRN      = 256,   /* second output y2 = LocalResponseNorm(size = Cout)(y) (layers.py:145,161-162: the LRN
+                                   behind the level-entry conv), computed from the storage-rounded y with lrn_alpha_over_n,
+                                   lrn_beta, lrn_k: y2 = y * (k + alpha/n * sum over [c - n/2, c + (n-1)/2] of y^2)^-beta.
+                                   Only with RELU_IN as the other flag; msau_conv2d_launch_info: info[7] & 4 when the
+                                   launch can take it (otherwise run msau_lrn_fwd on y). */
+    MSAU_CONV_POOL     = 512,   /* further output pool_y = MaxPool2d(2,2) of the zero-padded y (model/model.py:158-160),
+                                   [B][ceil(Hout/2)][ceil(Wout/2)][Cout], and, when pool_idx is not NULL, the position
+                                   0..3 (= 2*dy + dx) of the first maximum per element (what msau_maxpool2x2_bwd reads);
+                                   info[7] & 8 when the launch can take it (otherwise run msau_maxpool2x2_fwd on y). */
     MSAU_CONV_HEAD     = 64     /* inference head (kv_model.py:305-313): besides y, write softmax over the Cout real
                                    channels of the (storage-rounded) result to head_probs (fp32 [B][Hout][Wout][Cout],
                                    dense) and the index of its first maximum to head_argmax (uint8 [B][Hout][Wout]).
@@ -104,6 +113,10 @@ typedef struct {
     int32_t flags2;             /* MSAU_CONV_DOUT only: epilogue flags of y2                        */
     void* y2;                   /* MSAU_CONV_DOUT only                                              */
     const void* mask_b2;        /* MSAU_CONV_DOUT only                                              */
+    float lrn_alpha_over_n, lrn_beta, lrn_k;   /* MSAU_CONV_LRN only (y2 is the LRN output)          */
+    int32_t reserved0;
+    void* pool_y;               /* MSAU_CONV_POOL only                                              */
+    uint8_t* pool_idx;          /* MSAU_CONV_POOL only, may be NULL                                 */
 } msau_conv_desc;
 
 /* Geometry of the packed weight image the conv kernel expects for a given layer.
@@ -124,7 +137,8 @@ int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d);
  * info[0] = CT (16-row output-channel tiles), info[1] = PT (pixel tiles per wave: tile = 4*PT x 16),
  * info[2] = dynamic LDS bytes, info[3] = workgroups, info[4] = channel chunk, info[5] = chunks,
  * info[6] = 1 if a compile-time-specialised "lean" instance (conv_lean.hip) takes the launch,
- * info[7] = bit 0: that instance implements MSAU_CONV_HEAD for this descriptor, bit 1: MSAU_CONV_DOUT */
+ * info[7] = bit 0: that instance implements MSAU_CONV_HEAD for this descriptor, bit 1: MSAU_CONV_DOUT,
+ *           bit 2: MSAU_CONV_LRN, bit 3: MSAU_CONV_POOL */
 int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info8);
 
 /* ------------------------------------------------------------------------------------------

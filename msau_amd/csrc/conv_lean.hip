@@ -299,6 +299,59 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
                 }
             }
         }
+        // ---- LocalResponseNorm(size = Cout) of the result as a second output (MSAU_CONV_LRN; layers.py:145,161-162 after the
+        // level-entry conv): y2 = y * (k + alpha/n * window sum of y^2)^-beta, from the storage-rounded y exactly as the
+        // stand-alone msau_lrn_fwd reads it back.  The Cout channels of a pixel sit in RL lanes (lr, q = 0..RL-1), CT*4
+        // consecutive channels each; window sums are differences of the exclusive prefix sum taken half the channels away,
+        // i.e. RL/2 lanes away.  Outside the divergent store guards: every lane takes part in the shuffles.
+        if constexpr (CT <= 2 && !DOUT && !SPLIT && !DUAL && STRIDE == 1 && UPS == 1) {
+            if (flags & MSAU_CONV_LRN) {
+                const int RL = Cout == 8 ? 2 : 4;                          // lanes of a pixel that hold real channels
+                const bool b075 = d.lrn_beta == 0.75f;
+                char* y2 = static_cast<char*>(d.y2) + ((long long)(b * d.Hout + oyw)) * a.out_row + (long long)ox0 * a.out_px;
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) {
+                    float x[CT * 4], P[CT * 4];
+                    float run = 0.f;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const f32x4 v = acc[ct][pt] + bv[ct];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float r = (float)(T)v[j];
+                            x[ct * 4 + j] = r;
+                            run += r * r;
+                            P[ct * 4 + j] = run;
+                        }
+                    }
+                    float inc = run;
+                    const float n1 = __shfl(inc, lane - 16);
+                    if (lg >= 1) inc += n1;
+                    const float n2 = __shfl(inc, lane - 32);
+                    if (lg >= 2) inc += n2;
+                    const float E = inc - run;
+                    const float tot = __shfl(inc, lr + 16 * (RL - 1));
+                    V4 o[CT];
+#pragma unroll
+                    for (int i = 0; i < CT * 4; ++i) {
+                        const float X = E + (i ? P[i - 1] : 0.f);          // exclusive prefix at this lane's channel i
+                        const float Xo = __shfl(X, lane ^ (8 * RL));
+                        const float win = lg < RL / 2 ? Xo : tot - Xo;
+                        const float dd = d.lrn_k + d.lrn_alpha_over_n * win;
+                        float dnb;
+                        if (b075) { const float r = __builtin_amdgcn_rsqf(dd); dnb = r * __builtin_amdgcn_sqrtf(r); }
+                        else dnb = __expf(-d.lrn_beta * __logf(dd));
+                        o[i >> 2][i & 3] = (T)(x[i] * dnb);
+                    }
+                    if (oyw + pt < d.Hout && ox0 + cwt * 16 + lr < d.Wout) {
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            if (lg * (CTT * 4) + (cty + ct) * 4 < Cout)
+                                *reinterpret_cast<V4*>(y2 + (unsigned)(lane_out + ct * 4 * ESZ + pt * a.out_row)) = o[ct];
+                    }
+                }
+            }
+        }
         // ---- inference head on the end conv (MSAU_CONV_HEAD): the 16 channel rows of a pixel sit in the four lanes
         // (lr, q = 0..3); every lane gathers them, runs the shared softmax / first-max routine and writes its own
         // channels.  Outside the divergent store guards above so that all lanes take part in the shuffles.
@@ -484,6 +537,20 @@ int msau_conv_lean_dout_capable(int dtype, const msau_conv_desc* d, int nchunks,
     if (!msau_conv_lean_applicable(dtype, d, nchunks, CT)) return 0;
     return d->C2 == 0 && d->dil == 1 && (d->KH == 1 || d->KH == 3) && (CT == 1 || CT == 2 || CT == 4) &&
            d->Cout == CT * 16 && d->C1 == CT * 8;
+}
+
+// second output LRN(y) (MSAU_CONV_LRN): all Cout channels of a pixel in one workgroup, at most two 16-row tiles
+int msau_conv_lean_lrn_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
+    if (!msau_conv_lean_applicable(dtype, d, nchunks, CT)) return 0;
+    if (d->stride != 1 || d->ups != 1 || d->C2 || CT > 2 || (d->Cout != 8 && d->Cout != 16 * CT)) return 0;
+    if (d->flags & (MSAU_CONV_DOUT | MSAU_CONV_HEAD)) return 0;
+    return !lean_split_wanted(d, CT);
+}
+
+// pooled output (MSAU_CONV_POOL): any stride-1 single-output instance (a 16 x 16 tile holds whole 2 x 2 windows)
+int msau_conv_lean_pool_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
+    (void)dtype; (void)d; (void)nchunks; (void)CT;
+    return 0;
 }
 
 template <typename T>

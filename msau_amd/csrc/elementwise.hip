@@ -63,6 +63,36 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_tiled_kernel(const float* __
     }
 }
 
+// Register form (HW % 4 == 0): a thread owns 4 consecutive pixels x 8 consecutive channels -- eight 16-byte plane loads in
+// flight, an 8 x 4 transpose in registers, four 16-byte (bf16) pixel stores; the Cs/8 lanes of a pixel quad write whole
+// pixels (Cs * sizeof(T) contiguous bytes), lanes Cs/8 apart read 16-byte neighbours of one plane.  No LDS, no barrier.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_reg_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                               int C, int Cs, int64_t HW, int64_t total) {
+    const int cgs = Cs >> 3;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;        // (image, pixel quad, channel group), group fastest
+    if (i >= total) return;
+    const int cg = (int)(i % cgs);
+    const int64_t r = i / cgs;
+    const int64_t quads = HW >> 2;
+    const int64_t b = r / quads, q = r - b * quads;
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cg * 8 + j;
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < C) v[j] = *reinterpret_cast<const f32x4*>(src + ((int64_t)b * C + c) * HW + q * 4);
+    }
+    T* out = dst + ((int64_t)b * HW + q * 4) * Cs + cg * 8;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        typename Vec8<T>::type o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (T)v[j][p];
+        store8<T>(out + (int64_t)p * Cs, o);
+    }
+}
+
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int B, int C, int Cs, int64_t HW) {
     const int cgs = Cs >> 3;
@@ -703,6 +733,17 @@ extern "C" int msau_nchw_to_nhwc(void* stream, int dtype, const float* src, void
     MSAU_CHECK_ARG(src && dst && B > 0 && C > 0 && Cs >= C && Cs % 8 == 0 && H > 0 && W > 0, "nchw_to_nhwc: bad args");
     hipStream_t s = static_cast<hipStream_t>(stream);
     int64_t HW = (int64_t)H * W;
+    static const bool reg_off = std::getenv("MSAU_NCHW_REG") && std::getenv("MSAU_NCHW_REG")[0] == '0';
+    if (!reg_off && HW % 4 == 0 && Cs >= 16 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const int64_t total = (int64_t)B * (HW / 4) * (Cs / 8);
+        MSAU_CHECK_ARG(cdiv64(total, 256) < (1ll << 31), "nchw_to_nhwc: grid too large");
+        const int grid = (int)cdiv64(total, 256);
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL(nchw_to_nhwc_reg_kernel<float>, dim3(grid), dim3(256), 0, s, src, static_cast<float*>(dst), C, Cs, HW, total),
+                   hipLaunchKernelGGL(nchw_to_nhwc_reg_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, src, static_cast<bf16_t*>(dst), C, Cs, HW, total));
+        MSAU_CHECK_LAUNCH("nchw_to_nhwc_reg");
+        return 0;
+    }
     if (Cs >= 32 && Cs <= 1024) {
         const int tiles = (int)cdiv64(HW, 64);
         MSAU_CHECK_ARG((int64_t)B * tiles < (1ll << 31), "nchw_to_nhwc: grid too large");

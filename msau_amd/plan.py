@@ -136,7 +136,8 @@ class ConvOp(Op):
         return [t for t in (self.x1, self.x2, self.fwd_add) if t is not None]
 
     def writes(self):
-        return [self.out]
+        lrn = getattr(self, "lrn", None)           # a fused LRN's output is written by this launch too
+        return [self.out] + ([lrn.y] if lrn is not None else [])
 
     # ---- helpers -------------------------------------------------------------------------
     def _geom(self, C1, C2, Cout, dil, stride, ups):
@@ -235,6 +236,15 @@ class ConvOp(Op):
             P.head_fused = bool(info[7] & 1) and d.flags == 0 and out.C <= 16
             if P.head_fused:
                 d.flags = L.CONV_HEAD
+        lrn = getattr(self, "lrn", None)
+        if lrn is not None and conv and d.flags & ~L.CONV_RELU_IN == 0 and lrn.a.C == lrn.a.Cs:
+            info = (L.i32 * 8)()
+            L.call("msau_conv2d_launch_info", P.dtype, C.byref(d), info)
+            if info[7] & 4:                  # LocalResponseNorm(size=C) in this conv's epilogue: layers.py:145,161-162
+                d.flags |= L.CONV_LRN
+                d.y2 = _ptr(lrn.y.data)
+                d.lrn_alpha_over_n, d.lrn_beta, d.lrn_k = 1e-4 / lrn.a.C, 0.75, 1.0
+                lrn.fused_into = self
         self.fdesc = d
         self.ddesc = [None, None]
         self.wdesc = None
@@ -358,7 +368,7 @@ class ConvOp(Op):
             L.call("msau_conv2d_launch_info", P.dtype, C.byref(d), info)
             nin = d.B * d.Hin * d.Win * (d.C1 + d.C2)
             nout = d.B * d.Hout * d.Wout * d.Cout
-            extra = sum(1 for f in (L.CONV_ADD, L.CONV_ACCUM, L.CONV_MASK_A, L.CONV_MASK_B) if d.flags & f)
+            extra = sum(1 for f in (L.CONV_ADD, L.CONV_ACCUM, L.CONV_MASK_A, L.CONV_MASK_B, L.CONV_LRN) if d.flags & f)
             if d.flags & L.CONV_DOUT:
                 # both halves are written once; the epilogue operands are per half
                 half = nout // 2
@@ -367,6 +377,7 @@ class ConvOp(Op):
                 return f"conv_lean_kernel<{T},CIN{d.C1},CT{info[0]},K{d.KH},dout>", (nin + half * (2 + ex1 + ex2)) * esz
             if info[6]:
                 var = ",dual" if d.C2 else ",ups2" if d.ups == 2 else ",s2" if d.stride == 2 else ""
+                var += ",lrn" if d.flags & L.CONV_LRN else ""
                 name = f"conv_lean_kernel<{T},CIN{d.C1 + d.C2},CT{info[0]},K{d.KH}{var}>"
             else:
                 name = f"conv_kernel<{T},CT{info[0]},PT{info[1]}>"
@@ -637,6 +648,10 @@ class LrnOp(Op):
         self.plan, self.name, self.a, self.y = plan, name, a, y
         self.slot = a.register() if a.needs_grad else None
         self.stage = plan._cur_stage
+        self.fused_into = None             # the ConvOp whose epilogue writes y (MSAU_CONV_LRN), when its instance can
+        prod = plan.ops[-1] if plan.ops else None
+        if isinstance(prod, ConvOp) and prod.out is a and os.environ.get("MSAU_FUSE_LRN", "1") != "0":
+            prod.lrn = self
         plan.ops.append(self)
 
     def reads(self):
@@ -653,12 +668,15 @@ class LrnOp(Op):
         n = a.npix * a.Cs * esz
         self.fkey, self.bkey = f"lrn_fwd<{T},C{a.Cs}>", f"lrn_bwd<{T},C{a.Cs}>"
         self.fbytes, self.bbytes = 2 * n, 3 * n
-        P.note_launch(self.fkey, self.fbytes, 0.0)
+        if self.fused_into is None:
+            P.note_launch(self.fkey, self.fbytes, 0.0)
         if P.training and self.y.grad is not None and a.grad is not None:
             P.note_launch(self.bkey, self.bbytes, 0.0)
 
     def fwd_recs(self):
         a, y = self.a, self.y
+        if self.fused_into is not None:
+            return []
         self._fa = L.LrnArgs(_ptr(a.data), None, _ptr(y.data), a.npix, a.C, a.Cs, a.C, 1e-4, 0.75, 1.0)
         self.plan.rec_meta[C.addressof(self._fa)] = (self.fkey, self.fbytes)
         return [(L.OP_LRN_FWD, self._fa)]
@@ -677,6 +695,8 @@ class LrnOp(Op):
 
     def fwd(self, s):
         a, y = self.a, self.y
+        if self.fused_into is not None:
+            return
         L.call("msau_lrn_fwd", s, self.plan.dtype, _ptr(a.data), _ptr(y.data), a.npix, a.C, a.Cs, a.C, 1e-4, 0.75, 1.0, key=self.fkey)
 
     def bwd(self, s):
