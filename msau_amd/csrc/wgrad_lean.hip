@@ -3,6 +3,7 @@
 // and tap offset is a constant and the column-group offsets live in registers instead of an LDS table.
 // Same slab layout as wgrad_kernel: slabs[workgroup][chunk][Cout][kext], k = [tap][channel] + ones column.
 #include "msau_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -287,6 +288,199 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanArgs a) {
     }
 }
 
+
+// ---- 64-channel chunk -> 8 output channels, 3x3 (the net's first conv: 64 / 768 one-hot input channels -> featRoot): the
+// tail of the backward sweep, alone on the device.  With 8 output channels on the MFMA rows half of every MFMA is padding
+// and 37 k-tiles of input fragments are read per 32 pixels.  Here the roles are swapped:
+//     dW[ci][tap][co] = sum over INPUT pixels q of x[q][ci] * dy[q + pad - tap][co]
+// rows = 64 input channels (4 tiles), columns = (tap, co) pairs (72 -> 5 tiles of two taps), K = the pixels of a 16 x 16
+// INPUT tile; the gradient tile carries the halo (18 x 18 x 8 channels, a tenth of the bytes the input halo cost).  Per 32
+// pixels: 4 + 5 fragments, 20 MFMAs (before: 1 + 37 fragments, 37 MFMAs); waves split the pixels, the 20 accumulator tiles
+// meet in LDS after the last tile.  The bias gradient (the ones column of the slab) is summed from the gradient tile's
+// interior by the threads that stage it.  Slab layout unchanged: slab[co][tap * 64 + ci], ones column at 576.
+struct WIn64 {
+    static constexpr int PSX = 64 * 2 + 16, PSG = 8 * 2 + 16, TG = 18;
+    static constexpr int X_BYTES = 256 * PSX, G_BYTES = TG * TG * PSG;
+    static constexpr int ZERO = X_BYTES + G_BYTES;                  // 16 zero bytes: the missing tenth tap
+    static constexpr int TILE_BYTES = ZERO + 64;
+    static constexpr int RED_BYTES = 4 * 10 * 1024;                 // half of the 20 accumulator tiles of 4 waves
+    static constexpr int LDS = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
+};
+
+__global__ __launch_bounds__(256) void wgrad_in64_kernel(const WLeanArgs a) {
+    typedef bf16_t T;
+    typedef Vec8<T>::type V8;
+    constexpr int PSX = WIn64::PSX, PSG = WIn64::PSG, TG = WIn64::TG;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* lds_x = smem;
+    unsigned char* lds_g = smem + WIn64::X_BYTES;
+    const msau_wgrad_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int chunk = blockIdx.y;
+    const bool relu_in = d.flags & MSAU_CONV_RELU_IN;
+    const int c0 = chunk * 64;
+    const bool second = d.C2 != 0 && c0 >= d.C1;
+    const char* xsrc = static_cast<const char*>(second ? d.x2 : d.x1);
+    const int Cx = second ? d.C2 : d.C1;
+    const int cb = (second ? c0 - d.C1 : c0) * 2;
+    const int in_px = Cx * 2, in_row = d.Win * in_px;
+    const int g_px = d.Cout * 2, g_row = d.Wout * g_px;
+    if (tid < 4) reinterpret_cast<unsigned*>(smem + WIn64::ZERO)[tid] = 0u;
+
+    // B fragments: column group (li & 3) of N-tile nt = taps 2nt + (group >> 1), channels 4 * (group & 1) ..+3, read at
+    // the gradient pixel (r + 2 - ky, c + 2 - kx) of the haloed tile
+    int goff[5];
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) {
+        const int grp = li & 3, tap = 2 * nt + (grp >> 1);
+        const int ky = tap / 3, kx = tap - ky * 3;
+        goff[nt] = tap < 9 ? ((2 - ky) * TG + (2 - kx)) * PSG + (grp & 1) * 8 : WL_ABS | WIn64::ZERO;
+    }
+    f32x4 acc[4][5];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[2][8];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[it][j] = 0.f;
+
+    V8 xr[8], gr[2];
+    auto issue_loads = [&](int tile) {
+        const int t1 = a.tiles_x > 1 ? __umulhi((unsigned)tile, a.mag_tx) : tile;
+        const int txi = tile - t1 * a.tiles_x;
+        const int b = a.tiles_y > 1 ? __umulhi((unsigned)t1, a.mag_ty) : t1;
+        const int tyi = t1 - b * a.tiles_y;
+        const int iy0 = tyi * 16, ix0 = txi * 16;
+        const char* xb = xsrc + (long long)b * d.Hin * in_row + cb;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = tid + it * 256;
+            const int pix = idx >> 3, cg = idx & 7;
+            const int iy = iy0 + (pix >> 4), ix = ix0 + (pix & 15);
+            xr[it] = zero8<T>();
+            if (iy < d.Hin && ix < d.Win) xr[it] = *reinterpret_cast<const V8*>(xb + (unsigned)(iy * in_row + ix * in_px + cg * 16));
+        }
+        const char* gb = static_cast<const char*>(d.g) + (long long)b * d.Hout * g_row;
+        const int gy0 = iy0 + d.pad_t - 2, gx0 = ix0 + d.pad_l - 2;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int m = tid + it * 256;
+            const int i = m / TG, j = m - i * TG;
+            const int oy = gy0 + i, ox = gx0 + j;
+            gr[it] = zero8<T>();
+            if (m < TG * TG && (unsigned)oy < (unsigned)d.Hout && (unsigned)ox < (unsigned)d.Wout)
+                gr[it] = *reinterpret_cast<const V8*>(gb + (unsigned)(oy * g_row + ox * g_px));
+        }
+    };
+    if ((int)blockIdx.x < a.ntiles) issue_loads(blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = tid + it * 256;
+            V8 v = xr[it];
+            if (relu_in) v = relu8<T>(v);
+            *reinterpret_cast<V8*>(lds_x + (idx >> 3) * PSX + (idx & 7) * 16) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int m = tid + it * 256;
+            if (m < TG * TG) {
+                *reinterpret_cast<V8*>(lds_g + m * PSG) = gr[it];
+                // bias: every output pixel belongs to exactly one tile's rows / columns [2 - pad, 17 - pad]
+                const int i = m / TG, j = m - i * TG;
+                if (chunk == 0 && i >= 2 - d.pad_t && i <= 17 - d.pad_t && j >= 2 - d.pad_l && j <= 17 - d.pad_l) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[it][e] += (float)gr[it][e];
+                }
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.ntiles) issue_loads(tile + gridDim.x);
+
+        const int q = li >> 2, p = li & 3;
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            const int blk = wave * 2 + bb;
+            const int row = blk * 2 + (lg >> 1), col = (lg & 1) * 8 + q;
+            const unsigned char* xa = lds_x + (row * 16 + col) * PSX + 8 * p;
+            bf16x8 afrag[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(xa + mt * 32));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(xa + 4 * PSX + mt * 32));
+                afrag[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            const int pb0 = WIn64::X_BYTES + (row * TG + col) * PSG;
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) {
+                const int e = goff[nt];
+                const int o0 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + e;
+                const int o1 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + 4 * PSG + e;
+                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o0));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o1));
+                bf16x8 bfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[mt], bfrag, acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+
+    float* slab = d.slabs + ((size_t)blockIdx.x * a.nchunks + chunk) * d.Cout * a.kextc;
+    f32x4* red = reinterpret_cast<f32x4*>(smem);                      // [wave][10 tiles][lane]
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            const int tt = half * 10 + t;
+            red[(wave * 10 + t) * 64 + lane] = acc[tt / 5][tt % 5];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii) {
+            const int t = wave + 4 * ii;                              // wave-uniform
+            if (t >= 10) continue;
+            const int tt = half * 10 + t, mt = tt / 5, nt = tt % 5;
+            f32x4 v = red[(0 * 10 + t) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) v += red[(w * 10 + t) * 64 + lane];
+            const int tap = 2 * nt + (li >> 3), co = li & 7;
+            if (tap < 9 && co < d.Cout) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) slab[(size_t)co * a.kextc + tap * 64 + mt * 16 + lg * 4 + j] = v[j];
+            }
+        }
+    }
+    // bias gradient and the rest of the padded ones tile: k = 576 .. kext-1
+    __syncthreads();
+    float* bred = reinterpret_cast<float*>(smem);                     // [2][256][8]
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bred[(it * 256 + tid) * 8 + e] = bsum[it][e];
+    __syncthreads();
+    if (tid < 8 && tid < d.Cout) {
+        float s = 0.f;
+        for (int t = 0; t < 512; ++t) s += bred[t * 8 + tid];        // fixed order
+        for (int k = 576; k < a.kextc; ++k) slab[(size_t)tid * a.kextc + k] = k == 576 && chunk == 0 ? s : 0.f;
+    }
+}
+
+int launch_wgrad_in64(hipStream_t s, const WLeanArgs& a) {
+    if (a.kextc != 592) return 0;
+    hipLaunchKernelGGL(wgrad_in64_kernel, dim3(a.d.nslabs, a.nchunks), dim3(256), WIn64::LDS, s, a);
+    MSAU_CHECK_LAUNCH("wgrad_in64_kernel");
+    return 1;
+}
+
 template <typename T, int C8, int CO8, int KS, int DIL = 1, int STRIDE = 1>
 int launch_wlean(hipStream_t s, const WLeanArgs& a) {
     using Cfg = WLeanCfg<T, C8, CO8, KS, DIL, STRIDE>;
@@ -373,6 +567,9 @@ int msau_wgrad_lean_try(hipStream_t s, int dtype, const msau_wgrad_desc* d, int 
     if (d->stride != 1 || d->dil != 1)
         return dtype == MSAU_F32 ? wlean_special<float>(s, a, cch / 8, d->Cout / 8, d->dil, d->stride)
                                  : wlean_special<bf16_t>(s, a, cch / 8, d->Cout / 8, d->dil, d->stride);
+    static const bool in64_off = std::getenv("MSAU_WGRAD_IN64") && std::getenv("MSAU_WGRAD_IN64")[0] == '0';
+    if (!in64_off && dtype == MSAU_BF16 && d->KH == 3 && cch == 64 && d->Cout == 8 && d->pad_t <= 2 && d->pad_l <= 2)
+        return launch_wgrad_in64(s, a);
     if (d->KH == 4) return dtype == MSAU_F32 ? launch_wlean<float, 1, 1, 4>(s, a) : launch_wlean<bf16_t, 1, 1, 4>(s, a);
     if (dtype == MSAU_F32) return d->KH == 3 ? wlean_dispatch<float, 3>(s, a, cch / 8, d->Cout / 8) : wlean_dispatch<float, 1>(s, a, cch / 8, d->Cout / 8);
     return d->KH == 3 ? wlean_dispatch<bf16_t, 3>(s, a, cch / 8, d->Cout / 8) : wlean_dispatch<bf16_t, 1>(s, a, cch / 8, d->Cout / 8);
