@@ -203,6 +203,11 @@ typedef struct {
 
 int msau_wgrad_geometry(int dtype, const msau_wgrad_desc* d, msau_wgrad_geom* out);
 int msau_conv2d_wgrad(void* stream, int dtype, const msau_wgrad_desc* d);
+/* Up to 4 weight gradients of one shape (everything but the tensors equal: msau_conv2d_wgrad_groupable(a, b) != 0) in ONE
+ * grid -- the level-2/3 launches have 64-107 workgroups each and otherwise queue behind each other.  Same slabs, same bits
+ * as n separate launches. */
+int msau_conv2d_wgrad_groupable(int dtype, const msau_wgrad_desc* a, const msau_wgrad_desc* b);
+int msau_conv2d_wgrad_group(void* stream, int dtype, const msau_wgrad_desc* const* ds, int n);
 
 /* ------------------------------------------------------------------------------------------
  * Parameter packing (fp32 master parameters in the reference's OIHW / IOHW layouts -> packed

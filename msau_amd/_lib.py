@@ -118,6 +118,8 @@ _SIGNATURES = {
     "msau_conv_pair": (C.c_int, [vp, C.c_int, C.POINTER(ConvPairDesc)]),
     "msau_wgrad_geometry": (C.c_int, [C.c_int, C.POINTER(WgradDesc), C.POINTER(WgradGeom)]),
     "msau_conv2d_wgrad": (C.c_int, [vp, C.c_int, C.POINTER(WgradDesc)]),
+    "msau_conv2d_wgrad_groupable": (C.c_int, [C.c_int, C.POINTER(WgradDesc), C.POINTER(WgradDesc)]),
+    "msau_conv2d_wgrad_group": (C.c_int, [vp, C.c_int, C.POINTER(C.POINTER(WgradDesc)), C.c_int]),
     "msau_pack_params": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int]),
     "msau_wgrad_reduce": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int]),
     "msau_channel_sum": (C.c_int, [vp, C.c_int, vp, i64, C.c_int, vp, C.c_int]),

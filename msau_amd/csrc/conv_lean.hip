@@ -543,6 +543,7 @@ int msau_conv_lean_dout_capable(int dtype, const msau_conv_desc* d, int nchunks,
 int msau_conv_lean_lrn_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
     if (!msau_conv_lean_applicable(dtype, d, nchunks, CT)) return 0;
     if (d->stride != 1 || d->ups != 1 || d->C2 || CT > 2 || (d->Cout != 8 && d->Cout != 16 * CT)) return 0;
+    if (d->C1 > 32) return 0;          // measured: the 64-channel first conv (46 KB tile, 3 workgroups per CU) pays 22 us for a 12.6 us LRN
     if (d->flags & (MSAU_CONV_DOUT | MSAU_CONV_HEAD)) return 0;
     return !lean_split_wanted(d, CT);
 }

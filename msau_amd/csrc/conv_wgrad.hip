@@ -301,6 +301,8 @@ int launch_wgrad_ct(hipStream_t s, const WArgs& a, int CTN, int NKW, dim3 grid, 
 // wgrad_lean.hip: compile-time-specialised instances
 int msau_wgrad_lean_applicable(int dtype, const msau_wgrad_desc* d, int cch);
 int msau_wgrad_lean_try(hipStream_t s, int dtype, const msau_wgrad_desc* d, int cch, int nchunks, int kextc);
+int msau_wgrad_lean_group(hipStream_t s, int dtype, const msau_wgrad_desc* const* ds, int n, int cch, int nchunks, int kextc);
+int msau_wgrad_lean_groupable(int dtype, const msau_wgrad_desc* d, int cch);
 
 extern "C" int msau_wgrad_geometry(int dtype, const msau_wgrad_desc* d, msau_wgrad_geom* out) {
     WGeom g;
@@ -345,4 +347,33 @@ extern "C" int msau_conv2d_wgrad(void* stream, int dtype, const msau_wgrad_desc*
         if (rc) return rc;
     }
     return 0;
+}
+
+// ---- grouped launch: up to 4 weight gradients of one shape in one grid (include/msau_hip.h)
+extern "C" int msau_conv2d_wgrad_groupable(int dtype, const msau_wgrad_desc* a, const msau_wgrad_desc* b) {
+    if (!a || !b) return 0;
+    WGeom g;
+    if (wgrad_geom(dtype, a, &g)) return 0;
+    if (a->Cout > g.slice || !msau_wgrad_lean_groupable(dtype, a, g.cch)) return 0;
+    return a->B == b->B && a->Hin == b->Hin && a->Win == b->Win && a->Hout == b->Hout && a->Wout == b->Wout && a->C1 == b->C1 &&
+           a->C2 == b->C2 && a->Cout == b->Cout && a->KH == b->KH && a->KW == b->KW && a->dil == b->dil && a->pad_t == b->pad_t &&
+           a->pad_l == b->pad_l && a->stride == b->stride && a->nslabs == b->nslabs;
+}
+
+extern "C" int msau_conv2d_wgrad_group(void* stream, int dtype, const msau_wgrad_desc* const* ds, int n) {
+    MSAU_CHECK_ARG(ds && n >= 1 && n <= 4, "wgrad_group: 1..4 launches");
+    for (int i = 0; i < n; ++i) {
+        MSAU_CHECK_ARG(ds[i] && ds[i]->x1 && ds[i]->g && ds[i]->slabs && (ds[i]->C2 == 0 || ds[i]->x2), "wgrad_group: null pointer");
+        MSAU_CHECK_ARG(i == 0 || msau_conv2d_wgrad_groupable(dtype, ds[0], ds[i]), "wgrad_group: launch %d differs in shape from launch 0", i);
+    }
+    if (n == 1) return msau_conv2d_wgrad(stream, dtype, ds[0]);
+    WGeom g;
+    int rc = wgrad_geom(dtype, ds[0], &g);
+    if (rc) return rc;
+    const int ntiles = ds[0]->B * cdiv(ds[0]->Wout, 16) * cdiv(ds[0]->Hout, 16);
+    MSAU_CHECK_ARG(ds[0]->nslabs >= 1 && ds[0]->nslabs <= ntiles, "wgrad: nslabs %d not in [1,%d]", ds[0]->nslabs, ntiles);
+    rc = msau_wgrad_lean_group(static_cast<hipStream_t>(stream), dtype, ds, n, g.cch, g.nchunks, g.kextc);
+    if (rc == 1) return 0;
+    if (rc < 0) return rc;
+    return msau_set_error(MSAU_ERR_ARG, "wgrad_group: no shared-grid instance for this shape");
 }

@@ -109,8 +109,29 @@ extern "C" int msau_run_ops_overlap(void* stream, void* side_stream, const msau_
         if (rc) return rc;
         if (hipEventRecord(ev, ms) != hipSuccess || hipStreamWaitEvent(ss, ev, 0) != hipSuccess)
             return msau_set_error(MSAU_ERR_HIP, "run_ops_overlap: fork failed");
-        for (auto& po : pending) {
-            rc = run_one(side_stream, po.first, po.second);
+        // weight gradients of one shape released together share a grid (msau_conv2d_wgrad_group)
+        static const bool group_off = std::getenv("MSAU_WGRAD_GROUP") && std::getenv("MSAU_WGRAD_GROUP")[0] == '0';
+        std::vector<char> done(pending.size(), 0);
+        for (size_t i = 0; i < pending.size(); ++i) {
+            if (done[i]) continue;
+            const msau_op& o = pending[i].first;
+            if (!group_off && o.kind == MSAU_OP_WGRAD) {
+                const msau_wgrad_desc* ds[4] = {static_cast<const msau_wgrad_desc*>(o.args), nullptr, nullptr, nullptr};
+                int n = 1;
+                for (size_t j = i + 1; j < pending.size() && n < 4; ++j) {
+                    const msau_op& p = pending[j].first;
+                    if (done[j] || p.kind != MSAU_OP_WGRAD || p.dtype != o.dtype) continue;
+                    if (!msau_conv2d_wgrad_groupable(o.dtype, ds[0], static_cast<const msau_wgrad_desc*>(p.args))) continue;
+                    ds[n++] = static_cast<const msau_wgrad_desc*>(p.args);
+                    done[j] = 1;
+                }
+                if (n > 1) {
+                    rc = msau_conv2d_wgrad_group(side_stream, o.dtype, ds, n);
+                    if (rc) return rc;
+                    continue;
+                }
+            }
+            rc = run_one(side_stream, o, pending[i].second);
             if (rc) return rc;
         }
         pending.clear();

@@ -14,6 +14,12 @@ struct WLeanArgs {
     unsigned mag_tx, mag_ty;                     // ceil(2^32 / tiles_x), ceil(2^32 / tiles_y)
 };
 
+// up to kWGroup launches of one instance (same geometry, different tensors) share a grid: blockIdx.z picks the layer.  The
+// level-2/3 weight gradients have 64-107 workgroups each; two or three of them side by side fill the device instead
+// of queueing behind each other on the side stream.
+constexpr int kWGroup = 4;
+struct WLeanMulti { WLeanArgs a[kWGroup]; };
+
 #define WL_ABS 0x40000000
 #ifndef MSAU_WPS_MAX
 #define MSAU_WPS_MAX 10
@@ -45,7 +51,8 @@ struct WLeanCfg {
 };
 
 template <typename T, int C8, int CO8, int KS, int DIL = 1, int STRIDE = 1>
-__global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanArgs a) {
+__global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanMulti m) {
+    const WLeanArgs& a = m.a[blockIdx.z];
     using Cfg = WLeanCfg<T, C8, CO8, KS, DIL, STRIDE>;
     typedef typename Vec8<T>::type V8;
     constexpr int ESZ = Cfg::ESZ, TI = Cfg::TI, PSX = Cfg::PSX, PSG = Cfg::PSG, NKT = Cfg::NKT, NKW = Cfg::NKW, CTN = Cfg::CTN;
@@ -482,8 +489,9 @@ int launch_wgrad_in64(hipStream_t s, const WLeanArgs& a) {
 }
 
 template <typename T, int C8, int CO8, int KS, int DIL = 1, int STRIDE = 1>
-int launch_wlean(hipStream_t s, const WLeanArgs& a) {
+int launch_wlean(hipStream_t s, const WLeanMulti& m, int n) {
     using Cfg = WLeanCfg<T, C8, CO8, KS, DIL, STRIDE>;
+    const WLeanArgs& a = m.a[0];
     if (Cfg::KEXT != a.kextc) return 0;                              // geometry disagrees with the generic planner
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS > 60 * 1024) {
@@ -492,14 +500,14 @@ int launch_wlean(hipStream_t s, const WLeanArgs& a) {
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "wgrad_lean: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_lean_kernel<T, C8, CO8, KS, DIL, STRIDE>), dim3(a.d.nslabs, a.nchunks), dim3(256), Cfg::LDS, s, a);
+    hipLaunchKernelGGL((wgrad_lean_kernel<T, C8, CO8, KS, DIL, STRIDE>), dim3(a.d.nslabs, a.nchunks, n), dim3(256), Cfg::LDS, s, m);
     MSAU_CHECK_LAUNCH("wgrad_lean_kernel");
     return 1;
 }
 
 template <typename T, int KS>
-int wlean_dispatch(hipStream_t s, const WLeanArgs& a, int c8, int co8) {
-#define WL_CASE(C, O) if (c8 == C && co8 == O) return launch_wlean<T, C, O, KS>(s, a);
+int wlean_dispatch(hipStream_t s, const WLeanMulti& m, int n, int c8, int co8) {
+#define WL_CASE(C, O) if (c8 == C && co8 == O) return launch_wlean<T, C, O, KS>(s, m, n);
     WL_CASE(1, 1) WL_CASE(1, 2) WL_CASE(2, 1) WL_CASE(2, 2) WL_CASE(2, 4) WL_CASE(4, 2) WL_CASE(4, 4) WL_CASE(8, 1)
     WL_CASE(4, 8) WL_CASE(8, 4) WL_CASE(8, 8)
 #undef WL_CASE
@@ -508,17 +516,17 @@ int wlean_dispatch(hipStream_t s, const WLeanArgs& a, int c8, int co8) {
 
 // dilated 3x3 (encoder level-entry convs) and the stride-2 form (transposed-conv weight gradient, roles swapped)
 template <typename T>
-int wlean_special(hipStream_t s, const WLeanArgs& a, int c8, int co8, int dil, int stride) {
+int wlean_special(hipStream_t s, const WLeanMulti& m, int n, int c8, int co8, int dil, int stride) {
     if (stride == 2 && dil == 1) {
-        if (c8 == 1 && co8 == 2) return launch_wlean<T, 1, 2, 3, 1, 2>(s, a);
-        if (c8 == 2 && co8 == 4) return launch_wlean<T, 2, 4, 3, 1, 2>(s, a);
-        if (c8 == 4 && co8 == 8) return launch_wlean<T, 4, 8, 3, 1, 2>(s, a);
+        if (c8 == 1 && co8 == 2) return launch_wlean<T, 1, 2, 3, 1, 2>(s, m, n);
+        if (c8 == 2 && co8 == 4) return launch_wlean<T, 2, 4, 3, 1, 2>(s, m, n);
+        if (c8 == 4 && co8 == 8) return launch_wlean<T, 4, 8, 3, 1, 2>(s, m, n);
         return 0;
     }
     if (stride == 1) {
-        if (dil == 2 && c8 == 1 && co8 == 2) return launch_wlean<T, 1, 2, 3, 2, 1>(s, a);
-        if (dil == 4 && c8 == 2 && co8 == 4) return launch_wlean<T, 2, 4, 3, 4, 1>(s, a);
-        if (dil == 8 && c8 == 4 && co8 == 8) return launch_wlean<T, 4, 8, 3, 8, 1>(s, a);
+        if (dil == 2 && c8 == 1 && co8 == 2) return launch_wlean<T, 1, 2, 3, 2, 1>(s, m, n);
+        if (dil == 4 && c8 == 2 && co8 == 4) return launch_wlean<T, 2, 4, 3, 4, 1>(s, m, n);
+        if (dil == 8 && c8 == 4 && co8 == 8) return launch_wlean<T, 4, 8, 3, 8, 1>(s, m, n);
     }
     return 0;
 }
@@ -554,23 +562,46 @@ int msau_wgrad_lean_applicable(int dtype, const msau_wgrad_desc* d, int cch) {
     return 0;
 }
 
-// 1 = handled, 0 = not applicable (use the generic kernel), < 0 = error.  cch/nchunks/kextc are the generic geometry.
-int msau_wgrad_lean_try(hipStream_t s, int dtype, const msau_wgrad_desc* d, int cch, int nchunks, int kextc) {
-    if (!msau_wgrad_lean_applicable(dtype, d, cch)) return 0;
-    WLeanArgs a;
+static void wlean_fill(WLeanArgs& a, const msau_wgrad_desc* d, int nchunks, int kextc) {
     a.d = *d;
     a.kextc = kextc; a.nchunks = nchunks;
     a.tiles_x = cdiv(d->Wout, 16); a.tiles_y = cdiv(d->Hout, 16);
     a.ntiles = d->B * a.tiles_x * a.tiles_y;
     a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
     a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
-    if (d->stride != 1 || d->dil != 1)
-        return dtype == MSAU_F32 ? wlean_special<float>(s, a, cch / 8, d->Cout / 8, d->dil, d->stride)
-                                 : wlean_special<bf16_t>(s, a, cch / 8, d->Cout / 8, d->dil, d->stride);
+}
+
+static bool wlean_in64(int dtype, const msau_wgrad_desc* d, int cch) {
     static const bool in64_off = std::getenv("MSAU_WGRAD_IN64") && std::getenv("MSAU_WGRAD_IN64")[0] == '0';
-    if (!in64_off && dtype == MSAU_BF16 && d->KH == 3 && cch == 64 && d->Cout == 8 && d->pad_t <= 2 && d->pad_l <= 2)
-        return launch_wgrad_in64(s, a);
-    if (d->KH == 4) return dtype == MSAU_F32 ? launch_wlean<float, 1, 1, 4>(s, a) : launch_wlean<bf16_t, 1, 1, 4>(s, a);
-    if (dtype == MSAU_F32) return d->KH == 3 ? wlean_dispatch<float, 3>(s, a, cch / 8, d->Cout / 8) : wlean_dispatch<float, 1>(s, a, cch / 8, d->Cout / 8);
-    return d->KH == 3 ? wlean_dispatch<bf16_t, 3>(s, a, cch / 8, d->Cout / 8) : wlean_dispatch<bf16_t, 1>(s, a, cch / 8, d->Cout / 8);
+    return !in64_off && dtype == MSAU_BF16 && d->stride == 1 && d->dil == 1 && d->KH == 3 && cch == 64 && d->Cout == 8 &&
+           d->pad_t <= 2 && d->pad_l <= 2;
+}
+
+// 1 = handled, 0 = not applicable (use the generic kernel), < 0 = error.  cch/nchunks/kextc are the generic geometry.
+// ds[0..n): launches of ONE instance and geometry (msau_conv2d_wgrad_group checks that), n <= kWGroup.
+int msau_wgrad_lean_group(hipStream_t s, int dtype, const msau_wgrad_desc* const* ds, int n, int cch, int nchunks, int kextc) {
+    const msau_wgrad_desc* d = ds[0];
+    if (n < 1 || n > kWGroup || !msau_wgrad_lean_applicable(dtype, d, cch)) return 0;
+    WLeanMulti m;
+    for (int i = 0; i < n; ++i) wlean_fill(m.a[i], ds[i], nchunks, kextc);
+    for (int i = n; i < kWGroup; ++i) m.a[i] = m.a[0];
+    if (d->stride != 1 || d->dil != 1)
+        return dtype == MSAU_F32 ? wlean_special<float>(s, m, n, cch / 8, d->Cout / 8, d->dil, d->stride)
+                                 : wlean_special<bf16_t>(s, m, n, cch / 8, d->Cout / 8, d->dil, d->stride);
+    if (wlean_in64(dtype, d, cch)) {
+        if (n != 1) return 0;
+        return launch_wgrad_in64(s, m.a[0]);
+    }
+    if (d->KH == 4) return dtype == MSAU_F32 ? launch_wlean<float, 1, 1, 4>(s, m, n) : launch_wlean<bf16_t, 1, 1, 4>(s, m, n);
+    if (dtype == MSAU_F32) return d->KH == 3 ? wlean_dispatch<float, 3>(s, m, n, cch / 8, d->Cout / 8) : wlean_dispatch<float, 1>(s, m, n, cch / 8, d->Cout / 8);
+    return d->KH == 3 ? wlean_dispatch<bf16_t, 3>(s, m, n, cch / 8, d->Cout / 8) : wlean_dispatch<bf16_t, 1>(s, m, n, cch / 8, d->Cout / 8);
+}
+
+int msau_wgrad_lean_try(hipStream_t s, int dtype, const msau_wgrad_desc* d, int cch, int nchunks, int kextc) {
+    return msau_wgrad_lean_group(s, dtype, &d, 1, cch, nchunks, kextc);
+}
+
+// launches that may share a grid: the same lean instance (not the 64 -> 8 one)
+int msau_wgrad_lean_groupable(int dtype, const msau_wgrad_desc* d, int cch) {
+    return msau_wgrad_lean_applicable(dtype, d, cch) && !wlean_in64(dtype, d, cch);
 }
