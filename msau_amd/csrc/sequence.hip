@@ -99,7 +99,7 @@ extern "C" int msau_run_ops_overlap(void* stream, void* side_stream, const msau_
     // MI355X / ROCm 7.2 against 2 us for a whole tiny kernel (tools/launch_floor.py).  Side ops only need inputs that
     // stay valid for the rest of the sweep, so they are held back and released in batches behind ONE fork: when
     // `fork_every` of them are pending, before a slab reduction (it consumes them), before a join, and at the end.
-    static const int fork_every = std::getenv("MSAU_FORK_EVERY") ? atoi(std::getenv("MSAU_FORK_EVERY")) : 6;
+    static const int fork_every = std::getenv("MSAU_FORK_EVERY") ? atoi(std::getenv("MSAU_FORK_EVERY")) : 8;
     std::vector<std::pair<msau_op, int>> pending;
     bool any_side = false;
     auto flush = [&]() -> int {
