@@ -149,7 +149,7 @@ int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info8);
  *   t   = max(t, 0)                  if MSAU_PAIR_RELU_MID      (forward: the first conv's ReLU)
  *   t  *= (mask_mid > 0)             if MSAU_PAIR_MASK_MID      (backward: through that ReLU)
  *   mid = t                          ([B][H][W][C], zero outside the image: the second conv's SAME padding)
- *   y   = epilogue(W2 * mid + b2)    flags2 = MSAU_CONV_{MASK_A, ADD, ACCUM, RELU_OUT, MASK_B} exactly as msau_conv2d
+ *   y   = epilogue(W2 * mid + b2)    flags2 = MSAU_CONV_{MASK_A, ADD, ACCUM, RELU_OUT, MASK_B, POOL} exactly as msau_conv2d
  * w1 / w2 are the packed images msau_pack_params writes for a single-source 3x3 conv C -> C (forward or flipped
  * data-gradient image).  msau_conv_pair_applicable: 1 if an instance exists for the shape (C, enough tiles, LDS).
  * ------------------------------------------------------------------------------------------ */
@@ -168,6 +168,8 @@ typedef struct {
     const void* mask_a;
     const void* mask_b;
     void* y;
+    void* pool_y;               /* flags2 & MSAU_CONV_POOL (forward flag set only): MaxPool2d(2,2) of the zero-padded y, */
+    uint8_t* pool_idx;          /* [B][ceil(H/2)][ceil(W/2)][C] and the 1-byte positions (may be NULL), as msau_conv2d   */
 } msau_conv_pair_desc;
 int msau_conv_pair_applicable(int dtype, const msau_conv_pair_desc* d);
 int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc* d);

@@ -254,7 +254,18 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
                     }
                 }
             }
-        } else
+        } else {
+        // MSAU_CONV_POOL keeps the rounded results (0 where nothing is stored: the zero padding of the pool)
+        constexpr bool POOL_OK = CT <= 2 && !DOUT && STRIDE == 1 && UPS == 1;
+        V4 keep[POOL_OK ? CT : 1][4];
+        if constexpr (POOL_OK) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) keep[ct][pt][j] = (T)0.f;
+        }
         if (ox0 + cwt * 16 + lr < d.Wout) {
             char* y = static_cast<char*>(d.y) + ((long long)(b * d.Hout + oyw)) * a.out_row + (long long)ox0 * a.out_px;
 #pragma unroll
@@ -295,9 +306,56 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
 #pragma unroll
                         for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
                         *reinterpret_cast<V4*>(yp) = o;
+                        if constexpr (POOL_OK) keep[ct][pt] = o;
                     }
                 }
             }
+        }
+        // ---- MaxPool2d(2,2) of the zero-padded result as a further output (MSAU_CONV_POOL; model/model.py:158-160): the
+        // tile origin is even, so a 2 x 2 window is two rows of this lane (pt 2pp, 2pp + 1) x this lane and its neighbour
+        // lr ^ 1 (one DPP move per dword).  Even lanes compare in the order of msau_maxpool2x2_fwd (first maximum wins) on
+        // the storage-rounded values and write the pooled pixel and, if asked for, the 1-byte positions.
+        if constexpr (POOL_OK) {
+            if (flags & MSAU_CONV_POOL) {
+                const int Ho = (d.Hout + 1) >> 1, Wo = (d.Wout + 1) >> 1;
+                const int col = ox0 + cwt * 16 + lr;
+                constexpr int ND = (int)sizeof(V4) / 4;                    // dwords per 4 stored values
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        V4 nb[2];
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            typedef int dwords __attribute__((ext_vector_type(ND)));
+                            dwords src = __builtin_bit_cast(dwords, keep[ct][2 * pp + r]), dst;
+#pragma unroll
+                            for (int w = 0; w < ND; ++w) dst[w] = __builtin_amdgcn_mov_dpp(src[w], 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+                            nb[r] = __builtin_bit_cast(V4, dst);
+                        }
+                        const int r0 = oyw + 2 * pp;
+                        if (!(lr & 1) && r0 < d.Hout && col < d.Wout && lg * (CTT * 4) + (cty + ct) * 4 < Cout) {
+                            V4 best;
+                            unsigned idx = 0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float bv_ = (float)keep[ct][2 * pp][j];
+                                unsigned bi = 0;
+                                const float c1 = (float)nb[0][j], c2 = (float)keep[ct][2 * pp + 1][j], c3 = (float)nb[1][j];
+                                if (c1 > bv_) { bv_ = c1; bi = 1; }
+                                if (c2 > bv_) { bv_ = c2; bi = 2; }
+                                if (c3 > bv_) { bv_ = c3; bi = 3; }
+                                best[j] = (T)bv_;
+                                idx |= bi << (8 * j);
+                            }
+                            const long long e = (((long long)b * Ho + (r0 >> 1)) * Wo + (col >> 1)) * Cout + lg * (CTT * 4) + (cty + ct) * 4;
+                            *reinterpret_cast<V4*>(static_cast<T*>(d.pool_y) + e) = best;
+                            if (d.pool_idx) *reinterpret_cast<unsigned*>(d.pool_idx + e) = idx;
+                        }
+                    }
+                }
+            }
+        }
         }
         // ---- LocalResponseNorm(size = Cout) of the result as a second output (MSAU_CONV_LRN; layers.py:145,161-162 after the
         // level-entry conv): y2 = y * (k + alpha/n * window sum of y^2)^-beta, from the storage-rounded y exactly as the
@@ -550,8 +608,9 @@ int msau_conv_lean_lrn_capable(int dtype, const msau_conv_desc* d, int nchunks, 
 
 // pooled output (MSAU_CONV_POOL): any stride-1 single-output instance (a 16 x 16 tile holds whole 2 x 2 windows)
 int msau_conv_lean_pool_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
-    (void)dtype; (void)d; (void)nchunks; (void)CT;
-    return 0;
+    if (!msau_conv_lean_applicable(dtype, d, nchunks, CT)) return 0;
+    if (d->stride != 1 || d->ups != 1 || (d->flags & (MSAU_CONV_DOUT | MSAU_CONV_HEAD | MSAU_CONV_LRN))) return 0;
+    return (lean_split_wanted(d, CT) ? 1 : CT) <= 2;
 }
 
 template <typename T>

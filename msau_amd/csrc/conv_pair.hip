@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
             // the residual (forward) / other-path gradient (backward) operand is the input tensor itself: read it back
             // from the raw LDS input tile, position (oy + 2, ox + 2); lanes without channels read slot 0
             const int xt_lane = ch_ok ? (2 * XW + jcol + 2) * PS + ch0 * ESZ : 0;
+            V4 keep[BWD ? 1 : CT][4];                                      // MSAU_CONV_POOL: the rounded results, 0 where nothing is stored
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) {
                 const int oy = wave * 4 + pt;                    // wave-uniform
@@ -334,6 +335,56 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) ov[jj] = (T)v[jj];
                     buf_store4(ry, ok ? goff + ct * 4 * ESZ : kOOB, ov);
+                    if constexpr (!BWD) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) keep[ct][pt][jj] = ok ? ov[jj] : (T)0.f;
+                    }
+                }
+            }
+            // MaxPool2d(2,2) of the zero-padded output (MSAU_CONV_POOL, model/model.py:158-160): tile origins are even, a
+            // window is rows (2pp, 2pp + 1) of this lane and of its neighbour column lr ^ 1; even lanes write.  Same order
+            // of comparisons (first maximum wins) and the same rounded values as msau_maxpool2x2_fwd on y.
+            if constexpr (!BWD) {
+                if (d.flags2 & MSAU_CONV_POOL) {
+                    const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
+                    constexpr int ND = (int)sizeof(V4) / 4;
+                    typedef int dwords __attribute__((ext_vector_type(ND)));
+                    const unsigned pimg = (unsigned)Ho * (unsigned)Wo * (unsigned)a.px;
+                    const __amdgpu_buffer_rsrc_t rp = image_rsrc(static_cast<char*>(d.pool_y) + (long long)b * pimg, pimg);
+                    const __amdgpu_buffer_rsrc_t ri = image_rsrc(d.pool_idx ? d.pool_idx + (long long)b * (pimg / ESZ) : nullptr,
+                                                                 d.pool_idx ? pimg / ESZ : 0u);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp) {
+                            V4 nb[2];
+#pragma unroll
+                            for (int r = 0; r < 2; ++r) {
+                                dwords src = __builtin_bit_cast(dwords, keep[ct][2 * pp + r]), dst;
+#pragma unroll
+                                for (int w = 0; w < ND; ++w) dst[w] = __builtin_amdgcn_mov_dpp(src[w], 0xB1, 0xf, 0xf, true);
+                                nb[r] = __builtin_bit_cast(V4, dst);
+                            }
+                            const int oy = wave * 4 + 2 * pp;
+                            const bool pok = colok && !(lr & 1) && oy < Cfg::OH && ty0 + oy < H;
+                            V4 best;
+                            unsigned idx = 0;
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {
+                                float bv_ = (float)keep[ct][2 * pp][jj];
+                                unsigned bi = 0;
+                                const float c1 = (float)nb[0][jj], c2 = (float)keep[ct][2 * pp + 1][jj], c3 = (float)nb[1][jj];
+                                if (c1 > bv_) { bv_ = c1; bi = 1; }
+                                if (c2 > bv_) { bv_ = c2; bi = 2; }
+                                if (c3 > bv_) { bv_ = c3; bi = 3; }
+                                best[jj] = (T)bv_;
+                                idx |= bi << (8 * jj);
+                            }
+                            const unsigned e = (unsigned)((((ty0 + oy) >> 1) * Wo + ((tx0 + jcol) >> 1)) * Cfg::C + ch0 + ct * 4);   // elements
+                            buf_store4(rp, pok ? e * ESZ : kOOB, best);
+                            __builtin_amdgcn_raw_buffer_store_b32(idx, ri, pok ? e : kOOB, 0, 0);
+                        }
+                    }
                 }
             }
         }
@@ -410,7 +461,8 @@ extern "C" int msau_conv_pair_applicable(int dtype, const msau_conv_pair_desc* d
     if ((d->C != 8 && d->C != 16 && d->C != 32) || d->C > maxc) return 0;
     if (dtype == MSAU_F32 && d->C == 32) return 0;                 // two fp32 tiles + two weight sets exceed the LDS
     if (d->B <= 0 || d->H <= 0 || d->W <= 0) return 0;
-    const bool fwd = d->flags1 == kFwd1 && d->flags2 == kFwd2, bwd = d->flags1 == kBwd1 && d->flags2 == kBwd2;
+    const bool fwd = d->flags1 == kFwd1 && (d->flags2 & ~MSAU_CONV_POOL) == kFwd2, bwd = d->flags1 == kBwd1 && d->flags2 == kBwd2;
+    if (fwd && (d->flags2 & MSAU_CONV_POOL) && !d->pool_y) return 0;
     if (!fwd && !bwd) return 0;
     if (d->add != d->x) return 0;                                  // the ADD operand is read back from the input tile
     const int esz = dtype == MSAU_F32 ? 4 : 2;

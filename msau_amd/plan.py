@@ -136,8 +136,8 @@ class ConvOp(Op):
         return [t for t in (self.x1, self.x2, self.fwd_add) if t is not None]
 
     def writes(self):
-        lrn = getattr(self, "lrn", None)           # a fused LRN's output is written by this launch too
-        return [self.out] + ([lrn.y] if lrn is not None else [])
+        lrn, pool = getattr(self, "lrn", None), getattr(self, "pool", None)     # fused outputs are written by this launch too
+        return [self.out] + ([lrn.y] if lrn is not None else []) + ([pool.y] if pool is not None else [])
 
     # ---- helpers -------------------------------------------------------------------------
     def _geom(self, C1, C2, Cout, dil, stride, ups):
@@ -245,6 +245,14 @@ class ConvOp(Op):
                 d.y2 = _ptr(lrn.y.data)
                 d.lrn_alpha_over_n, d.lrn_beta, d.lrn_k = 1e-4 / lrn.a.C, 0.75, 1.0
                 lrn.fused_into = self
+        pool = getattr(self, "pool", None)
+        if pool is not None and conv and not (d.flags & (L.CONV_LRN | L.CONV_HEAD)):
+            info = (L.i32 * 8)()
+            L.call("msau_conv2d_launch_info", P.dtype, C.byref(d), info)
+            if info[7] & 8:                  # zero pad + MaxPool2d(2,2) in this conv's epilogue: model/model.py:158-160
+                d.flags |= L.CONV_POOL
+                d.pool_y, d.pool_idx = _ptr(pool.y.data), _ptr(pool.idx)
+                pool.fused_into = self
         self.fdesc = d
         self.ddesc = [None, None]
         self.wdesc = None
@@ -381,7 +389,8 @@ class ConvOp(Op):
                 name = f"conv_lean_kernel<{T},CIN{d.C1 + d.C2},CT{info[0]},K{d.KH}{var}>"
             else:
                 name = f"conv_kernel<{T},CT{info[0]},PT{info[1]}>"
-            return name, (nin + nout * (1 + extra)) * esz
+            pooled = (nout // 4) * (esz + 1) if d.flags & L.CONV_POOL else 0       # pooled tensor + 1-byte positions
+            return name, (nin + nout * (1 + extra)) * esz + pooled
 
         self.fkey, self.fbytes = conv_meta(self.fdesc)
         P.note_launch(self.fkey, self.fbytes, self.flops)
@@ -509,12 +518,23 @@ class PairOp:
         f.w2, f.b2, f.add, f.y = P.pack_ptr(c2.w_off), P.pack_ptr(c2.b_off), _ptr(x0.data), _ptr(out.data)
         if not L.load().msau_conv_pair_applicable(P.dtype, C.byref(f)):
             return
+        pool = getattr(c2, "pool", None)
+        if pool is not None:                 # the pooled output rides on the fused launch (c2's own descriptor is not launched)
+            f.flags2 |= L.CONV_POOL
+            f.pool_y, f.pool_idx = _ptr(pool.y.data), _ptr(pool.idx)
+            if L.load().msau_conv_pair_applicable(P.dtype, C.byref(f)):
+                pool.fused_into = self
+            else:
+                f.flags2 &= ~L.CONV_POOL
+                pool.fused_into = None
         self.fdesc = f
         T = "f32" if P.dtype == L.F32 else "bf16"
         esz = 4 if P.dtype == L.F32 else 2
         self.key = f"conv_pair_kernel<{T},C{x0.Cs}>"
         n = P.B * x0.H * x0.W * x0.Cs
         self.fbytes = 3 * n * esz                       # x0 read once (it is also the residual operand), r1 and out written once
+        if f.flags2 & L.CONV_POOL:
+            self.fbytes += (n // 4) * (esz + 1)
         if P.training and c1.ddesc[0] is not None and c2.ddesc[0] is not None and c1.ddesc[1] is None and c2.ddesc[1] is None \
                 and c1.d_off[0] is not None and c2.d_off[0] is not None:
             d1, d2 = c1.ddesc[0], c2.ddesc[0]
@@ -717,6 +737,10 @@ class PoolOp(Op):
         self.idx = torch.zeros((plan.B, y.H, y.W, y.Cs), dtype=torch.uint8, device=plan.device) if plan.training else None
         self.slot = x.register() if x.needs_grad else None
         self.stage = plan._cur_stage
+        self.fused_into = None             # the ConvOp / PairOp whose epilogue writes y and idx (MSAU_CONV_POOL)
+        prod = plan.ops[-1] if plan.ops else None
+        if isinstance(prod, ConvOp) and prod.out is x and os.environ.get("MSAU_FUSE_POOL", "1") != "0":
+            prod.pool = self
         plan.ops.append(self)
 
     def reads(self):
@@ -733,7 +757,8 @@ class PoolOp(Op):
         nx, ny = x.npix * x.Cs, y.npix * y.Cs
         self.fkey, self.bkey = f"pool_fwd<{T},C{x.Cs}>", f"pool_bwd<{T},C{x.Cs}>"
         self.fbytes = (nx + ny) * esz + (ny if P.training else 0)
-        P.note_launch(self.fkey, self.fbytes, 0.0)
+        if self.fused_into is None:
+            P.note_launch(self.fkey, self.fbytes, 0.0)
         self.bbytes = 0
         if P.training and y.grad is not None and x.grad is not None:
             accum, maskb = x.slot_flags(self.slot)
@@ -742,6 +767,8 @@ class PoolOp(Op):
 
     def fwd_recs(self):
         x, y = self.x, self.y
+        if self.fused_into is not None:
+            return []
         self._fa = L.PoolArgs(_ptr(x.data), _ptr(y.data), _ptr(self.idx), None, self.plan.B, x.H, x.W, x.Cs, 0)
         self.plan.rec_meta[C.addressof(self._fa)] = (self.fkey, self.fbytes)
         return [(L.OP_POOL_FWD, self._fa)]
@@ -758,6 +785,8 @@ class PoolOp(Op):
 
     def fwd(self, s):
         x, y = self.x, self.y
+        if self.fused_into is not None:
+            return
         L.call("msau_maxpool2x2_fwd", s, self.plan.dtype, _ptr(x.data), _ptr(y.data), _ptr(self.idx), self.plan.B, x.H, x.W, x.Cs,
                key=self.fkey)
 

@@ -1,0 +1,189 @@
+"""GPU: the fused forms added in round 2 against the launches they replace, at sizes where the specialised ("lean")
+instances take the launch (>= 64 pixel tiles) -- the golden op fixtures are too small for that and go through the generic
+kernels.  Everything through the C ABI (msau_amd.plan -> msau_run_ops / direct ctypes calls).
+
+  * MSAU_CONV_POOL   zero pad + MaxPool2d(2,2) in the producing conv's epilogue: bit-exact (values, positions -> gradients)
+  * MSAU_CONV_LRN    LocalResponseNorm(size=C) in the level-entry conv's epilogue: same arithmetic, other summation order
+  * msau_conv2d_wgrad_group   several weight gradients of one shape in one grid: the same slabs, bit for bit
+  * the role-swapped 64 -> 8 weight gradient (the net's first conv) against autograd
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+from msau_amd import _lib as L
+from oracle import msau_oracle as O
+from tests.golden_util import err
+from tests.hip_harness import Act, ConvOp, LrnOp, PoolOp, run_graph
+
+pytestmark = pytest.mark.gpu
+DT = [pytest.param(L.F32, id="f32"), pytest.param(L.BF16, id="bf16")]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cin,cout,k,hw", [(16, 16, 1, (65, 63)), (8, 32, 3, (49, 70)), (8, 8, 3, (130, 142))])
+def test_pool_in_the_conv_epilogue_is_bit_exact(monkeypatch, dtype, cin, cout, k, hw):
+    torch.manual_seed(11)
+    B, (H, W) = 4, hw
+    x = torch.randn(B, cin, H, W)
+    p = {"w": 0.2 * torch.randn(cout, cin, k, k), "b": 0.1 * torch.randn(cout)}
+    gy = torch.randn(B, cout, (H + 1) // 2, (W + 1) // 2)
+    took = []
+
+    def build(plan):
+        xi = plan.x_in
+        y = Act(plan, "y", H, W, cout, relu_out=True)
+        ConvOp(plan, "c", xi, None, "w", "b", y, k, relu_out=True)
+        q = Act(plan, "q", (H + 1) // 2, (W + 1) // 2, cout)
+        po = PoolOp(plan, "p", y, q)
+        plan.logits = q
+        took.append(po)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MSAU_FUSE_POOL", mode)
+        out[mode] = run_graph(build, p, x, gy, dtype)
+    assert took[0].fused_into is not None and took[1].fused_into is None
+    for a, b in zip(out["1"], out["0"]):
+        if isinstance(a, dict):
+            for n in a:
+                assert torch.equal(a[n], b[n]), n
+        elif a is not None:
+            assert torch.equal(a, b)
+    # and against autograd
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.max_pool2d(torch.nn.functional.pad(O.conv_same(xr, p["w"], p["b"], relu=True), (0, W % 2, 0, H % 2)), 2, 2)
+    assert err(out["1"][0], yr.detach(), dtype == L.BF16) < (3e-2 if dtype == L.BF16 else 1e-4)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("C8,hw", [(8, (57, 61)), (16, (60, 129)), (8, (70, 250))])
+def test_pool_in_the_residual_pair_epilogue_is_bit_exact(monkeypatch, dtype, C8, hw):
+    """conv -> ReLU -> conv -> add -> ReLU (one msau_conv_pair launch) followed by the pool: fused vs stand-alone pool"""
+    torch.manual_seed(12)
+    B, (H, W), c = 4, hw, C8
+    x = torch.randn(B, c, H, W)
+    p = {"w": 0.2 * torch.randn(c, c, 3, 3), "b": 0.1 * torch.randn(c), "w2": 0.2 * torch.randn(c, c, 3, 3), "b2": 0.1 * torch.randn(c)}
+    gy = torch.randn(B, c, (H + 1) // 2, (W + 1) // 2)
+    took = []
+
+    def build(plan):
+        x0 = plan.x_in
+        r1 = Act(plan, "r1", H, W, c, relu_out=True)
+        c1 = ConvOp(plan, "c1", x0, None, "w", "b", r1, 3, relu_in=True, relu_out=True)
+        out = Act(plan, "out", H, W, c, relu_out=True)
+        c2 = ConvOp(plan, "c2", r1, None, "w2", "b2", out, 3, relu_out=True, fwd_add=x0)
+        c1.bwd_add = out                      # d(x0) += g(block output), as Plan._res_block
+        from msau_amd.plan import PairOp
+        PairOp(plan, c1, c2)
+        q = Act(plan, "q", (H + 1) // 2, (W + 1) // 2, c)
+        took.append((PoolOp(plan, "p", out, q), plan))
+        plan.logits = q
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MSAU_FUSE_POOL", mode)
+        out[mode] = run_graph(build, p, x, gy, dtype)
+    pool1, plan1 = took[0]
+    assert plan1.pairs[0].active and pool1.fused_into is plan1.pairs[0] and took[1][0].fused_into is None
+    for a, b in zip(out["1"], out["0"]):
+        if isinstance(a, dict):
+            for n in a:
+                assert torch.equal(a[n], b[n]), n
+        elif a is not None:
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cin,cout,dil,hw", [(8, 8, 1, (130, 140)), (8, 16, 2, (66, 65)), (16, 32, 4, (52, 70))])
+def test_lrn_in_the_conv_epilogue_matches_the_standalone_pass(monkeypatch, dtype, cin, cout, dil, hw):
+    torch.manual_seed(13)
+    B, (H, W) = 4, hw
+    x = torch.randn(B, cin, H, W)
+    p = {"w": 0.3 * torch.randn(cout, cin, 3, 3), "b": 0.1 * torch.randn(cout)}
+    gy = torch.randn(B, cout, H, W)
+    took = []
+
+    def build(plan):
+        a = Act(plan, "a", H, W, cout)
+        ConvOp(plan, "c", plan.x_in, None, "w", "b", a, 3, dil=dil)
+        y = Act(plan, "y", H, W, cout)
+        took.append(LrnOp(plan, "l", a, y))
+        plan.logits = y
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MSAU_FUSE_LRN", mode)
+        out[mode] = run_graph(build, p, x, gy, dtype)
+    assert took[0].fused_into is not None and took[1].fused_into is None
+    bf = dtype == L.BF16
+    # same inputs (the storage-rounded conv result), same formula, different order of the window sums: one bf16 ulp at most
+    assert err(out["1"][0], out["0"][0], bf) < (4e-3 if bf else 1e-6)
+    assert torch.equal(out["1"][2], out["0"][2])           # the backward does not depend on who wrote y
+    xr = x.clone().requires_grad_(True)
+    yr = O.lrn(O.conv_same(xr, p["w"], p["b"], dilation=dil), cout)
+    if True:
+        assert err(out["1"][0], yr.detach(), bf) < (3e-2 if bf else 1e-4)
+
+
+def _wdesc(x, g, slabs, cin, cout, k, nslabs):
+    B, H, W, _ = x.shape
+    w = L.WgradDesc()
+    w.B, w.Hin, w.Win, w.Hout, w.Wout = B, H, W, H, W
+    w.C1, w.C2, w.Cout, w.KH, w.KW = cin, 0, cout, k, k
+    w.dil, w.pad_t, w.pad_l, w.stride, w.flags = 1, k // 2, k // 2, 1, 0
+    w.x1, w.x2, w.g, w.slabs, w.nslabs = x.data_ptr(), None, g.data_ptr(), slabs.data_ptr(), nslabs
+    return w
+
+
+@pytest.mark.parametrize("cin,cout,k,hw", [(32, 32, 3, (42, 32)), (64, 64, 1, (21, 16)), (8, 8, 3, (64, 80))])
+def test_grouped_weight_gradients_write_the_same_slabs(cin, cout, k, hw):
+    torch.manual_seed(14)
+    lib = L.load()
+    s = torch.cuda.current_stream().cuda_stream
+    B, (H, W), n = 4, hw, 3
+    xs = [(torch.randn(B, H, W, cin, device="cuda") * 0.5).to(torch.bfloat16) for _ in range(n)]
+    gs = [(torch.randn(B, H, W, cout, device="cuda") * 0.5).to(torch.bfloat16) for _ in range(n)]
+    probe = _wdesc(xs[0], gs[0], xs[0], cin, cout, k, 1)
+    geom = L.WgradGeom()
+    L.check(lib.msau_wgrad_geometry(L.BF16, C.byref(probe), C.byref(geom)), "geometry")
+    nslabs = min(geom.max_slabs, 48)
+    elems = nslabs * geom.slab_bytes // 4
+    one = [torch.full((elems,), float("nan"), device="cuda") for _ in range(n)]
+    grp = [torch.full((elems,), float("nan"), device="cuda") for _ in range(n)]
+    d1 = [_wdesc(xs[i], gs[i], one[i], cin, cout, k, nslabs) for i in range(n)]
+    d2 = [_wdesc(xs[i], gs[i], grp[i], cin, cout, k, nslabs) for i in range(n)]
+    assert lib.msau_conv2d_wgrad_groupable(L.BF16, C.byref(d2[0]), C.byref(d2[1])) == 1
+    for d in d1:
+        L.check(lib.msau_conv2d_wgrad(s, L.BF16, C.byref(d)), "wgrad")
+    arr = (C.POINTER(L.WgradDesc) * n)(*[C.pointer(d) for d in d2])
+    L.check(lib.msau_conv2d_wgrad_group(s, L.BF16, arr, n), "wgrad_group")
+    torch.cuda.synchronize()
+    for a, b in zip(one, grp):
+        assert not torch.isnan(a).any() and torch.equal(a, b)
+    # a launch of another shape is refused, not mis-grouped
+    other = _wdesc(xs[0], gs[0], grp[0], cin, cout, k, max(1, nslabs - 1))
+    assert lib.msau_conv2d_wgrad_groupable(L.BF16, C.byref(d2[0]), C.byref(other)) == 0
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cin,hw,B", [(64, (37, 45), 3), (128, (33, 18), 2), (64, (16, 16), 1)])
+def test_first_conv_weight_gradient_vs_autograd(dtype, cin, hw, B):
+    """Cin in 64-channel chunks -> 8, 3x3: bf16 takes the role-swapped instance (wgrad_lean.hip, wgrad_in64_kernel), partial
+    tiles and the bias column included; fp32 the generic one"""
+    torch.manual_seed(15)
+    H, W = hw
+    x = (torch.rand(B, cin, H, W) < 0.3).float()            # chargrid-like occupancy
+    p = {"w": 0.1 * torch.randn(8, cin, 3, 3), "b": 0.1 * torch.randn(8)}
+    gy = torch.randn(B, 8, H, W)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    yr = O.conv_same(x, leaves["w"], leaves["b"])
+    yr.backward(gy)
+
+    def build(plan):
+        y = Act(plan, "y", H, W, 8)
+        ConvOp(plan, "c", plan.x_in, None, "w", "b", y, 3)
+        plan.logits = y
+    y, _, _, grads = run_graph(build, p, x, gy, dtype)
+    bf = dtype == L.BF16
+    assert err(y, yr.detach(), bf) < (3e-2 if bf else 1e-4)
+    assert err(grads["w"], leaves["w"].grad, bf) < (3e-2 if bf else 1e-4)
+    assert err(grads["b"], leaves["b"].grad, bf) < (3e-2 if bf else 1e-4)
