@@ -50,8 +50,12 @@ struct LeanCfg {
 // STRIDE = 2: the data gradient of a transposed conv (each output pixel gathers input pixels 2y + k - pad).
 // UPS = 2: the transposed conv itself as a conv over the zero-stuffed input: the LDS tile is the virtual image, only
 // its even/even positions are loaded (the MFMAs run over the zeros; the launch is bound by its 4x larger output).
+// EPI: extra output compiled in -- 0 none, 1 LocalResponseNorm (MSAU_CONV_LRN), 2 max pool (MSAU_CONV_POOL).  Compile-time,
+// not a run-time flag: with the epilogue code merely PRESENT every plain launch of the instance ran 1.3-4 us slower
+// (8 -> 8 3x3: 12.8 -> 15.8 us, tools/small_bench.py), which ate most of what the fusion saved.
+enum { EPI_NONE = 0, EPI_LRN = 1, EPI_POOL = 2 };
 template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false, bool SPLIT = false,
-          int STRIDE = 1, int UPS = 1>
+          int STRIDE = 1, int UPS = 1, int EPI = EPI_NONE>
 __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) {
     static_assert(!SPLIT || (CT == 1 && !DUAL && !DOUT && WGW == 1), "SPLIT instances are single-source, one tile per workgroup");
     static_assert((STRIDE == 1 && UPS == 1) || (!DUAL && !DOUT && WGW == 1 && DIL == 1 && STRIDE * UPS == 2), "strided / upsampling instances");
@@ -256,7 +260,8 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
             }
         } else {
         // MSAU_CONV_POOL keeps the rounded results (0 where nothing is stored: the zero padding of the pool)
-        constexpr bool POOL_OK = CT <= 2 && !DOUT && STRIDE == 1 && UPS == 1;
+        constexpr bool POOL_OK = EPI == EPI_POOL;
+        static_assert(EPI == EPI_NONE || (CT <= 2 && !DOUT && STRIDE == 1 && UPS == 1), "fused epilogues: <= 2 channel tiles, one output");
         V4 keep[POOL_OK ? CT : 1][4];
         if constexpr (POOL_OK) {
 #pragma unroll
@@ -362,7 +367,8 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
         // stand-alone msau_lrn_fwd reads it back.  The Cout channels of a pixel sit in RL lanes (lr, q = 0..RL-1), CT*4
         // consecutive channels each; window sums are differences of the exclusive prefix sum taken half the channels away,
         // i.e. RL/2 lanes away.  Outside the divergent store guards: every lane takes part in the shuffles.
-        if constexpr (CT <= 2 && !DOUT && !SPLIT && !DUAL && STRIDE == 1 && UPS == 1) {
+        if constexpr (EPI == EPI_LRN) {
+            static_assert(!SPLIT && !DUAL, "LRN needs all channels of a pixel in one workgroup");
             if (flags & MSAU_CONV_LRN) {
                 const int RL = Cout == 8 ? 2 : 4;                          // lanes of a pixel that hold real channels
                 const bool b075 = d.lrn_beta == 0.75f;
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
 }
 
 template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false, bool SPLIT = false,
-          int STRIDE = 1, int UPS = 1>
+          int STRIDE = 1, int UPS = 1, int EPI = EPI_NONE>
 int launch_lean(hipStream_t s, const LeanArgs& a0) {
     using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL, WGW, STRIDE>;
     if (Cfg::LDS + 256 > MSAU_LDS_LIMIT) return 0;          // does not fit: the generic kernel takes the launch
@@ -455,7 +461,7 @@ int launch_lean(hipStream_t s, const LeanArgs& a0) {
     a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS > 60 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT, STRIDE, UPS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT, STRIDE, UPS, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_lean: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -470,7 +476,7 @@ int launch_lean(hipStream_t s, const LeanArgs& a0) {
         grid &= ~7;
         a.per_xcd = cdiv(a.ntiles, 8);
     }
-    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT, STRIDE, UPS>), dim3(grid, SPLIT ? a.ct_total : 1), dim3(256 * WGW), Cfg::LDS, s, a);
+    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT, STRIDE, UPS, EPI>), dim3(grid, SPLIT ? a.ct_total : 1), dim3(256 * WGW), Cfg::LDS, s, a);
     MSAU_CHECK_LAUNCH("conv_lean_kernel");
     return 1;
 }
@@ -597,20 +603,62 @@ int msau_conv_lean_dout_capable(int dtype, const msau_conv_desc* d, int nchunks,
            d->Cout == CT * 16 && d->C1 == CT * 8;
 }
 
+// ---- fused epilogues: the instances that exist (the featRoot-8 / featRoot-16 shapes of the reference's configurations);
+// everything else runs the stand-alone LRN / pool launch.  One table for the capability queries and the dispatch.
+//   LRN : level-entry convs  8 -> 8 (3x3), 8 -> 16 (dilation 2), 16 -> 16, 16 -> 32 (dilation 4 / 2)
+//   POOL: coupling 1x1 convs over concat (8+8 -> 8, 16+16 -> 16, 32+32 -> 32) and the split 32 -> 32 3x3 (stage 0, level 2)
+static bool lean_wide_tile(const msau_conv_desc* d, int tiles_y) {          // the 16 x 32 tile of lean_ct
+    return d->Wout >= 64 && (int64_t)d->B * tiles_y * cdiv(d->Wout, 32) >= 512;
+}
+static int lean_epi_case(int dtype, const msau_conv_desc* d, int CT, int epi) {
+    const int c8 = (d->C1 + d->C2) / 8, k = d->KH;
+    const bool dual = d->C2 != 0, split = lean_split_wanted(d, CT);
+    if (epi == EPI_LRN && !dual && !split && k == 3) {
+        if (c8 == 1 && CT == 1 && d->dil == 1 && d->Cout == 8) return dtype == MSAU_BF16 && lean_wide_tile(d, cdiv(d->Hout, 16)) ? 1 : 2;
+        if (c8 == 1 && CT == 1 && d->dil == 2 && d->Cout == 16) return 3;
+        if (c8 == 2 && CT == 2 && d->dil == 4 && d->Cout == 32) return 4;
+        if (c8 == 2 && CT == 1 && d->dil == 1 && d->Cout == 16) return 5;
+        if (c8 == 2 && CT == 2 && d->dil == 2 && d->Cout == 32) return 6;
+    }
+    if (epi == EPI_POOL && d->dil == 1) {
+        if (dual && k == 1 && !split) {
+            if (c8 == 2 && CT == 1) return 10;
+            if (c8 == 4 && CT == 1) return 11;
+            if (c8 == 8 && CT == 2) return 12;
+        }
+        if (!dual && k == 3 && split && c8 == 4) return 13;
+    }
+    return 0;
+}
+template <typename T>
+int lean_epi(hipStream_t s, const LeanArgs& a, int which) {
+    switch (which) {
+        case 1: if constexpr (sizeof(T) == 2) return launch_lean<T, 1, 1, 3, false, 1, 2, false, false, 1, 1, EPI_LRN>(s, a); else return 0;
+        case 2: return launch_lean<T, 1, 1, 3, false, 1, 1, false, false, 1, 1, EPI_LRN>(s, a);
+        case 3: return launch_lean<T, 1, 1, 3, false, 2, 1, false, false, 1, 1, EPI_LRN>(s, a);
+        case 4: return launch_lean<T, 2, 2, 3, false, 4, 1, false, false, 1, 1, EPI_LRN>(s, a);
+        case 5: return launch_lean<T, 2, 1, 3, false, 1, 1, false, false, 1, 1, EPI_LRN>(s, a);
+        case 6: return launch_lean<T, 2, 2, 3, false, 2, 1, false, false, 1, 1, EPI_LRN>(s, a);
+        case 10: return launch_lean<T, 2, 1, 1, true, 1, 1, false, false, 1, 1, EPI_POOL>(s, a);
+        case 11: return launch_lean<T, 4, 1, 1, true, 1, 1, false, false, 1, 1, EPI_POOL>(s, a);
+        case 12: return launch_lean<T, 8, 2, 1, true, 1, 1, false, false, 1, 1, EPI_POOL>(s, a);
+        case 13: return launch_lean<T, 4, 1, 3, false, 1, 1, false, true, 1, 1, EPI_POOL>(s, a);
+        default: return 0;
+    }
+}
+
 // second output LRN(y) (MSAU_CONV_LRN): all Cout channels of a pixel in one workgroup, at most two 16-row tiles
 int msau_conv_lean_lrn_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
     if (!msau_conv_lean_applicable(dtype, d, nchunks, CT)) return 0;
-    if (d->stride != 1 || d->ups != 1 || d->C2 || CT > 2 || (d->Cout != 8 && d->Cout != 16 * CT)) return 0;
-    if (d->C1 > 32) return 0;          // measured: the 64-channel first conv (46 KB tile, 3 workgroups per CU) pays 22 us for a 12.6 us LRN
-    if (d->flags & (MSAU_CONV_DOUT | MSAU_CONV_HEAD)) return 0;
-    return !lean_split_wanted(d, CT);
+    if (d->stride != 1 || d->ups != 1 || (d->flags & (MSAU_CONV_DOUT | MSAU_CONV_HEAD | MSAU_CONV_POOL))) return 0;
+    return lean_epi_case(dtype, d, CT, EPI_LRN) != 0;
 }
 
-// pooled output (MSAU_CONV_POOL): any stride-1 single-output instance (a 16 x 16 tile holds whole 2 x 2 windows)
+// pooled output (MSAU_CONV_POOL): a 16 x 16 tile holds whole 2 x 2 windows
 int msau_conv_lean_pool_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
     if (!msau_conv_lean_applicable(dtype, d, nchunks, CT)) return 0;
     if (d->stride != 1 || d->ups != 1 || (d->flags & (MSAU_CONV_DOUT | MSAU_CONV_HEAD | MSAU_CONV_LRN))) return 0;
-    return (lean_split_wanted(d, CT) ? 1 : CT) <= 2;
+    return lean_epi_case(dtype, d, CT, EPI_POOL) != 0;
 }
 
 template <typename T>
@@ -665,6 +713,11 @@ int msau_conv_lean_try(hipStream_t s, int dtype, const msau_conv_desc* d, int kc
     a.ct_total = CT;
     if (d->stride * d->ups == 2)
         return dtype == MSAU_F32 ? lean_strided<float>(s, a, cin8, CT, d->ups == 2) : lean_strided<bf16_t>(s, a, cin8, CT, d->ups == 2);
+    if (d->flags & (MSAU_CONV_LRN | MSAU_CONV_POOL)) {
+        const int which = lean_epi_case(dtype, d, CT, (d->flags & MSAU_CONV_LRN) ? EPI_LRN : EPI_POOL);
+        if (!which) return msau_set_error(MSAU_ERR_ARG, "conv_lean: no instance with this fused epilogue (msau_conv2d_launch_info)");
+        return dtype == MSAU_F32 ? lean_epi<float>(s, a, which) : lean_epi<bf16_t>(s, a, which);
+    }
     if (lean_split_wanted(d, CT))
         return dtype == MSAU_F32 ? lean_split<float>(s, a, cin8, d->KH) : lean_split<bf16_t>(s, a, cin8, d->KH);
     if (dout) {

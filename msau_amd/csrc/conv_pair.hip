@@ -94,8 +94,11 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned of
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
 }
 
-template <typename T, int C8, int TW, bool BWD>
+// POOL: the forward launch also writes the max-pooled output (MSAU_CONV_POOL).  A template parameter, not a run-time
+// flag: epilogue code that is merely present slows the plain launches (see conv_lean.hip, EPI).
+template <typename T, int C8, int TW, bool BWD, bool POOL = false>
 __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
+    static_assert(!(BWD && POOL), "the pooled output belongs to the forward launch");
     using Cfg = PairCfg<T, C8, TW, BWD>;
     typedef typename Vec8<T>::type V8;
     typedef typename Vec4<T>::type V4;
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
             // the residual (forward) / other-path gradient (backward) operand is the input tensor itself: read it back
             // from the raw LDS input tile, position (oy + 2, ox + 2); lanes without channels read slot 0
             const int xt_lane = ch_ok ? (2 * XW + jcol + 2) * PS + ch0 * ESZ : 0;
-            V4 keep[BWD ? 1 : CT][4];                                      // MSAU_CONV_POOL: the rounded results, 0 where nothing is stored
+            V4 keep[POOL ? CT : 1][4];                                     // MSAU_CONV_POOL: the rounded results, 0 where nothing is stored
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) {
                 const int oy = wave * 4 + pt;                    // wave-uniform
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) ov[jj] = (T)v[jj];
                     buf_store4(ry, ok ? goff + ct * 4 * ESZ : kOOB, ov);
-                    if constexpr (!BWD) {
+                    if constexpr (POOL) {
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) keep[ct][pt][jj] = ok ? ov[jj] : (T)0.f;
                     }
@@ -344,8 +347,8 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
             // MaxPool2d(2,2) of the zero-padded output (MSAU_CONV_POOL, model/model.py:158-160): tile origins are even, a
             // window is rows (2pp, 2pp + 1) of this lane and of its neighbour column lr ^ 1; even lanes write.  Same order
             // of comparisons (first maximum wins) and the same rounded values as msau_maxpool2x2_fwd on y.
-            if constexpr (!BWD) {
-                if (d.flags2 & MSAU_CONV_POOL) {
+            if constexpr (POOL) {
+                {
                     const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
                     constexpr int ND = (int)sizeof(V4) / 4;
                     typedef int dwords __attribute__((ext_vector_type(ND)));
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
     }
 }
 
-template <typename T, int C8, int TW, bool BWD>
+template <typename T, int C8, int TW, bool BWD, bool POOL = false>
 int launch_pair(hipStream_t s, const PairArgs& a0) {
     using Cfg = PairCfg<T, C8, TW, BWD>;
     static_assert(Cfg::LDS + Cfg::LDS_PAD + 256 <= MSAU_LDS_LIMIT, "conv_pair instance does not fit the LDS");
@@ -406,7 +409,7 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
     a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS + Cfg::LDS_PAD > 60 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD, POOL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_pair: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -417,7 +420,7 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
     if (!per_cu) {
         // (hipOccupancyMaxActiveBlocksPerMultiprocessor budgets 64 KB of LDS per CU, not gfx950's 160 KB: compute it here)
         hipFuncAttributes fa;
-        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD>));
+        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD, POOL>));
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_pair: hipFuncGetAttributes: %s", hipGetErrorString(e));
         const int vgprs = ((fa.numRegs > 0 ? fa.numRegs : 64) + 7) & ~7;
         int waves_per_simd = 512 / vgprs;                      // 512 VGPRs per SIMD lane, 8 waves at most
@@ -435,7 +438,7 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
         grid &= ~7;
         a.per_xcd = cdiv(a.ntiles, 8);
     }
-    hipLaunchKernelGGL((conv_pair_kernel<T, C8, TW, BWD>), dim3(grid), dim3(256 * TW), Cfg::LDS + Cfg::LDS_PAD, s, a);
+    hipLaunchKernelGGL((conv_pair_kernel<T, C8, TW, BWD, POOL>), dim3(grid), dim3(256 * TW), Cfg::LDS + Cfg::LDS_PAD, s, a);
     MSAU_CHECK_LAUNCH("conv_pair_kernel");
     return 0;
 }
@@ -487,7 +490,9 @@ extern "C" int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc
     a.px = d->C * esz;
     a.row = d->W * a.px;
     const int c8 = d->C / 8, tw = pair_tw(dtype, d);
-#define PAIR_CASE(T, C8V, TWV) if (c8 == C8V && tw == TWV) return bwd ? launch_pair<T, C8V, TWV, true>(s, a) : launch_pair<T, C8V, TWV, false>(s, a);
+    const bool pool = !bwd && (d->flags2 & MSAU_CONV_POOL);
+#define PAIR_CASE(T, C8V, TWV) if (c8 == C8V && tw == TWV) return bwd ? launch_pair<T, C8V, TWV, true>(s, a) : \
+        pool ? launch_pair<T, C8V, TWV, false, true>(s, a) : launch_pair<T, C8V, TWV, false>(s, a);
     if (dtype == MSAU_BF16) {
         PAIR_CASE(bf16_t, 1, 1) PAIR_CASE(bf16_t, 1, 2) PAIR_CASE(bf16_t, 2, 1) PAIR_CASE(bf16_t, 2, 2) PAIR_CASE(bf16_t, 4, 1)
     } else {

@@ -22,23 +22,35 @@ DT = [pytest.param(L.F32, id="f32"), pytest.param(L.BF16, id="bf16")]
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("cin,cout,k,hw", [(16, 16, 1, (65, 63)), (8, 32, 3, (49, 70)), (8, 8, 3, (130, 142))])
-def test_pool_in_the_conv_epilogue_is_bit_exact(monkeypatch, dtype, cin, cout, k, hw):
+@pytest.mark.parametrize("c,k,dual,hw", [(8, 1, True, (65, 63)), (16, 1, True, (49, 70)), (32, 1, True, (49, 64)), (32, 3, False, (64, 61))])
+def test_pool_in_the_conv_epilogue_is_bit_exact(monkeypatch, dtype, c, k, dual, hw):
+    """the instances that carry the pooled output: the coupling 1x1 conv over concat(prev, cur) (model/model.py:143-148) and
+    the channel-split 32 -> 32 3x3 (second conv of the level-2 residual block)"""
+    if dtype == L.F32 and k == 3:
+        pytest.skip("fp32 32 -> 32 3x3 stages its K in two chunks and runs the generic kernel: nothing to fuse into")
     torch.manual_seed(11)
     B, (H, W) = 4, hw
-    x = torch.randn(B, cin, H, W)
-    p = {"w": 0.2 * torch.randn(cout, cin, k, k), "b": 0.1 * torch.randn(cout)}
-    gy = torch.randn(B, cout, (H + 1) // 2, (W + 1) // 2)
+    x = torch.randn(B, c, H, W)
+    p = {"w": 0.2 * torch.randn(c, 2 * c if dual else c, k, k), "b": 0.1 * torch.randn(c), "w0": 0.3 * torch.randn(c, c, 1, 1),
+         "b0": 0.1 * torch.randn(c)}
+    gy = torch.randn(B, c, (H + 1) // 2, (W + 1) // 2)
     took = []
 
     def build(plan):
         xi = plan.x_in
-        y = Act(plan, "y", H, W, cout, relu_out=True)
-        ConvOp(plan, "c", xi, None, "w", "b", y, k, relu_out=True)
-        q = Act(plan, "q", (H + 1) // 2, (W + 1) // 2, cout)
+        y = Act(plan, "y", H, W, c, relu_out=True)
+        if dual:
+            other = Act(plan, "o", H, W, c)
+            ConvOp(plan, "c0", xi, None, "w0", "b0", other, 1)
+            ConvOp(plan, "c", xi, other, "w", "b", y, k, relu_out=True)
+        else:
+            ConvOp(plan, "c", xi, None, "w", "b", y, k, relu_out=True)
+        q = Act(plan, "q", (H + 1) // 2, (W + 1) // 2, c)
         po = PoolOp(plan, "p", y, q)
         plan.logits = q
         took.append(po)
+    if not dual:
+        p.pop("w0"); p.pop("b0")
     out = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("MSAU_FUSE_POOL", mode)
@@ -51,9 +63,10 @@ def test_pool_in_the_conv_epilogue_is_bit_exact(monkeypatch, dtype, cin, cout, k
         elif a is not None:
             assert torch.equal(a, b)
     # and against autograd
-    xr = x.clone().requires_grad_(True)
-    yr = torch.nn.functional.max_pool2d(torch.nn.functional.pad(O.conv_same(xr, p["w"], p["b"], relu=True), (0, W % 2, 0, H % 2)), 2, 2)
-    assert err(out["1"][0], yr.detach(), dtype == L.BF16) < (3e-2 if dtype == L.BF16 else 1e-4)
+    xr = x.clone()
+    src = torch.cat([xr, O.conv_same(xr, p["w0"], p["b0"])], 1) if dual else xr
+    yr = torch.nn.functional.max_pool2d(torch.nn.functional.pad(O.conv_same(src, p["w"], p["b"], relu=True), (0, W % 2, 0, H % 2)), 2, 2)
+    assert err(out["1"][0], yr, dtype == L.BF16) < (3e-2 if dtype == L.BF16 else 1e-4)
 
 
 @pytest.mark.parametrize("dtype", DT)

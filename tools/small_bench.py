@@ -38,7 +38,7 @@ def t(H, W, Cc):
 
 
 rows_out = []
-for (H, W, Cc, K) in ((168, 128, 16, 3), (84, 64, 32, 3), (84, 64, 32, 1), (42, 32, 64, 3), (42, 32, 64, 1), (336, 256, 8, 3)):
+for (H, W, Cc, K) in ((168, 128, 16, 3), (84, 64, 32, 3), (84, 64, 32, 1), (42, 32, 64, 3), (42, 32, 64, 1), (336, 256, 8, 3), (336, 256, 8, 4), (336, 256, 8, 1), (336, 256, 16, 1)):
     x, y, m = t(H, W, Cc), t(H, W, Cc), t(H, W, Cc)
     kchunk = -(-K * K * Cc // 32) * 32
     rows = max(16, Cc)
@@ -50,7 +50,7 @@ for (H, W, Cc, K) in ((168, 128, 16, 3), (84, 64, 32, 3), (84, 64, 32, 1), (42, 
         d.B, d.Hin, d.Win, d.Hout, d.Wout = B, H, W, H, W
         d.C1, d.C2, d.Cout = Cc, 0, Cc
         d.KH = d.KW = K
-        d.dil, d.pad_t, d.pad_l, d.stride, d.ups = 1, K // 2, K // 2, 1, 1
+        d.dil, d.pad_t, d.pad_l, d.stride, d.ups = 1, (K - 1) // 2, (K - 1) // 2, 1, 1
         d.flags = flags
         d.x1, d.wpack, d.bias, d.y = xi.data_ptr(), w.data_ptr(), b.data_ptr(), yo.data_ptr()
         d.add = add.data_ptr() if add is not None else None
