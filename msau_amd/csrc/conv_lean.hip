@@ -53,7 +53,7 @@ struct LeanCfg {
 // EPI: extra output compiled in -- 0 none, 1 LocalResponseNorm (MSAU_CONV_LRN), 2 max pool (MSAU_CONV_POOL).  Compile-time,
 // not a run-time flag: with the epilogue code merely PRESENT every plain launch of the instance ran 1.3-4 us slower
 // (8 -> 8 3x3: 12.8 -> 15.8 us, tools/small_bench.py), which ate most of what the fusion saved.
-enum { EPI_NONE = 0, EPI_LRN = 1, EPI_POOL = 2 };
+enum { EPI_NONE = 0, EPI_LRN = 1, EPI_POOL = 2, EPI_HEAD = 3 };
 template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false, bool SPLIT = false,
           int STRIDE = 1, int UPS = 1, int EPI = EPI_NONE>
 __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) {
@@ -419,7 +419,8 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
         // ---- inference head on the end conv (MSAU_CONV_HEAD): the 16 channel rows of a pixel sit in the four lanes
         // (lr, q = 0..3); every lane gathers them, runs the shared softmax / first-max routine and writes its own
         // channels.  Outside the divergent store guards above so that all lanes take part in the shuffles.
-        if constexpr (KS == 4 && CT == 1 && !DUAL) {
+        if constexpr (EPI == EPI_HEAD) {
+            static_assert(CT == 1 && !DUAL && !DOUT, "the head gathers 16 channel rows of one tile");
             if (flags & MSAU_CONV_HEAD) {
                 const int ncls = d.head_classes;
 #pragma unroll
@@ -713,6 +714,11 @@ int msau_conv_lean_try(hipStream_t s, int dtype, const msau_conv_desc* d, int kc
     a.ct_total = CT;
     if (d->stride * d->ups == 2)
         return dtype == MSAU_F32 ? lean_strided<float>(s, a, cin8, CT, d->ups == 2) : lean_strided<bf16_t>(s, a, cin8, CT, d->ups == 2);
+    if (d->flags & MSAU_CONV_HEAD) {                             // forward-only: the 8-channel 4x4 end conv (head_capable)
+        if (!msau_conv_lean_head_capable(dtype, d, nchunks, CT)) return 0;
+        return dtype == MSAU_F32 ? launch_lean<float, 1, 1, 4, false, 1, 1, false, false, 1, 1, EPI_HEAD>(s, a)
+                                 : launch_lean<bf16_t, 1, 1, 4, false, 1, 1, false, false, 1, 1, EPI_HEAD>(s, a);
+    }
     if (d->flags & (MSAU_CONV_LRN | MSAU_CONV_POOL)) {
         const int which = lean_epi_case(dtype, d, CT, (d->flags & MSAU_CONV_LRN) ? EPI_LRN : EPI_POOL);
         if (!which) return msau_set_error(MSAU_ERR_ARG, "conv_lean: no instance with this fused epilogue (msau_conv2d_launch_info)");
