@@ -52,7 +52,7 @@ struct WLeanCfg {
 
 template <typename T, int C8, int CO8, int KS, int DIL = 1, int STRIDE = 1>
 __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanMulti m) {
-    const WLeanArgs& a = m.a[blockIdx.z];
+    const WLeanArgs a = m.a[blockIdx.z];                               // by value: one scalar load of the layer's descriptor
     using Cfg = WLeanCfg<T, C8, CO8, KS, DIL, STRIDE>;
     typedef typename Vec8<T>::type V8;
     constexpr int ESZ = Cfg::ESZ, TI = Cfg::TI, PSX = Cfg::PSX, PSG = Cfg::PSG, NKT = Cfg::NKT, NKW = Cfg::NKW, CTN = Cfg::CTN;
