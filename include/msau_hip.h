@@ -170,6 +170,9 @@ typedef struct {
     void* y;
     void* pool_y;               /* flags2 & MSAU_CONV_POOL (forward flag set only): MaxPool2d(2,2) of the zero-padded y, */
     uint8_t* pool_idx;          /* [B][ceil(H/2)][ceil(W/2)][C] and the 1-byte positions (may be NULL), as msau_conv2d   */
+    uint8_t* bits_mid;          /* both NULL, or ReLU masks as bit planes [B][H][W][C/8] (bit c%8 of byte c/8 = element > 0): */
+    uint8_t* bits_a;            /* the forward flag set WRITES (mid > 0) and (x > 0); the backward flag set READS them     */
+                                /* instead of the tensors mask_mid / mask_a (which may then be NULL)                       */
 } msau_conv_pair_desc;
 int msau_conv_pair_applicable(int dtype, const msau_conv_pair_desc* d);
 int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc* d);

@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
 
 class ConvPairDesc(C.Structure):
     _fields_ = [(n, i32) for n in ("B", "H", "W", "C", "flags1", "flags2")] + \
-               [(n, vp) for n in ("x", "w1", "b1", "mask_mid", "mid", "w2", "b2", "add", "mask_a", "mask_b", "y", "pool_y", "pool_idx")]
+               [(n, vp) for n in ("x", "w1", "b1", "mask_mid", "mid", "w2", "b2", "add", "mask_a", "mask_b", "y", "pool_y", "pool_idx", "bits_mid", "bits_a")]
 
 
 PAIR_RELU_IN, PAIR_RELU_MID, PAIR_MASK_MID = 1, 2, 4

@@ -96,7 +96,10 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned of
 
 // POOL: the forward launch also writes the max-pooled output (MSAU_CONV_POOL).  A template parameter, not a run-time
 // flag: epilogue code that is merely present slows the plain launches (see conv_lean.hip, EPI).
-template <typename T, int C8, int TW, bool BWD, bool POOL = false>
+// BITS: the ReLU masks travel as bit planes ([B][H][W][C/8] bytes: one bit per element) -- the forward launch writes the
+// planes of its input (x > 0) and of its intermediate (mid > 0), the backward launch reads them instead of re-reading the
+// two bf16 tensors for one bit per element (110 -> 69 MB per backward launch at level 0).
+template <typename T, int C8, int TW, bool BWD, bool POOL = false, bool BITS = false>
 __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
     static_assert(!(BWD && POOL), "the pooled output belongs to the forward launch");
     using Cfg = PairCfg<T, C8, TW, BWD>;
@@ -150,7 +153,9 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
     const int rt_lane = ch_ok ? Cfg::X_BYTES + jcol * PS + ch0 * ESZ : Cfg::LDS + (lane & 15) * 16;
 
     V8 pre_x[Cfg::NITX];
-    V8 pre_m[BWD ? Cfg::NITM : 1], pre_a[BWD ? Cfg::NITM : 1];
+    V8 pre_m[BWD && !BITS ? Cfg::NITM : 1], pre_a[BWD && !BITS ? Cfg::NITM : 1];
+    unsigned char bit_m[BWD && BITS ? Cfg::NITM : 1], bit_a[BWD && BITS ? Cfg::NITM : 1];
+    constexpr int NITB = (16 * IW * C8) / NT;                      // bit-plane items (a byte each) per thread
     auto decode = [&](int tile, int& b, int& ty0, int& tx0) {
         const int t1 = a.tiles_x > 1 ? __umulhi((unsigned)tile, a.mag_tx) : tile;
         tx0 = (tile - t1 * a.tiles_x) * Cfg::OW;
@@ -173,7 +178,22 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
             const bool ok = ((it + 1) * NT <= NITEMS || idx < NITEMS) && (unsigned)vy < (unsigned)H && (unsigned)vx < (unsigned)W;
             pre_x[it] = buf_load8<T>(rx, ok ? (unsigned)(vy * a.row + vx * a.px + cg * 8 * ESZ) : kOOB);
         }
-        if constexpr (BWD) {
+        if constexpr (BWD && BITS) {
+            const unsigned plane = (unsigned)H * (unsigned)W * C8;
+            const __amdgpu_buffer_rsrc_t rm = image_rsrc(d.bits_mid + (long long)b * plane, live ? plane : 0u);
+            const __amdgpu_buffer_rsrc_t ra = image_rsrc(d.bits_a + (long long)b * plane, live ? plane : 0u);
+#pragma unroll
+            for (int it = 0; it < NITB; ++it) {
+                const int idx = tid + it * NT;
+                const int pix = idx / C8, cg = idx - pix * C8;
+                const int iy = pix / IW, ix = pix - iy * IW;
+                const int my = ty0 - 1 + iy, mx = tx0 - 1 + ix;      // lattice position
+                const bool mok = (unsigned)my < (unsigned)H && (unsigned)mx < (unsigned)W;
+                bit_m[it] = __builtin_amdgcn_raw_buffer_load_b8(rm, mok ? (unsigned)((my * W + mx) * C8 + cg) : kOOB, 0, 0);
+                const int ay = ty0 + iy, ax = tx0 + ix;              // output position
+                bit_a[it] = __builtin_amdgcn_raw_buffer_load_b8(ra, (ay < H && ax < W) ? (unsigned)((ay * W + ax) * C8 + cg) : kOOB, 0, 0);
+            }
+        } else if constexpr (BWD) {
             const __amdgpu_buffer_rsrc_t rm = image_rsrc(static_cast<const char*>(d.mask_mid) + img, live ? img_bytes : 0u);
             const __amdgpu_buffer_rsrc_t ra = image_rsrc(static_cast<const char*>(d.mask_a) + img, live ? img_bytes : 0u);
 #pragma unroll
@@ -198,7 +218,14 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
             const bool ok = (it + 1) * NT <= NITEMS || idx < NITEMS;
             *reinterpret_cast<V8*>(smem + (ok ? pix * PS + cg * 8 * ESZ : Cfg::LDS + 256 + (tid & 15) * 32)) = pre_x[it];   // raw
         }
-        if constexpr (BWD) {
+        if constexpr (BWD && BITS) {
+#pragma unroll
+            for (int it = 0; it < NITB; ++it) {
+                const int idx = tid + it * NT;
+                mt[idx] = bit_m[it];
+                at[idx] = bit_a[it];
+            }
+        } else if constexpr (BWD) {
 #pragma unroll
             for (int it = 0; it < Cfg::NITM; ++it) {
                 const int idx = tid + it * NT;
@@ -287,6 +314,25 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
             }
         }
         __syncthreads();
+        if constexpr (!BWD && BITS) {
+            // bit planes of the input (x > 0, raw tile) and of the intermediate (mid > 0) at this tile's own pixels
+            const unsigned plane = (unsigned)H * (unsigned)W * C8;
+            const __amdgpu_buffer_rsrc_t rbm = image_rsrc(d.bits_mid + (long long)b * plane, plane);
+            const __amdgpu_buffer_rsrc_t rba = image_rsrc(d.bits_a + (long long)b * plane, plane);
+#pragma unroll
+            for (int it = 0; it < NITB; ++it) {
+                const int idx = tid + it * NT;
+                const int pix = idx / C8, cg = idx - pix * C8;
+                const int i = pix / IW, j = pix - i * IW;             // lattice position
+                const int yy = ty0 - 1 + i, xx = tx0 - 1 + j;
+                const bool ownpx = i >= 1 && i <= Cfg::OH && j >= 1 && j <= Cfg::OW && yy < H && xx < W;
+                const V8 xv = *reinterpret_cast<const V8*>(xt + ((i + 1) * XW + (j + 1)) * PS + cg * 8 * ESZ);
+                const V8 rv = *reinterpret_cast<const V8*>(rt + (i * XW + j) * PS + cg * 8 * ESZ);
+                const unsigned off = ownpx ? (unsigned)((yy * W + xx) * C8 + cg) : kOOB;
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)positive_bits<T>(xv), rba, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)positive_bits<T>(rv), rbm, off, 0, 0);
+            }
+        }
         // ================= phase 2: output tile, image position (ty0+oy, tx0+ox), reads the intermediate from LDS ====
         {
             f32x4 acc[CT][4];
@@ -397,7 +443,7 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
     }
 }
 
-template <typename T, int C8, int TW, bool BWD, bool POOL = false>
+template <typename T, int C8, int TW, bool BWD, bool POOL = false, bool BITS = false>
 int launch_pair(hipStream_t s, const PairArgs& a0) {
     using Cfg = PairCfg<T, C8, TW, BWD>;
     static_assert(Cfg::LDS + Cfg::LDS_PAD + 256 <= MSAU_LDS_LIMIT, "conv_pair instance does not fit the LDS");
@@ -409,7 +455,7 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
     a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS + Cfg::LDS_PAD > 60 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD, POOL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD, POOL, BITS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_pair: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -420,7 +466,7 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
     if (!per_cu) {
         // (hipOccupancyMaxActiveBlocksPerMultiprocessor budgets 64 KB of LDS per CU, not gfx950's 160 KB: compute it here)
         hipFuncAttributes fa;
-        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD, POOL>));
+        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD, POOL, BITS>));
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_pair: hipFuncGetAttributes: %s", hipGetErrorString(e));
         const int vgprs = ((fa.numRegs > 0 ? fa.numRegs : 64) + 7) & ~7;
         int waves_per_simd = 512 / vgprs;                      // 512 VGPRs per SIMD lane, 8 waves at most
@@ -438,7 +484,7 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
         grid &= ~7;
         a.per_xcd = cdiv(a.ntiles, 8);
     }
-    hipLaunchKernelGGL((conv_pair_kernel<T, C8, TW, BWD, POOL>), dim3(grid), dim3(256 * TW), Cfg::LDS + Cfg::LDS_PAD, s, a);
+    hipLaunchKernelGGL((conv_pair_kernel<T, C8, TW, BWD, POOL, BITS>), dim3(grid), dim3(256 * TW), Cfg::LDS + Cfg::LDS_PAD, s, a);
     MSAU_CHECK_LAUNCH("conv_pair_kernel");
     return 0;
 }
@@ -481,7 +527,8 @@ extern "C" int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc
     MSAU_CHECK_ARG(msau_conv_pair_applicable(dtype, d), "conv_pair: unsupported shape or flags (C %d, %dx%d, B %d, flags 0x%x / 0x%x; "
                    "MSAU_CONV_ADD must name the input tensor)", d->C, d->H, d->W, d->B, d->flags1, d->flags2);
     const bool bwd = d->flags1 == kBwd1;
-    MSAU_CHECK_ARG(!bwd || (d->mask_mid && d->mask_a), "conv_pair: backward without mask_mid / mask_a");
+    MSAU_CHECK_ARG(!bwd || (d->mask_mid && d->mask_a) || (d->bits_mid && d->bits_a), "conv_pair: backward without mask_mid / mask_a (tensors or bit planes)");
+    MSAU_CHECK_ARG(!d->bits_mid == !d->bits_a, "conv_pair: bits_mid and bits_a come together");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int esz = dtype == MSAU_F32 ? 4 : 2;
     PairArgs a;
@@ -491,8 +538,11 @@ extern "C" int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc
     a.row = d->W * a.px;
     const int c8 = d->C / 8, tw = pair_tw(dtype, d);
     const bool pool = !bwd && (d->flags2 & MSAU_CONV_POOL);
-#define PAIR_CASE(T, C8V, TWV) if (c8 == C8V && tw == TWV) return bwd ? launch_pair<T, C8V, TWV, true>(s, a) : \
-        pool ? launch_pair<T, C8V, TWV, false, true>(s, a) : launch_pair<T, C8V, TWV, false>(s, a);
+    const bool bits = d->bits_mid && d->bits_a;
+#define PAIR_CASE(T, C8V, TWV) if (c8 == C8V && tw == TWV) { \
+        if (bwd) return bits ? launch_pair<T, C8V, TWV, true, false, true>(s, a) : launch_pair<T, C8V, TWV, true>(s, a); \
+        if (pool) return bits ? launch_pair<T, C8V, TWV, false, true, true>(s, a) : launch_pair<T, C8V, TWV, false, true>(s, a); \
+        return bits ? launch_pair<T, C8V, TWV, false, false, true>(s, a) : launch_pair<T, C8V, TWV, false>(s, a); }
     if (dtype == MSAU_BF16) {
         PAIR_CASE(bf16_t, 1, 1) PAIR_CASE(bf16_t, 1, 2) PAIR_CASE(bf16_t, 2, 1) PAIR_CASE(bf16_t, 2, 2) PAIR_CASE(bf16_t, 4, 1)
     } else {

@@ -547,6 +547,14 @@ class PairOp:
                 if L.load().msau_conv_pair_applicable(P.dtype, C.byref(b)):     # MASK_A + ADD of the input tensor only
                     self.bdesc = b
                 self.bbytes = 5 * n * esz               # g (also the ADD operand), r1 mask, x0 mask read once; g_r1, dx written once
+                if self.bdesc is not None and os.environ.get("MSAU_PAIR_BITS", "1") != "0":
+                    # the two ReLU masks as bit planes: written by the forward launch, read by the backward launch
+                    self.bits_mid = torch.zeros((P.B, x0.H, x0.W, x0.Cs // 8), dtype=torch.uint8, device=P.device)
+                    self.bits_a = torch.zeros_like(self.bits_mid)
+                    for dsc in (f, b):
+                        dsc.bits_mid, dsc.bits_a = _ptr(self.bits_mid), _ptr(self.bits_a)
+                    self.fbytes += 2 * (n // 8)
+                    self.bbytes = 3 * n * esz + 2 * (n // 8)
         self.active = True
 
     def note(self):

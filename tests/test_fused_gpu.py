@@ -107,6 +107,41 @@ def test_pool_in_the_residual_pair_epilogue_is_bit_exact(monkeypatch, dtype, C8,
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c,hw", [(8, (57, 61)), (16, (60, 129)), (8, (71, 250))])
+def test_relu_masks_as_bit_planes_give_the_same_gradients(monkeypatch, dtype, c, hw):
+    """the residual pair's backward reads (mid > 0) and (x > 0) from bit planes its forward wrote, instead of the tensors"""
+    torch.manual_seed(16)
+    B, (H, W) = 4, hw
+    x = torch.randn(B, c, H, W)
+    p = {"w": 0.2 * torch.randn(c, c, 3, 3), "b": 0.1 * torch.randn(c), "w2": 0.2 * torch.randn(c, c, 3, 3), "b2": 0.1 * torch.randn(c)}
+    gy = torch.randn(B, c, H, W)
+    plans = []
+
+    def build(plan):
+        x0 = plan.x_in
+        r1 = Act(plan, "r1", H, W, c, relu_out=True)
+        c1 = ConvOp(plan, "c1", x0, None, "w", "b", r1, 3, relu_in=True, relu_out=True)
+        out = Act(plan, "out", H, W, c, relu_out=True)
+        c2 = ConvOp(plan, "c2", r1, None, "w2", "b2", out, 3, relu_out=True, fwd_add=x0)
+        c1.bwd_add = out
+        from msau_amd.plan import PairOp
+        PairOp(plan, c1, c2)
+        plan.logits = out
+        plans.append(plan)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MSAU_PAIR_BITS", mode)
+        out[mode] = run_graph(build, p, x, gy, dtype)
+    assert plans[0].pairs[0].bdesc is not None and plans[0].pairs[0].bdesc.bits_mid and not plans[1].pairs[0].bdesc.bits_mid
+    for a, b in zip(out["1"], out["0"]):
+        if isinstance(a, dict):
+            for n in a:
+                assert torch.equal(a[n], b[n]), n
+        elif a is not None:
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("cin,cout,dil,hw", [(8, 8, 1, (130, 140)), (8, 16, 2, (66, 65)), (16, 32, 4, (52, 70))])
 def test_lrn_in_the_conv_epilogue_matches_the_standalone_pass(monkeypatch, dtype, cin, cout, dil, hw):
     torch.manual_seed(13)
