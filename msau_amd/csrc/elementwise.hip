@@ -156,9 +156,12 @@ __device__ __forceinline__ float rsqrt_valu(float d) {
     return y;
 }
 
-template <typename T, int G, bool BWD>
+// F075: beta == 0.75 with the raw rsq / sqrt path compiled in alone (the reference's only setting); otherwise `powmode`
+// picks at run time (0 exp/log, 1 rsq/sqrt, 2 VALU Newton)
+template <typename T, int G, bool BWD, bool F075>
 __global__ void lrn_fast_kernel(const T* __restrict__ a, const T* __restrict__ dy, T* __restrict__ out,
-                                int64_t npix, float alpha_over_n, float beta, float k, int powmode) {
+                                int64_t npix, float alpha_over_n, float beta, float k, int powmode_rt) {
+    const int powmode = F075 ? 1 : powmode_rt;
     const int64_t total = npix * G;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     // all lanes of a G-group run the same number of iterations (total % G == 0, stride % G == 0)
@@ -310,12 +313,18 @@ int lrn_dispatch(hipStream_t s, const void* a, const void* dy, void* out, int64_
     if (fast) {
         int grid = grid_for(npix * G);
         switch (G) {
-            case 1: hipLaunchKernelGGL((lrn_fast_kernel<T, 1, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
-            case 2: hipLaunchKernelGGL((lrn_fast_kernel<T, 2, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
-            case 4: hipLaunchKernelGGL((lrn_fast_kernel<T, 4, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
-            case 8: hipLaunchKernelGGL((lrn_fast_kernel<T, 8, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
-            case 16: hipLaunchKernelGGL((lrn_fast_kernel<T, 16, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
-            default: hipLaunchKernelGGL((lrn_fast_kernel<T, 32, BWD>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
+            case 1: if (powmode == 1) hipLaunchKernelGGL((lrn_fast_kernel<T, 1, BWD, true>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode);
+                    else hipLaunchKernelGGL((lrn_fast_kernel<T, 1, BWD, false>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
+            case 2: if (powmode == 1) hipLaunchKernelGGL((lrn_fast_kernel<T, 2, BWD, true>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode);
+                    else hipLaunchKernelGGL((lrn_fast_kernel<T, 2, BWD, false>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
+            case 4: if (powmode == 1) hipLaunchKernelGGL((lrn_fast_kernel<T, 4, BWD, true>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode);
+                    else hipLaunchKernelGGL((lrn_fast_kernel<T, 4, BWD, false>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
+            case 8: if (powmode == 1) hipLaunchKernelGGL((lrn_fast_kernel<T, 8, BWD, true>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode);
+                    else hipLaunchKernelGGL((lrn_fast_kernel<T, 8, BWD, false>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
+            case 16: if (powmode == 1) hipLaunchKernelGGL((lrn_fast_kernel<T, 16, BWD, true>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode);
+                    else hipLaunchKernelGGL((lrn_fast_kernel<T, 16, BWD, false>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
+            default: if (powmode == 1) hipLaunchKernelGGL((lrn_fast_kernel<T, 32, BWD, true>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode);
+                     else hipLaunchKernelGGL((lrn_fast_kernel<T, 32, BWD, false>), dim3(grid), dim3(kThreads), 0, s, ap, gp, op, npix, aon, beta, k, powmode); break;
         }
     } else {
         hipLaunchKernelGGL((lrn_generic_kernel<T, BWD>), dim3(grid_for(npix)), dim3(kThreads), 0, s, ap, gp, op, npix, C, Cs, n, aon, beta, k, b075);
