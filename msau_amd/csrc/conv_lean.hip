@@ -50,12 +50,16 @@ struct LeanCfg {
 // STRIDE = 2: the data gradient of a transposed conv (each output pixel gathers input pixels 2y + k - pad).
 // UPS = 2: the transposed conv itself as a conv over the zero-stuffed input: the LDS tile is the virtual image, only
 // its even/even positions are loaded (the MFMAs run over the zeros; the launch is bound by its 4x larger output).
+// EOP: the epilogue-OPERAND bits of the flags (ADD, ACCUM, MASK_A, MASK_B) as a compile-time constant, or -1 = read them at
+// run time.  The 8- and 16-channel instances are instruction-bound; with the unused operand paths compiled out a plain
+// 8 -> 8 3x3 launch takes 11.1 instead of 12.2 us (tools/small_bench.py).  RELU_IN / RELU_OUT stay run-time flags.
+constexpr int kOperandBits = MSAU_CONV_ADD | MSAU_CONV_ACCUM | MSAU_CONV_MASK_A | MSAU_CONV_MASK_B;
 // EPI: extra output compiled in -- 0 none, 1 LocalResponseNorm (MSAU_CONV_LRN), 2 max pool (MSAU_CONV_POOL).  Compile-time,
 // not a run-time flag: with the epilogue code merely PRESENT every plain launch of the instance ran 1.3-4 us slower
 // (8 -> 8 3x3: 12.8 -> 15.8 us, tools/small_bench.py), which ate most of what the fusion saved.
 enum { EPI_NONE = 0, EPI_LRN = 1, EPI_POOL = 2, EPI_HEAD = 3 };
 template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false, bool SPLIT = false,
-          int STRIDE = 1, int UPS = 1, int EPI = EPI_NONE>
+          int STRIDE = 1, int UPS = 1, int EPI = EPI_NONE, int EOP = -1>
 __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) {
     static_assert(!SPLIT || (CT == 1 && !DUAL && !DOUT && WGW == 1), "SPLIT instances are single-source, one tile per workgroup");
     static_assert((STRIDE == 1 && UPS == 1) || (!DUAL && !DOUT && WGW == 1 && DIL == 1 && STRIDE * UPS == 2), "strided / upsampling instances");
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
     }
     const unsigned char* pixp = smem + ((wave * 4) * STRIDE * TI + (cwt * 16 + lr) * STRIDE) * PS;
 
-    const int flags = d.flags;
+    const int flags = EOP >= 0 ? ((d.flags & ~kOperandBits) | EOP) : d.flags;
     const int Cout = d.Cout;
     f32x4 bv[CT];
 #pragma unroll
@@ -452,8 +456,8 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
 }
 
 template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false, bool SPLIT = false,
-          int STRIDE = 1, int UPS = 1, int EPI = EPI_NONE>
-int launch_lean(hipStream_t s, const LeanArgs& a0) {
+          int STRIDE = 1, int UPS = 1, int EPI = EPI_NONE, int EOP = -1>
+int launch_lean_e(hipStream_t s, const LeanArgs& a0) {
     using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL, WGW, STRIDE>;
     if (Cfg::LDS + 256 > MSAU_LDS_LIMIT) return 0;          // does not fit: the generic kernel takes the launch
     LeanArgs a = a0;
@@ -462,7 +466,7 @@ int launch_lean(hipStream_t s, const LeanArgs& a0) {
     a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS > 60 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT, STRIDE, UPS, EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT, STRIDE, UPS, EPI, EOP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_lean: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -477,9 +481,26 @@ int launch_lean(hipStream_t s, const LeanArgs& a0) {
         grid &= ~7;
         a.per_xcd = cdiv(a.ntiles, 8);
     }
-    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT, STRIDE, UPS, EPI>), dim3(grid, SPLIT ? a.ct_total : 1), dim3(256 * WGW), Cfg::LDS, s, a);
+    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT, STRIDE, UPS, EPI, EOP>), dim3(grid, SPLIT ? a.ct_total : 1), dim3(256 * WGW), Cfg::LDS, s, a);
     MSAU_CHECK_LAUNCH("conv_lean_kernel");
     return 1;
+}
+
+// picks the operand-specialised instance for the 8- / 16-channel layers (the combinations the training step launches:
+// none, MASK_B, ACCUM|MASK_B, MASK_A|ADD, ADD); everything else keeps run-time flags
+template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false, bool SPLIT = false,
+          int STRIDE = 1, int UPS = 1, int EPI = EPI_NONE>
+int launch_lean(hipStream_t s, const LeanArgs& a) {
+    if constexpr (CIN8 <= 2 && !DOUT && EPI != EPI_HEAD) {
+        switch (a.d.flags & kOperandBits) {
+#define EOP_CASE(V) case V: return launch_lean_e<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT, STRIDE, UPS, EPI, V>(s, a);
+            EOP_CASE(0) EOP_CASE(MSAU_CONV_MASK_B) EOP_CASE(MSAU_CONV_ACCUM | MSAU_CONV_MASK_B) EOP_CASE(MSAU_CONV_MASK_A | MSAU_CONV_ADD)
+            EOP_CASE(MSAU_CONV_ADD)
+#undef EOP_CASE
+            default: break;
+        }
+    }
+    return launch_lean_e<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT, STRIDE, UPS, EPI, -1>(s, a);
 }
 
 template <typename T, int CIN8, int KS, bool DUAL>
