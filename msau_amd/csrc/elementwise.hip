@@ -368,33 +368,33 @@ __global__ void pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint
     }
 }
 
+// One image row per blockIdx.y (+ 65535 * blockIdx.z), threads along (x, channel group): no 64-bit divisions (the flat-index
+// form spent ~300 of its ~400 instructions per item on three of them).
 template <typename T>
-__global__ void pool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx,
-                                const T* __restrict__ mask, int B, int H, int W, int Ho, int Wo, int Cs, int accumulate) {
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx,
+                                                       const T* __restrict__ mask, int rows, int H, int W, int Ho, int Wo, int Cs, int accumulate) {
     const int cgs = Cs >> 3;
-    const int64_t total = (int64_t)B * H * W * cgs;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int cg = (int)(i % cgs);
-        int64_t p = i / cgs;
-        int ix = (int)(p % W); p /= W;
-        int iy = (int)(p % H);
-        int b = (int)(p / H);
-        const int pos = ((iy & 1) << 1) | (ix & 1);
-        const int64_t o = ((((int64_t)b * Ho + (iy >> 1)) * Wo + (ix >> 1)) * cgs + cg) * 8;
-        typename Vec8<T>::type g = load8<T>(dy + o);
-        uint64_t packed = *reinterpret_cast<const uint64_t*>(idx + o);
-        typename Vec8<T>::type old = accumulate ? load8<T>(dx + i * 8) : zero8<T>();
-        typename Vec8<T>::type m;
-        if (mask) m = load8<T>(mask + i * 8);
-        typename Vec8<T>::type r;
+    const int row = blockIdx.y + 65535 * blockIdx.z;                 // b * H + iy
+    const int t = blockIdx.x * 256 + threadIdx.x;                    // ix * cgs + cg
+    if (row >= rows || t >= W * cgs) return;
+    const int b = row / H, iy = row - b * H;
+    const int ix = t / cgs, cg = t - ix * cgs;
+    const int pos = ((iy & 1) << 1) | (ix & 1);
+    const int64_t i = (int64_t)row * W * cgs + t;
+    const int64_t o = ((((int64_t)b * Ho + (iy >> 1)) * Wo + (ix >> 1)) * cgs + cg) * 8;
+    typename Vec8<T>::type g = load8<T>(dy + o);
+    uint64_t packed = *reinterpret_cast<const uint64_t*>(idx + o);
+    typename Vec8<T>::type old = accumulate ? load8<T>(dx + i * 8) : zero8<T>();
+    typename Vec8<T>::type m;
+    if (mask) m = load8<T>(mask + i * 8);
+    typename Vec8<T>::type r;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = (float)old[j] + ((int)((packed >> (8 * j)) & 0xff) == pos ? (float)g[j] : 0.f);
-            if (mask && !((float)m[j] > 0.f)) v = 0.f;
-            r[j] = (T)v;
-        }
-        store8<T>(dx + i * 8, r);
+    for (int j = 0; j < 8; ++j) {
+        float v = (float)old[j] + ((int)((packed >> (8 * j)) & 0xff) == pos ? (float)g[j] : 0.f);
+        if (mask && !((float)m[j] > 0.f)) v = 0.f;
+        r[j] = (T)v;
     }
+    store8<T>(dx + i * 8, r);
 }
 
 // =============================================================================================
@@ -832,10 +832,12 @@ extern "C" int msau_maxpool2x2_bwd(void* stream, int dtype, const void* dy, cons
     MSAU_CHECK_ARG(dy && dx && idx && B > 0 && H > 0 && W > 0 && Cs % 8 == 0, "maxpool_bwd: bad args");
     hipStream_t s = static_cast<hipStream_t>(stream);
     int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    int grid = grid_for((int64_t)B * H * W * (Cs / 8));
+    MSAU_CHECK_ARG((int64_t)B * H < 65535ll * 65535ll && (int64_t)W * (Cs / 8) < (1ll << 30), "maxpool_bwd: image too large");
+    const int rows = B * H;
+    const dim3 grid(cdiv(W * (Cs / 8), 256), rows < 65535 ? rows : 65535, cdiv(rows, 65535));
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(pool_bwd_kernel<float>, dim3(grid), dim3(kThreads), 0, s, static_cast<const float*>(dy), idx, static_cast<float*>(dx), static_cast<const float*>(mask), B, H, W, Ho, Wo, Cs, accumulate),
-               hipLaunchKernelGGL(pool_bwd_kernel<bf16_t>, dim3(grid), dim3(kThreads), 0, s, static_cast<const bf16_t*>(dy), idx, static_cast<bf16_t*>(dx), static_cast<const bf16_t*>(mask), B, H, W, Ho, Wo, Cs, accumulate));
+               hipLaunchKernelGGL(pool_bwd_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(dy), idx, static_cast<float*>(dx), static_cast<const float*>(mask), rows, H, W, Ho, Wo, Cs, accumulate),
+               hipLaunchKernelGGL(pool_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, static_cast<const bf16_t*>(dy), idx, static_cast<bf16_t*>(dx), static_cast<const bf16_t*>(mask), rows, H, W, Ho, Wo, Cs, accumulate));
     MSAU_CHECK_LAUNCH("pool_bwd");
     return 0;
 }
