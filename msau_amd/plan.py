@@ -519,6 +519,11 @@ class PairOp:
         if not L.load().msau_conv_pair_applicable(P.dtype, C.byref(f)):
             return
         pool = getattr(c2, "pool", None)
+        if pool is not None and x0.Cs < int(os.environ.get("MSAU_PAIR_POOL_MINC", "16")):
+            # measured: at 8 channels the pooled-output variant of the pair launch (97 VGPRs, 4 waves per SIMD instead of 6)
+            # costs 12 us for a 10.8 us pool launch; at 16 channels 3.3 us for 8.6 us
+            pool.fused_into = None
+            pool = None
         if pool is not None:                 # the pooled output rides on the fused launch (c2's own descriptor is not launched)
             f.flags2 |= L.CONV_POOL
             f.pool_y, f.pool_idx = _ptr(pool.y.data), _ptr(pool.idx)

@@ -93,6 +93,7 @@ def test_pool_in_the_residual_pair_epilogue_is_bit_exact(monkeypatch, dtype, C8,
         took.append((PoolOp(plan, "p", out, q), plan))
         plan.logits = q
     out = {}
+    monkeypatch.setenv("MSAU_PAIR_POOL_MINC", "8")          # the 8-channel pooled pair instance is off by default (slower than the pool launch)
     for mode in ("1", "0"):
         monkeypatch.setenv("MSAU_FUSE_POOL", mode)
         out[mode] = run_graph(build, p, x, gy, dtype)

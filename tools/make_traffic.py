@@ -60,8 +60,8 @@ def main():
     res = passes("pair", ["python3", os.path.join(ROOT, "tools", "pair_bench.py"), "3", "8"])
     names = [n for n in res["FETCH_SIZE"] if "conv_pair_kernel" in n]
     assert len(names) == 2, names
-    fwd = entry(res, names[0], "conv_pair forward (x0 -> r1, out), B=16 336x256 C=8", 3 * n8)
-    bwd = entry(res, names[1], "conv_pair data gradient (g -> g_r1, g_x0), B=16 336x256 C=8", 5 * n8)
+    fwd = entry(res, names[0], "conv_pair forward (x0 -> r1, out, two mask bit planes), B=16 336x256 C=8", 3 * n8 + 2 * (n8 // 16))
+    bwd = entry(res, names[1], "conv_pair data gradient (g + two mask bit planes -> g_r1, g_x0), B=16 336x256 C=8", 3 * n8 + 2 * (n8 // 16))
     both = {"launch": "mean of the forward and the data-gradient launch (12 each per step), B=16 336x256 C=8",
             "mangled": names[0] + " | " + names[1],
             "hbm_bytes_per_launch": (fwd["hbm_bytes_per_launch"] + bwd["hbm_bytes_per_launch"]) // 2,

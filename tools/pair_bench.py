@@ -59,9 +59,14 @@ for (H, W, Cc) in ((336, 256, 8), (168, 128, 16)):
         d.mask_b = mask_b.data_ptr() if mask_b is not None else None
         return d
 
+    bits_mid = torch.zeros(B, H, W, Cc // 8, dtype=torch.uint8, device=dev)     # ReLU masks as bit planes, as the plan runs it
+    bits_a = torch.zeros_like(bits_mid)
+
     def pair_desc(fwd):
         p = L.ConvPairDesc()
         p.B, p.H, p.W, p.C = B, H, W, Cc
+        if os.environ.get("MSAU_PAIR_BITS", "1") != "0":
+            p.bits_mid, p.bits_a = bits_mid.data_ptr(), bits_a.data_ptr()
         if fwd:
             p.flags1, p.flags2 = L.PAIR_RELU_IN | L.PAIR_RELU_MID, L.CONV_ADD | L.CONV_RELU_OUT
             p.x, p.w1, p.b1, p.mid = x.data_ptr(), w1.data_ptr(), b1.data_ptr(), r1.data_ptr()
