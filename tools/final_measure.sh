@@ -6,12 +6,13 @@ set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02
 mkdir -p "$O" && cd "$R" || exit 1
 python -m pytest tests -m gpu -q > "$O/tests.log" 2>&1; echo "pytest rc=$?" | tee -a "$O/tests.log"; tail -3 "$O/tests.log"
+# PMC traffic first (it stamps profiles/r02_traffic.json with this tree's kernel hash), then the bench line that reads it
+python tools/make_traffic.py > "$O/traffic.log" 2>&1 || { tail -5 "$O/traffic.log"; exit 1; }
 python bench.py --dump-kernels "$O/r02_final_hip_events.csv" > "$O/r02_final_bench.json" 2> "$O/bench.err" || { tail -5 "$O/bench.err"; exit 1; }
 cut -c1-400 "$O/r02_final_bench.json"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -o r02 -- python3 "$R/bench.py" --no-secondary --no-cpu-baseline --steps 60 --warmup 10 > "$O/prof.log" 2>&1 || { tail -5 "$O/prof.log"; exit 1; }
 MSAU_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_serial" -o r02s -- python3 "$R/bench.py" --no-secondary --no-cpu-baseline --no-roofline --steps 30 --warmup 10 > "$O/prof_serial.log" 2>&1 || { tail -5 "$O/prof_serial.log"; exit 1; }
 find "$O/prof" "$O/prof_serial" -name "*kernel_trace.csv" -delete        # large; the stats are what is kept
-cd "$R" && python tools/make_traffic.py > "$O/traffic.log" 2>&1 || { tail -5 "$O/traffic.log"; exit 1; }
-python bench.py --no-secondary --no-cpu-baseline > "$O/r02_final_bench_with_traffic.json" 2>> "$O/bench.err"
+cd "$R"
 ls -R "$O" | head -40
