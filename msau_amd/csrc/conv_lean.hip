@@ -53,7 +53,7 @@ struct LeanCfg {
 // EOP: the epilogue-OPERAND bits of the flags (ADD, ACCUM, MASK_A, MASK_B) as a compile-time constant, or -1 = read them at
 // run time.  The 8- and 16-channel instances are instruction-bound; with the unused operand paths compiled out a plain
 // 8 -> 8 3x3 launch takes 11.1 instead of 12.2 us (tools/small_bench.py).  RELU_IN / RELU_OUT stay run-time flags.
-constexpr int kOperandBits = MSAU_CONV_ADD | MSAU_CONV_ACCUM | MSAU_CONV_MASK_A | MSAU_CONV_MASK_B;
+constexpr int kOperandBits = MSAU_CONV_RELU_IN | MSAU_CONV_RELU_OUT | MSAU_CONV_ADD | MSAU_CONV_ACCUM | MSAU_CONV_MASK_A | MSAU_CONV_MASK_B;
 // EPI: extra output compiled in -- 0 none, 1 LocalResponseNorm (MSAU_CONV_LRN), 2 max pool (MSAU_CONV_POOL).  Compile-time,
 // not a run-time flag: with the epilogue code merely PRESENT every plain launch of the instance ran 1.3-4 us slower
 // (8 -> 8 3x3: 12.8 -> 15.8 us, tools/small_bench.py), which ate most of what the fusion saved.
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave = wave_all & 3, cwt = wave_all >> 2;       // 4 row groups x WGW column tiles
     const int lr = lane & 15, lg = lane >> 4;
-    const bool relu_in = d.flags & MSAU_CONV_RELU_IN;
+    const bool relu_in = (EOP >= 0 ? EOP : d.flags) & MSAU_CONV_RELU_IN;
 
     // ---- weights: registers (small) or LDS, once per (persistent) workgroup
     const T* wp = static_cast<const T*>(d.wpack) + (SPLIT ? (size_t)cty * 16 * a.kchunk : 0);     // [row][k], one chunk
@@ -494,8 +494,7 @@ int launch_lean(hipStream_t s, const LeanArgs& a) {
     if constexpr (CIN8 <= 2 && !DOUT && EPI != EPI_HEAD) {
         switch (a.d.flags & kOperandBits) {
 #define EOP_CASE(V) case V: return launch_lean_e<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT, STRIDE, UPS, EPI, V>(s, a);
-            EOP_CASE(0) EOP_CASE(MSAU_CONV_MASK_B) EOP_CASE(MSAU_CONV_ACCUM | MSAU_CONV_MASK_B) EOP_CASE(MSAU_CONV_MASK_A | MSAU_CONV_ADD)
-            EOP_CASE(MSAU_CONV_ADD)
+            EOP_CASE(0) EOP_CASE(2) EOP_CASE(3) EOP_CASE(6) EOP_CASE(8) EOP_CASE(12) EOP_CASE(20) EOP_CASE(32) EOP_CASE(40)
 #undef EOP_CASE
             default: break;
         }
