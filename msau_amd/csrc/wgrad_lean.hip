@@ -192,8 +192,11 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanMulti m) {
 #pragma unroll
                 for (int i = 0; i < NKT; ++i) {
                     const int e = coloff[i];
-                    const int o0 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + e;
-                    const int o1 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + 4 * STRIDE * PSX + e;
+                    // only the k-tile that holds the ones / padding columns can carry an absolute offset: after unrolling
+                    // the test is a constant and the selects vanish from the other tiles
+                    const bool abs_ok = (i + 1) * 16 > Cfg::KREAL;
+                    const int o0 = (abs_ok && (e & WL_ABS)) ? (e & ~WL_ABS) : pb0 + e;
+                    const int o1 = (abs_ok && (e & WL_ABS)) ? (e & ~WL_ABS) : pb0 + 4 * STRIDE * PSX + e;
                     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o0));
                     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o1));
                     bf16x8 bfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -428,8 +431,9 @@ __global__ __launch_bounds__(256) void wgrad_in64_kernel(const WLeanArgs a) {
 #pragma unroll
             for (int nt = 0; nt < 5; ++nt) {
                 const int e = goff[nt];
-                const int o0 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + e;
-                const int o1 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + 4 * PSG + e;
+                const bool abs_ok = nt == 4;                           // only the last column tile holds the missing tenth tap
+                const int o0 = (abs_ok && (e & WL_ABS)) ? (e & ~WL_ABS) : pb0 + e;
+                const int o1 = (abs_ok && (e & WL_ABS)) ? (e & ~WL_ABS) : pb0 + 4 * PSG + e;
                 bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o0));
                 bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o1));
                 bf16x8 bfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
