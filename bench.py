@@ -256,7 +256,7 @@ def secondary_measurements(args, L, MSAUWrapper, TrainEngine, dev, n_class):
     run("cfg5: model_box variant 512x384x64, 3-stage (BASELINE configs[4]; BoxConv2d is third-party: self-consistent only)", 64, 3,
         "bf16", args.batch, box=True, hw=(512, 384))
     if hasattr(TrainEngine, "step_ids"):
-        run("cfg2 fed with character-id masks (one-hot input painted on the device: no fp32 NCHW tensor, no conversion pass; the first conv still runs dense; SURVEY 8f N1) -- NOT the headline input", args.channels,
+        run("cfg2 fed with character-id masks (the first conv and its weight gradient read the id mask and synthesise the one-hot tile in LDS: no dense input tensor at all; SURVEY 8f N1) -- NOT the headline input", args.channels,
             args.stages, "bf16", args.batch, feed="ids")
     return out
 

@@ -82,6 +82,10 @@ enum {
                                    [B][ceil(Hout/2)][ceil(Wout/2)][Cout], and, when pool_idx is not NULL, the position
                                    0..3 (= 2*dy + dx) of the first maximum per element (what msau_maxpool2x2_bwd reads);
                                    info[7] & 8 when the launch can take it (otherwise run msau_maxpool2x2_fwd on y). */
+    MSAU_CONV_IDS      = 1024,  /* x1 is an int32 id mask [B][Hin][Win] instead of a tensor: input channel c of a pixel is
+                                   (id == c), ids outside [0, C1) are empty pixels -- the one-hot chargrid is synthesised in
+                                   LDS, never painted nor read, and the result equals the dense launch bit for bit.  C1 = 64,
+                                   3x3, <= 16 output channels; info[7] & 16.  msau_conv2d_wgrad takes the same flag. */
     MSAU_CONV_HEAD     = 64     /* inference head (kv_model.py:305-313): besides y, write softmax over the Cout real
                                    channels of the (storage-rounded) result to head_probs (fp32 [B][Hout][Wout][Cout],
                                    dense) and the index of its first maximum to head_argmax (uint8 [B][Hout][Wout]).
@@ -138,7 +142,7 @@ int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d);
  * info[2] = dynamic LDS bytes, info[3] = workgroups, info[4] = channel chunk, info[5] = chunks,
  * info[6] = 1 if a compile-time-specialised "lean" instance (conv_lean.hip) takes the launch,
  * info[7] = bit 0: that instance implements MSAU_CONV_HEAD for this descriptor, bit 1: MSAU_CONV_DOUT,
- *           bit 2: MSAU_CONV_LRN, bit 3: MSAU_CONV_POOL */
+ *           bit 2: MSAU_CONV_LRN, bit 3: MSAU_CONV_POOL, bit 4: MSAU_CONV_IDS */
 int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info8);
 
 /* ------------------------------------------------------------------------------------------
@@ -189,7 +193,7 @@ typedef struct {
     int32_t B, Hin, Win, Hout, Wout;
     int32_t C1, C2, Cout;
     int32_t KH, KW, dil, pad_t, pad_l, stride;
-    int32_t flags;              /* MSAU_CONV_RELU_IN only                                           */
+    int32_t flags;              /* MSAU_CONV_RELU_IN; MSAU_CONV_IDS (x1 = int32 id mask, C1 = 64, Cout = 8, 3x3) */
     const void* x1;
     const void* x2;
     const void* g;              /* [B][Hout][Wout][Cout] gradient w.r.t. the conv's pre-activation  */

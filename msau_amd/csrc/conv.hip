@@ -314,6 +314,7 @@ int msau_conv_lean_head_capable(int dtype, const msau_conv_desc* d, int nchunks,
 int msau_conv_lean_dout_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT);
 int msau_conv_lean_lrn_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT);
 int msau_conv_lean_pool_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT);
+int msau_conv_lean_ids_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT);
 
 extern "C" int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info) {
     MSAU_CHECK_ARG(d && info, "conv2d_launch_info: null pointer");
@@ -323,7 +324,8 @@ extern "C" int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32
     info[0] = g.CT; info[1] = PT; info[2] = t.total; info[3] = (int32_t)nb; info[4] = g.cch; info[5] = g.nchunks;
     info[6] = msau_conv_lean_applicable(dtype, d, g.nchunks, g.CT);
     info[7] = msau_conv_lean_head_capable(dtype, d, g.nchunks, g.CT) | (msau_conv_lean_dout_capable(dtype, d, g.nchunks, g.CT) << 1) |
-              (msau_conv_lean_lrn_capable(dtype, d, g.nchunks, g.CT) << 2) | (msau_conv_lean_pool_capable(dtype, d, g.nchunks, g.CT) << 3);
+              (msau_conv_lean_lrn_capable(dtype, d, g.nchunks, g.CT) << 2) | (msau_conv_lean_pool_capable(dtype, d, g.nchunks, g.CT) << 3) |
+              (msau_conv_lean_ids_capable(dtype, d, g.nchunks, g.CT) << 4);
     return 0;
 }
 
@@ -373,6 +375,11 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
         if (!msau_conv_lean_lrn_capable(dtype, d, g.nchunks, g.CT))
             return msau_set_error(MSAU_ERR_ARG, "conv2d: MSAU_CONV_LRN is not implemented for this launch (see "
                                   "msau_conv2d_launch_info info[7]); run msau_lrn_fwd on y instead");
+    }
+    if (d->flags & MSAU_CONV_IDS) {
+        if (!msau_conv_lean_ids_capable(dtype, d, g.nchunks, g.CT))
+            return msau_set_error(MSAU_ERR_ARG, "conv2d: MSAU_CONV_IDS is not implemented for this launch (see msau_conv2d_launch_info "
+                                  "info[7] & 16); paint the one-hot input with msau_onehot_ids instead");
     }
     if (d->flags & MSAU_CONV_POOL) {
         MSAU_CHECK_ARG(d->pool_y && !(d->flags & (MSAU_CONV_DOUT | MSAU_CONV_HEAD | MSAU_CONV_LRN)), "conv2d: bad POOL arguments");

@@ -59,8 +59,12 @@ constexpr int kOperandBits = MSAU_CONV_RELU_IN | MSAU_CONV_RELU_OUT | MSAU_CONV_
 // (8 -> 8 3x3: 12.8 -> 15.8 us, tools/small_bench.py), which ate most of what the fusion saved.
 enum { EPI_NONE = 0, EPI_LRN = 1, EPI_POOL = 2, EPI_HEAD = 3 };
 template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false, bool SPLIT = false,
-          int STRIDE = 1, int UPS = 1, int EPI = EPI_NONE, int EOP = -1>
+          int STRIDE = 1, int UPS = 1, int EPI = EPI_NONE, int EOP = -1, bool IDS = false>
 __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) {
+    // IDS (MSAU_CONV_IDS): x1 is an int32 id mask [B][Hin][Win]; input channel c of a pixel is (id == c).  The one-hot tile is
+    // synthesised in LDS -- the dense one-hot tensor is never painted nor read (the net's first conv fed with
+    // character ids), and the MFMA sequence is the dense launch's: bit-identical results.
+    static_assert(!IDS || (!DUAL && STRIDE == 1 && UPS == 1 && !DOUT && !SPLIT), "id-mask input: plain single-source instances");
     static_assert(!SPLIT || (CT == 1 && !DUAL && !DOUT && WGW == 1), "SPLIT instances are single-source, one tile per workgroup");
     static_assert((STRIDE == 1 && UPS == 1) || (!DUAL && !DOUT && WGW == 1 && DIL == 1 && STRIDE * UPS == 2), "strided / upsampling instances");
     const int cty = SPLIT ? (int)blockIdx.y : 0;                 // this workgroup's channel tile
@@ -126,8 +130,10 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
     constexpr int NITEMS = Cfg::NPIX * C8S;
     constexpr int NIT = (NITEMS + NT - 1) / NT;
     constexpr int NSRC = DUAL ? 2 : 1;
-    constexpr bool PIPE = NIT * NSRC <= 6;
-    V8 pre[NSRC][NIT];
+    constexpr bool PIPE = IDS || NIT * NSRC <= 6;
+    V8 pre[IDS ? 1 : NSRC][IDS ? 1 : NIT];
+    constexpr int NIDS = (Cfg::NPIX + NT - 1) / NT;            // id-mask input: tile pixels per thread
+    int pre_id[IDS ? NIDS : 1];
     auto decode = [&](int tile, int& b, int& oy0, int& ox0) {
         const int t1 = a.tiles_x > 1 ? __umulhi((unsigned)tile, a.mag_tx) : tile;
         ox0 = (tile - t1 * a.tiles_x) * (16 * WGW);
@@ -138,6 +144,17 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
         int b, oy0, ox0;
         decode(tile, b, oy0, ox0);
         const int vy0 = oy0 * STRIDE - d.pad_t, vx0 = ox0 * STRIDE - d.pad_l;    // forward: SAME pad; data gradient: (k-1) - pad
+        if constexpr (IDS) {
+            const int* ids = static_cast<const int*>(d.x1) + (long long)b * d.Hin * d.Win;
+#pragma unroll
+            for (int it = 0; it < NIDS; ++it) {
+                const int pix = tid + it * NT;
+                const int iy = pix / TI, ix = pix - iy * TI;
+                const int vy = vy0 + iy, vx = vx0 + ix;
+                pre_id[it] = -1;
+                if (pix < Cfg::NPIX && (unsigned)vy < (unsigned)d.Hin && (unsigned)vx < (unsigned)d.Win) pre_id[it] = ids[vy * d.Win + vx];
+            }
+        } else
 #pragma unroll
         for (int sidx = 0; sidx < NSRC; ++sidx) {
             const char* base = static_cast<const char*>(sidx ? d.x2 : d.x1) + (long long)b * d.Hin * (sidx ? a.in_row2 : a.in_row1);
@@ -164,6 +181,22 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
         }
     };
     auto write_lds = [&]() {
+        if constexpr (IDS) {
+#pragma unroll
+            for (int it = 0; it < NIDS; ++it) {
+                const int pix = tid + it * NT;
+                if (pix < Cfg::NPIX) {
+                    const int id = pre_id[it];
+#pragma unroll
+                    for (int cg = 0; cg < C8S; ++cg) {
+                        V8 v;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = (T)(cg * 8 + j == id ? 1.0f : 0.0f);
+                        *reinterpret_cast<V8*>(smem + pix * PS + cg * 8 * ESZ) = v;
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int sidx = 0; sidx < NSRC; ++sidx)
 #pragma unroll
@@ -456,7 +489,7 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
 }
 
 template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false, bool SPLIT = false,
-          int STRIDE = 1, int UPS = 1, int EPI = EPI_NONE, int EOP = -1>
+          int STRIDE = 1, int UPS = 1, int EPI = EPI_NONE, int EOP = -1, bool IDS = false>
 int launch_lean_e(hipStream_t s, const LeanArgs& a0) {
     using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL, WGW, STRIDE>;
     if (Cfg::LDS + 256 > MSAU_LDS_LIMIT) return 0;          // does not fit: the generic kernel takes the launch
@@ -466,7 +499,7 @@ int launch_lean_e(hipStream_t s, const LeanArgs& a0) {
     a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS > 60 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT, STRIDE, UPS, EPI, EOP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT, STRIDE, UPS, EPI, EOP, IDS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_lean: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -481,7 +514,7 @@ int launch_lean_e(hipStream_t s, const LeanArgs& a0) {
         grid &= ~7;
         a.per_xcd = cdiv(a.ntiles, 8);
     }
-    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT, STRIDE, UPS, EPI, EOP>), dim3(grid, SPLIT ? a.ct_total : 1), dim3(256 * WGW), Cfg::LDS, s, a);
+    hipLaunchKernelGGL((conv_lean_kernel<T, CIN8, CT, KS, DUAL, DIL, WGW, DOUT, SPLIT, STRIDE, UPS, EPI, EOP, IDS>), dim3(grid, SPLIT ? a.ct_total : 1), dim3(256 * WGW), Cfg::LDS, s, a);
     MSAU_CHECK_LAUNCH("conv_lean_kernel");
     return 1;
 }
@@ -710,6 +743,14 @@ int lean_split(hipStream_t s, const LeanArgs& a, int cin8, int KS) {
 }
 
 // 1 if the lean instance that takes this launch implements MSAU_CONV_HEAD (the 4x4 end conv, one 16-row tile)
+// id-mask input (MSAU_CONV_IDS): 64 one-hot channels -> one 16-row tile, 3x3, no other source / epilogue operand
+int msau_conv_lean_ids_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
+    msau_conv_desc e = *d;
+    e.flags &= ~MSAU_CONV_IDS;
+    return msau_conv_lean_applicable(dtype, &e, nchunks, CT) && d->C1 == 64 && d->C2 == 0 && CT == 1 && d->KH == 3 && d->dil == 1 &&
+           d->stride == 1 && d->ups == 1 && !(d->flags & ~(MSAU_CONV_IDS | MSAU_CONV_RELU_OUT));
+}
+
 int msau_conv_lean_head_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
     return msau_conv_lean_applicable(dtype, d, nchunks, CT) && d->KH == 4 && CT == 1 && d->dil == 1;
 }
@@ -734,6 +775,11 @@ int msau_conv_lean_try(hipStream_t s, int dtype, const msau_conv_desc* d, int kc
     a.ct_total = CT;
     if (d->stride * d->ups == 2)
         return dtype == MSAU_F32 ? lean_strided<float>(s, a, cin8, CT, d->ups == 2) : lean_strided<bf16_t>(s, a, cin8, CT, d->ups == 2);
+    if (d->flags & MSAU_CONV_IDS) {                              // id-mask input: the 64 -> 8/16 3x3 first conv (ids_capable)
+        if (!msau_conv_lean_ids_capable(dtype, d, nchunks, CT)) return 0;
+        return dtype == MSAU_F32 ? launch_lean_e<float, 8, 1, 3, false, 1, 1, false, false, 1, 1, EPI_NONE, -1, true>(s, a)
+                                 : launch_lean_e<bf16_t, 8, 1, 3, false, 1, 1, false, false, 1, 1, EPI_NONE, -1, true>(s, a);
+    }
     if (d->flags & MSAU_CONV_HEAD) {                             // forward-only: the 8-channel 4x4 end conv (head_capable)
         if (!msau_conv_lean_head_capable(dtype, d, nchunks, CT)) return 0;
         return dtype == MSAU_F32 ? launch_lean<float, 1, 1, 4, false, 1, 1, false, false, 1, 1, EPI_HEAD>(s, a)

@@ -328,6 +328,7 @@ extern "C" int msau_conv2d_wgrad(void* stream, int dtype, const msau_wgrad_desc*
         rc = msau_wgrad_lean_try(static_cast<hipStream_t>(stream), dtype, d, g.cch, g.nchunks, g.kextc);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
+    MSAU_CHECK_ARG(!(d->flags & MSAU_CONV_IDS), "wgrad: MSAU_CONV_IDS is implemented by the bf16 64 -> 8 3x3 instance only");
     // CTN as instantiated (3 -> 4)
     int CTN = g.CTN == 3 ? 4 : (g.CTN > 4 ? 8 : g.CTN);
     MSAU_CHECK_ARG(!(CTN == 8 && g.NKW > 5), "wgrad: Cout %d with K %d unsupported", d->Cout, g.kextc);

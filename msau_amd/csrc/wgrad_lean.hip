@@ -317,6 +317,8 @@ struct WIn64 {
     static constexpr int LDS = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
 };
 
+// IDS (MSAU_CONV_IDS): d.x1 is the int32 id mask; the one-hot input tile is synthesised in LDS (bit-identical to the dense launch)
+template <bool IDS>
 __global__ __launch_bounds__(256) void wgrad_in64_kernel(const WLeanArgs a) {
     typedef bf16_t T;
     typedef Vec8<T>::type V8;
@@ -359,7 +361,8 @@ __global__ __launch_bounds__(256) void wgrad_in64_kernel(const WLeanArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) bsum[it][j] = 0.f;
 
-    V8 xr[8], gr[2];
+    V8 xr[IDS ? 1 : 8], gr[2];
+    int idr = -1;                                                  // IDS: this thread's pixel of the 16 x 16 input tile
     auto issue_loads = [&](int tile) {
         const int t1 = a.tiles_x > 1 ? __umulhi((unsigned)tile, a.mag_tx) : tile;
         const int txi = tile - t1 * a.tiles_x;
@@ -367,6 +370,11 @@ __global__ __launch_bounds__(256) void wgrad_in64_kernel(const WLeanArgs a) {
         const int tyi = t1 - b * a.tiles_y;
         const int iy0 = tyi * 16, ix0 = txi * 16;
         const char* xb = xsrc + (long long)b * d.Hin * in_row + cb;
+        if constexpr (IDS) {
+            const int iy = iy0 + (tid >> 4), ix = ix0 + (tid & 15);
+            idr = -1;
+            if (iy < d.Hin && ix < d.Win) idr = static_cast<const int*>(d.x1)[((long long)b * d.Hin + iy) * d.Win + ix];
+        } else
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int idx = tid + it * 256;
@@ -391,6 +399,15 @@ __global__ __launch_bounds__(256) void wgrad_in64_kernel(const WLeanArgs a) {
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         __syncthreads();
+        if constexpr (IDS) {
+#pragma unroll
+            for (int cg = 0; cg < 8; ++cg) {
+                V8 v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (T)(cg * 8 + j == idr ? 1.0f : 0.0f);
+                *reinterpret_cast<V8*>(lds_x + tid * PSX + cg * 16) = v;
+            }
+        } else
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int idx = tid + it * 256;
@@ -487,7 +504,11 @@ __global__ __launch_bounds__(256) void wgrad_in64_kernel(const WLeanArgs a) {
 
 int launch_wgrad_in64(hipStream_t s, const WLeanArgs& a) {
     if (a.kextc != 592) return 0;
-    hipLaunchKernelGGL(wgrad_in64_kernel, dim3(a.d.nslabs, a.nchunks), dim3(256), WIn64::LDS, s, a);
+    if (a.d.flags & MSAU_CONV_IDS) {
+        if (a.nchunks != 1 || a.d.C2) return msau_set_error(MSAU_ERR_ARG, "wgrad: MSAU_CONV_IDS needs one 64-channel one-hot source");
+        hipLaunchKernelGGL(wgrad_in64_kernel<true>, dim3(a.d.nslabs, 1), dim3(256), WIn64::LDS, s, a);
+    } else
+    hipLaunchKernelGGL(wgrad_in64_kernel<false>, dim3(a.d.nslabs, a.nchunks), dim3(256), WIn64::LDS, s, a);
     MSAU_CHECK_LAUNCH("wgrad_in64_kernel");
     return 1;
 }

@@ -1309,6 +1309,43 @@ class Plan:
         a = self.x_in
         L.call("msau_nchw_to_nhwc", self._stream(), self.dtype, x_nchw.data_ptr(), a.data.data_ptr(), self.B, a.C, a.Cs, self.H, self.W)
 
+    def _feed_ids(self, ids: Optional[torch.Tensor]) -> bool:
+        """Switch the net's first conv (and its weight gradient) between the dense input tensor and an id mask
+        (MSAU_CONV_IDS: the one-hot tile is synthesised in LDS, nothing is painted or read; same bits as the dense launch).
+        Returns True when the id mask feeds the conv directly; False = paint the dense one-hot input (`load_ids`).  The
+        descriptors are launched by value, so flipping them between sweeps is safe."""
+        if not hasattr(self, "_ids_conv"):
+            c = next((op for op in self.ops if isinstance(op, ConvOp) and op.x1 is self.x_in and op.x2 is None), None)
+            ok = c is not None and os.environ.get("MSAU_IDS_DIRECT", "1") != "0" and not (c.pair is not None and c.pair.active)
+            if ok:
+                probe = L.ConvDesc.from_buffer_copy(c.fdesc)
+                probe.flags |= L.CONV_IDS
+                info = (L.i32 * 8)()
+                L.call("msau_conv2d_launch_info", self.dtype, C.byref(probe), info)
+                ok = bool(info[7] & 16)
+            if ok and self.training and c.wdesc is not None:        # the id-mask weight gradient is the bf16 64 -> 8 instance
+                ok = self.dtype == L.BF16 and c.wgeom.lean and c.wdesc.C1 == 64 and c.wdesc.Cout == 8 and c.wgeom.nchunks == 1
+            self._ids_conv = c if ok else None
+            self._ids_keep = None
+        c = self._ids_conv
+        if c is None:
+            return False
+        if ids is not None:
+            c.fdesc.flags |= L.CONV_IDS
+            c.fdesc.x1 = ids.data_ptr()
+            if c.wdesc is not None:
+                c.wdesc.flags |= L.CONV_IDS
+                c.wdesc.x1 = ids.data_ptr()
+            self._ids_keep = ids                                    # read again by the backward's weight gradient
+        else:
+            c.fdesc.flags &= ~L.CONV_IDS
+            c.fdesc.x1 = _ptr(self.x_in.data)
+            if c.wdesc is not None:
+                c.wdesc.flags &= ~L.CONV_IDS
+                c.wdesc.x1 = _ptr(self.x_in.data)
+            self._ids_keep = None
+        return True
+
     def load_ids(self, ids: torch.Tensor):
         """Paint the one-hot input from a character-id mask int32 [B,H,W] (to_categorical, generic_util.py:97-98):
         H*W*4 bytes cross PCIe instead of the dense H*W*C float grid."""
@@ -1323,8 +1360,11 @@ class Plan:
         s = self._stream()
         self.pack(flat_params)
         if ids is not None:
-            self.load_ids(ids)
+            assert ids.dtype == torch.int32 and ids.is_contiguous() and tuple(ids.shape) == (self.B, self.H, self.W), (ids.shape, ids.dtype)
+            if not self._feed_ids(ids):
+                self.load_ids(ids)
         else:
+            self._feed_ids(None)
             self.load_input(x_nchw)
         self._run_seq(self._fwd_seq, s)
         if not self.head_fused:
@@ -1339,8 +1379,11 @@ class Plan:
         s = self._stream()
         self.pack(flat_params)
         if ids is not None:
-            self.load_ids(ids)
+            assert ids.dtype == torch.int32 and ids.is_contiguous() and tuple(ids.shape) == (self.B, self.H, self.W), (ids.shape, ids.dtype)
+            if not self._feed_ids(ids):
+                self.load_ids(ids)
         else:
+            self._feed_ids(None)
             self.load_input(x_nchw)
         if L._profiler is None:
             self._run_seq(self._fwd_seq, s)          # one C call enqueues the whole forward sweep

@@ -283,7 +283,8 @@ def test_device_dense_rasteriser_matches_cpu_painter(dtype, tmp_path):
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_training_from_id_masks_equals_dense_one_hot_input(dtype):
-    """TrainEngine.step_ids (N1: only the character-id mask crosses the boundary; the one-hot grid is painted on the device)
+    """TrainEngine.step_ids (N1: only the character-id mask crosses the boundary; the one-hot grid is synthesised in LDS by
+    the first conv and its weight gradient -- bf16 -- or painted on the device -- fp32)
     against TrainEngine.step on the dense float tensor of the same ids: every bit of loss, gradients and updated
     parameters.  Includes ids outside the charset (painted as empty pixels, like unknown characters in the reference's
     `transform_from_charset`, funsd_preprocessing_word_level.py:50-57)."""
@@ -304,6 +305,11 @@ def test_training_from_id_masks_equals_dense_one_hot_input(dtype):
             loss = eng.step(dense.cuda(), lab.cuda()) if feed == "dense" else eng.step_ids(ids.cuda(), lab.cuda())
         torch.cuda.synchronize()
         res.append((float(loss), eng.flat_grad.clone(), m.flat_parameters.clone()))
+        if feed == "ids":
+            # bf16: the first conv and its weight gradient read the id mask directly (MSAU_CONV_IDS, one-hot tile synthesised
+            # in LDS); fp32 storage has no id-mask weight-gradient instance and paints the dense input
+            plan = next(iter(m._plans.values()))
+            assert (plan._ids_conv is not None) == (dtype == "bf16")
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
 
 
