@@ -70,6 +70,14 @@ int conv_geom(int dtype, int C1, int C2, int Cout, int KH, int KW, int dil, int 
         g.ngroups = g.kchunk / 8;
         if (tile_geom(g, 1, KH, KW, dil, stride, ups).total <= 150 * 1024) best = 64;
     }
+    // 32 -> 64 3x3 with dilation 8 (the level-3 entry conv) in bf16: one K chunk as well -- its lean instance
+    // (conv_lean.hip, lean_dil<8>: a 32 x 32 pixel tile, 120 KB of LDS) takes the launch instead of the generic kernel
+    if (!best && g.esz == 2 && C2 == 0 && Cin == 32 && g.CT == 4 && KH == 3 && KW == 3 && dil == 8 && stride == 1 && ups == 1) {
+        g.cch = 32;
+        g.kchunk = roundup(g.taps * 32, 32);
+        g.ngroups = g.kchunk / 8;
+        if (tile_geom(g, 1, KH, KW, dil, stride, ups).total <= 150 * 1024) best = 32;
+    }
     for (int pass = 0; pass < 2 && !best; ++pass) {
         for (int c = (Cin < 128 ? Cin : 128); c >= 8; c -= 8) {
             if (Cin % c) continue;
