@@ -78,6 +78,15 @@ int conv_geom(int dtype, int C1, int C2, int Cout, int KH, int KW, int dil, int 
         g.ngroups = g.kchunk / 8;
         if (tile_geom(g, 1, KH, KW, dil, stride, ups).total <= 150 * 1024) best = 32;
     }
+    // the level-3 -> level-2 transposed conv 64 -> 32 (ups = 2) and its data gradient 32 -> 64 (stride = 2), bf16: one K chunk
+    // too, for the strided / zero-stuffed lean instances (84 / 125 KB of LDS)
+    if (!best && g.esz == 2 && C2 == 0 && KH == 3 && KW == 3 && dil == 1 &&
+        ((Cin == 64 && g.CT == 2 && stride == 1 && ups == 2) || (Cin == 32 && g.CT == 4 && stride == 2 && ups == 1))) {
+        g.cch = Cin;
+        g.kchunk = roundup(g.taps * Cin, 32);
+        g.ngroups = g.kchunk / 8;
+        if (tile_geom(g, 1, KH, KW, dil, stride, ups).total <= 150 * 1024) best = Cin;
+    }
     for (int pass = 0; pass < 2 && !best; ++pass) {
         for (int c = (Cin < 128 ? Cin : 128); c >= 8; c -= 8) {
             if (Cin % c) continue;

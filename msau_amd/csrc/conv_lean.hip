@@ -653,7 +653,7 @@ int msau_conv_lean_applicable(int dtype, const msau_conv_desc* d, int nchunks, i
 // two-output data gradient (MSAU_CONV_DOUT): g [C] -> (dx1 [C], dx2 [C]) with C = CT*8 in {8, 16, 32}
 int msau_conv_lean_dout_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
     if (!msau_conv_lean_applicable(dtype, d, nchunks, CT)) return 0;
-    return d->C2 == 0 && d->dil == 1 && (d->KH == 1 || d->KH == 3) && (CT == 1 || CT == 2 || CT == 4) &&
+    return d->C2 == 0 && d->dil == 1 && d->stride == 1 && d->ups == 1 && (d->KH == 1 || d->KH == 3) && (CT == 1 || CT == 2 || CT == 4) &&
            d->Cout == CT * 16 && d->C1 == CT * 8;
 }
 
