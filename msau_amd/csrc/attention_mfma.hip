@@ -65,31 +65,67 @@ __global__ __launch_bounds__(256) void attn_stats_mfma(const bf16_t* __restrict_
     if (i0 >= N) return;
     bf16x8 afrag = zero8<bf16_t>();                               // A: G rows, k = d (lanes g < DS/8)
     if (lg < DS / 8 && i0 + lr < N) afrag = load8<bf16_t>(g + ((size_t)b * N + i0 + lr) * DS + lg * 8);
+    // Two passes over the columns instead of one online-softmax sweep: the running (m, Z) update is a serial chain of two
+    // exponentials per score tile, and with one or two waves per SIMD nothing hides it (84 tiles x ~450 cycles).  Pass 1
+    // takes the row maximum (MFMA + max only), pass 2 sums exp(s - m) with the final m: twice the (cheap) MFMAs, half the
+    // exponentials, and the tiles of a pass are independent -- four in flight.
     float m[4], Z[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { m[r] = -1e30f; Z[r] = 0.f; }
     const int boff = lg < DS / 8 ? lg * 16 : -1;
-    for (int j0 = 0; j0 < Npad; j0 += 16) {
+    auto score = [&](int j0) {
         bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(smem + (boff < 0 ? zoff : (j0 + lr) * RB + boff));
-        f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        const bool valid = j0 + lr < N;                           // this lane's column
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    };
+    const int Nq = Npad & ~63;                                     // whole groups of four 16-column tiles
+    for (int j0 = 0; j0 < Nq; j0 += 64) {
+        f32x4 s4[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float mn = fmaxf(m[r], s[r]);
-            float zn = Z[r] * __builtin_amdgcn_exp2f((m[r] - mn) * LOG2E) + __builtin_amdgcn_exp2f((s[r] - mn) * LOG2E);
-            if (valid) { m[r] = mn; Z[r] = zn; }
+        for (int t = 0; t < 4; ++t) s4[t] = score(j0 + t * 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool valid = j0 + t * 16 + lr < N;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[r] = valid ? fmaxf(m[r], s4[t][r]) : m[r];
         }
     }
-    // merge the 16 column-lanes of each q (lanes differing in bits 0..3)
+    for (int j0 = Nq; j0 < Npad; j0 += 16) {
+        const f32x4 s = score(j0);
+        const bool valid = j0 + lr < N;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = valid ? fmaxf(m[r], s[r]) : m[r];
+    }
+    // the row maximum over all columns: merge the 16 column-lanes of each row group
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float mo = __shfl_xor(m[r], o, 64), zo = __shfl_xor(Z[r], o, 64);
-            float mn = fmaxf(m[r], mo);
-            Z[r] = Z[r] * __builtin_amdgcn_exp2f((m[r] - mn) * LOG2E) + zo * __builtin_amdgcn_exp2f((mo - mn) * LOG2E);
-            m[r] = mn;
+        for (int r = 0; r < 4; ++r) m[r] = fmaxf(m[r], __shfl_xor(m[r], o, 64));
+    }
+    float ml[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ml[r] = m[r] * LOG2E;
+    for (int j0 = 0; j0 < Nq; j0 += 64) {
+        f32x4 s4[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s4[t] = score(j0 + t * 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool valid = j0 + t * 16 + lr < N;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Z[r] += valid ? __builtin_amdgcn_exp2f(s4[t][r] * LOG2E - ml[r]) : 0.f;
         }
+    }
+    for (int j0 = Nq; j0 < Npad; j0 += 16) {
+        const f32x4 s = score(j0);
+        const bool valid = j0 + lr < N;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Z[r] += valid ? __builtin_amdgcn_exp2f(s[r] * LOG2E - ml[r]) : 0.f;
+    }
+    // sum over the 16 column-lanes
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Z[r] += __shfl_xor(Z[r], o, 64);
     }
     if (lr == 0) {
 #pragma unroll
