@@ -19,7 +19,7 @@
 namespace {
 
 enum { M_O = 0, M_DH = 1, M_DG = 2, M_DF = 3 };
-constexpr int CHUNK = 128;                // sweep rows staged in LDS per barrier phase
+constexpr int CHUNK = 256;                // sweep rows staged in LDS per barrier phase (128: -0.3 %)
 constexpr float LOG2E = 1.4426950408889634f;
 
 typedef __attribute__((address_space(3))) bf16x4* lds_v4;
