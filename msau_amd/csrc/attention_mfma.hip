@@ -21,6 +21,7 @@ namespace {
 enum { M_O = 0, M_DH = 1, M_DG = 2, M_DF = 3 };
 constexpr int CHUNK = 256;                // sweep rows staged in LDS per barrier phase (128: -0.3 %)
 constexpr float LOG2E = 1.4426950408889634f;
+constexpr int kSweepWays = 2;             // waves sharing one group of own positions in the sweeps (see attn_sweep_body)
 
 typedef __attribute__((address_space(3))) bf16x4* lds_v4;
 
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void attn_stats_mfma(const bf16_t* __restrict_
 // ---------------------------------------------------------------------------------------------
 // the four sweep modes
 // ---------------------------------------------------------------------------------------------
-template <int DS, int CS, int MODE>
+template <int DS, int CS, int MODE, int SW>
 __device__ __forceinline__ void attn_sweep_body(const bf16_t* __restrict__ f, const bf16_t* __restrict__ g,
                                                 const bf16_t* __restrict__ h, const bf16_t* __restrict__ xdy,
                                                 const float* __restrict__ stats, float* __restrict__ delta,
@@ -158,7 +159,13 @@ __device__ __forceinline__ void attn_sweep_body(const bf16_t* __restrict__ f, co
     float* st_z = st_m + CHUNK;
     float* st_d = st_z + CHUNK;
 
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // SW waves share a group of 16 own positions and split the swept rows between them (wave w takes the 32-row steps
+    // w/4, w/4 + SW, ...): the sweep is one dependent chain per wave (fragment read -> MFMA -> exp -> MFMA), and with 336
+    // workgroups of four waves a SIMD held one or two of them -- nothing to overlap the chain with.  The SW partial
+    // accumulators meet in LDS after the last chunk (fixed order).
+    constexpr int NT = 256 * SW;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
+    const int wave = wave_all & 3, part_id = wave_all >> 2;
     const int lr = lane & 15, lg = lane >> 4;
     const int o0 = (blockIdx.x * 4 + wave) * 16;                  // this wave's own positions
     const int own = o0 + lr;
@@ -199,19 +206,19 @@ __device__ __forceinline__ void attn_sweep_body(const bf16_t* __restrict__ f, co
 
     // ---- sweep-side staging with a one-chunk register prefetch: the global loads of chunk k+1 are in flight while
     // chunk k is consumed (the sweeps are latency-bound: 11 chunks, each one load round trip otherwise)
-    constexpr int NV = (CHUNK * (DS / 8) + 255) / 256, NTT = (CHUNK * (CS / 8) + 255) / 256;
+    constexpr int NV = (CHUNK * (DS / 8) + NT - 1) / NT, NTT = (CHUNK * (CS / 8) + NT - 1) / NT;
     bf16x8 pv[NV], ptn[NTT];
     float pm = 0.f, piz = 0.f, pdl = 0.f;
     auto issue = [&](int r0) {
 #pragma unroll
         for (int it = 0; it < NV; ++it) {
-            const int idx = tid + it * 256, r = idx / (DS / 8), c = idx % (DS / 8);
+            const int idx = tid + it * NT, r = idx / (DS / 8), c = idx % (DS / 8);
             pv[it] = zero8<bf16_t>();
             if (idx < CHUNK * (DS / 8) && r0 + r < N) pv[it] = load8<bf16_t>(sweep_v + ((size_t)b * N + r0 + r) * DS + c * 8);
         }
 #pragma unroll
         for (int it = 0; it < NTT; ++it) {
-            const int idx = tid + it * 256, r = idx / (CS / 8), c = idx % (CS / 8);
+            const int idx = tid + it * NT, r = idx / (CS / 8), c = idx % (CS / 8);
             ptn[it] = zero8<bf16_t>();
             if (idx < CHUNK * (CS / 8) && r0 + r < N) ptn[it] = load8<bf16_t>(sweep_t + ((size_t)b * N + r0 + r) * CS + c * 8);
         }
@@ -230,12 +237,12 @@ __device__ __forceinline__ void attn_sweep_body(const bf16_t* __restrict__ f, co
         __syncthreads();                                          // the previous chunk has been consumed
 #pragma unroll
         for (int it = 0; it < NV; ++it) {
-            const int idx = tid + it * 256, r = idx / (DS / 8), c = idx % (DS / 8);
+            const int idx = tid + it * NT, r = idx / (DS / 8), c = idx % (DS / 8);
             if (idx < CHUNK * (DS / 8)) *reinterpret_cast<bf16x8*>(vs + r * RB + c * 16) = pv[it];
         }
 #pragma unroll
         for (int it = 0; it < NTT; ++it) {
-            const int idx = tid + it * 256, r = idx / (CS / 8), c = idx % (CS / 8);
+            const int idx = tid + it * NT, r = idx / (CS / 8), c = idx % (CS / 8);
             if (idx < CHUNK * (CS / 8)) *reinterpret_cast<bf16x8*>(ts + r * TS + c * 16) = ptn[it];
         }
         if (!OWN_I && tid < CHUNK) { st_m[tid] = pm; st_z[tid] = piz; st_d[tid] = pdl; }
@@ -243,7 +250,7 @@ __device__ __forceinline__ void attn_sweep_body(const bf16_t* __restrict__ f, co
         if (r0 + CHUNK < N) issue(r0 + CHUNK);
 
         const int nstep = min(CHUNK, ((N - r0 + 31) / 32) * 32) / 32;
-        for (int st = 0; st < nstep; ++st) {
+        for (int st = part_id; st < nstep; st += SW) {
             const int s0 = st * 32;
             // ---- two 16x16 score tiles: rows = sweep positions, columns = own positions
             f32x4 S[2];
@@ -303,6 +310,21 @@ __device__ __forceinline__ void attn_sweep_body(const bf16_t* __restrict__ f, co
         }
     }
 
+    // ---- the SW partial sums of a group of own positions: parts 1.. through LDS, part 0 adds them in order and finishes
+    if constexpr (SW > 1) {
+        __syncthreads();                                          // the last chunk has been consumed
+        f32x4* red = reinterpret_cast<f32x4*>(ts);                // [part - 1][wave][tile][lane]
+        if (part_id > 0) {
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) red[(((part_id - 1) * 4 + wave) * NACC + i) * 64 + lane] = acc[i];
+        }
+        __syncthreads();
+        if (part_id > 0) return;
+#pragma unroll
+        for (int p = 1; p < SW; ++p)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] += red[(((p - 1) * 4 + wave) * NACC + i) * 64 + lane];
+    }
     // ---- epilogue: lane (column own, q = lg) holds rows 4q + r of every accumulator tile
     if constexpr (ACC_C) {
         float part = 0.f;
@@ -343,29 +365,29 @@ __device__ __forceinline__ void attn_sweep_body(const bf16_t* __restrict__ f, co
 }
 
 template <int DS, int CS, int MODE>
-__global__ __launch_bounds__(256) void attn_sweep_mfma(const bf16_t* __restrict__ f, const bf16_t* __restrict__ g,
+__global__ __launch_bounds__(256 * kSweepWays) void attn_sweep_mfma(const bf16_t* __restrict__ f, const bf16_t* __restrict__ g,
                                                        const bf16_t* __restrict__ h, const bf16_t* __restrict__ xdy,
                                                        const float* __restrict__ stats, float* __restrict__ delta,
                                                        bf16_t* __restrict__ out, int N) {
-    attn_sweep_body<DS, CS, MODE>(f, g, h, xdy, stats, delta, out, N);
+    attn_sweep_body<DS, CS, MODE, kSweepWays>(f, g, h, xdy, stats, delta, out, N);
 }
 
 // dg and df need the same inputs (delta from the DH sweep) and nothing from each other: one launch, blockIdx.z picks
 // the mode, twice the workgroups in flight (the sweeps are latency-bound at 336 workgroups).
 template <int DS, int CS>
-__global__ __launch_bounds__(256) void attn_sweep_dgdf(const bf16_t* __restrict__ f, const bf16_t* __restrict__ g,
+__global__ __launch_bounds__(256 * kSweepWays) void attn_sweep_dgdf(const bf16_t* __restrict__ f, const bf16_t* __restrict__ g,
                                                        const bf16_t* __restrict__ h, const bf16_t* __restrict__ dy,
                                                        const float* __restrict__ stats, float* __restrict__ delta,
                                                        bf16_t* __restrict__ dg, bf16_t* __restrict__ df, int N) {
-    if (blockIdx.z == 0) attn_sweep_body<DS, CS, M_DG>(f, g, h, dy, stats, delta, dg, N);
-    else attn_sweep_body<DS, CS, M_DF>(f, g, h, dy, stats, delta, df, N);
+    if (blockIdx.z == 0) attn_sweep_body<DS, CS, M_DG, kSweepWays>(f, g, h, dy, stats, delta, dg, N);
+    else attn_sweep_body<DS, CS, M_DF, kSweepWays>(f, g, h, dy, stats, delta, df, N);
 }
 
 template <int DS, int CS, int MODE>
 int launch_sweep(hipStream_t s, const bf16_t* f, const bf16_t* g, const bf16_t* h, const bf16_t* xdy, const float* stats,
                  float* delta, bf16_t* out, int B, int N) {
     constexpr int lds = (CHUNK * DS * 2 + 64) + CHUNK * (CS * 2 + 16) + 3 * CHUNK * 4;
-    hipLaunchKernelGGL((attn_sweep_mfma<DS, CS, MODE>), dim3(cdiv(N, 64), B), dim3(256), lds, s, f, g, h, xdy, stats, delta, out, N);
+    hipLaunchKernelGGL((attn_sweep_mfma<DS, CS, MODE>), dim3(cdiv(N, 64), B), dim3(256 * kSweepWays), lds, s, f, g, h, xdy, stats, delta, out, N);
     MSAU_CHECK_LAUNCH("attn_sweep_mfma");
     return 0;
 }
@@ -397,7 +419,7 @@ int bwd_t(hipStream_t s, const void* f, const void* g, const void* h, const void
     int rc = launch_sweep<DS, CS, M_DH>(s, fp, gp, hp, dyp, stats, ws, static_cast<bf16_t*>(dh), B, N);
     if (rc) return rc;
     constexpr int lds = (CHUNK * DS * 2 + 64) + CHUNK * (CS * 2 + 16) + 3 * CHUNK * 4;
-    hipLaunchKernelGGL((attn_sweep_dgdf<DS, CS>), dim3(cdiv(N, 64), B, 2), dim3(256), lds, s, fp, gp, hp, dyp, stats, ws,
+    hipLaunchKernelGGL((attn_sweep_dgdf<DS, CS>), dim3(cdiv(N, 64), B, 2), dim3(256 * kSweepWays), lds, s, fp, gp, hp, dyp, stats, ws,
                        static_cast<bf16_t*>(dg), static_cast<bf16_t*>(df), N);
     MSAU_CHECK_LAUNCH("attn_sweep_dgdf");
     return 0;
