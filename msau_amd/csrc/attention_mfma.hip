@@ -313,6 +313,7 @@ __device__ __forceinline__ void attn_sweep_body(const bf16_t* __restrict__ f, co
     // ---- the SW partial sums of a group of own positions: parts 1.. through LDS, part 0 adds them in order and finishes
     if constexpr (SW > 1) {
         __syncthreads();                                          // the last chunk has been consumed
+        static_assert((SW - 1) * 4 * NACC * 1024 <= TS_BYTES, "the partial sums are parked in the C-tensor tile");
         f32x4* red = reinterpret_cast<f32x4*>(ts);                // [part - 1][wave][tile][lane]
         if (part_id > 0) {
 #pragma unroll
