@@ -332,6 +332,7 @@ int msau_conv_lean_dout_capable(int dtype, const msau_conv_desc* d, int nchunks,
 int msau_conv_lean_lrn_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT);
 int msau_conv_lean_pool_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT);
 int msau_conv_lean_ids_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT);
+int msau_conv_chunked_try(hipStream_t s, int dtype, const msau_conv_desc* d, int cch, int kchunk, int nchunks, int CT);
 
 extern "C" int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info) {
     MSAU_CHECK_ARG(d && info, "conv2d_launch_info: null pointer");
@@ -403,6 +404,10 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
         if (!msau_conv_lean_pool_capable(dtype, d, g.nchunks, g.CT))
             return msau_set_error(MSAU_ERR_ARG, "conv2d: MSAU_CONV_POOL is not implemented for this launch (see "
                                   "msau_conv2d_launch_info info[7]); run msau_maxpool2x2_fwd on y instead");
+    }
+    if (g.nslices == 1 && !(d->flags & (MSAU_CONV_HEAD | MSAU_CONV_DOUT | MSAU_CONV_LRN | MSAU_CONV_POOL | MSAU_CONV_IDS))) {
+        rc = msau_conv_chunked_try(static_cast<hipStream_t>(stream), dtype, d, g.cch, g.kchunk, g.nchunks, g.CT);
+        if (rc != 0) return rc < 0 ? rc : 0;
     }
     if (g.nslices == 1) {
         rc = msau_conv_lean_try(static_cast<hipStream_t>(stream), dtype, d, g.kchunk, g.nchunks, g.CT);

@@ -488,6 +488,114 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
     }
 }
 
+
+// ---- many input channels -> one 16-row tile, 3x3 (the first conv of a BERT-embedding chargrid: 768 -> 8, BASELINE configs[3]).
+// The packed image is chunked ([chunk][row][k], 64 channels per chunk: what fits the generic kernel's LDS budget) and the
+// generic kernel took the launch at 1.4 TB/s.  Here a persistent workgroup walks the chunks of its 16 x 16 tile with the
+// accumulators in registers: per chunk one 18 x 18 x 64 input tile and one 16 x 576 weight block go through LDS, both
+// prefetched into registers while the previous chunk's 72 MFMAs per wave run.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_chunked_kernel(const LeanArgs a, const int nchunks) {
+    using Cfg = LeanCfg<T, 8, 1, 3, false>;
+    typedef typename Vec8<T>::type V8;
+    typedef typename Vec4<T>::type V4;
+    constexpr int ESZ = Cfg::ESZ, TI = Cfg::TIW, PS = Cfg::PS, NKS = Cfg::NKS, WS = Cfg::WS;
+    constexpr int NPIX = Cfg::NPIX, NITX = (NPIX * 8 + 255) / 256, WG8 = NKS * 4, NITW = (16 * WG8 + 255) / 256;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* lds_w = smem + Cfg::IN_BYTES;
+    const msau_conv_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    int koff[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int G = ks * 4 + lg, tap = G >> 3, cg = G & 7;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        koff[ks] = (ky * TI + kx) * PS + cg * 8 * ESZ;
+    }
+    const unsigned char* pixp = smem + ((wave * 4) * TI + lr) * PS;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (d.bias && lg * 4 < d.Cout) bv = *reinterpret_cast<const f32x4*>(d.bias + lg * 4);
+    const T* wp = static_cast<const T*>(d.wpack);
+    V8 xr[NITX], wr[NITW];
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int t1 = a.tiles_x > 1 ? __umulhi((unsigned)tile, a.mag_tx) : tile;
+        const int ox0 = (tile - t1 * a.tiles_x) * 16;
+        const int b = a.tiles_y > 1 ? __umulhi((unsigned)t1, a.mag_ty) : t1;
+        const int oy0 = (t1 - b * a.tiles_y) * 16;
+        const int vy0 = oy0 - d.pad_t, vx0 = ox0 - d.pad_l;
+        const char* xb = static_cast<const char*>(d.x1) + (long long)b * d.Hin * a.in_row1;
+        auto issue = [&](int ch) {
+#pragma unroll
+            for (int it = 0; it < NITX; ++it) {
+                const int idx = tid + it * 256;
+                const int pix = idx >> 3, cg = idx & 7;
+                const int iy = pix / TI, ix = pix - iy * TI;
+                const int vy = vy0 + iy, vx = vx0 + ix;
+                xr[it] = zero8<T>();
+                if (idx < NPIX * 8 && (unsigned)vy < (unsigned)d.Hin && (unsigned)vx < (unsigned)d.Win)
+                    xr[it] = *reinterpret_cast<const V8*>(xb + (unsigned)(vy * a.in_row1 + vx * a.in_px1 + (ch * 64 + cg * 8) * ESZ));
+            }
+#pragma unroll
+            for (int it = 0; it < NITW; ++it) {
+                const int idx = tid + it * 256;
+                const int r = idx / WG8, g8 = idx - r * WG8;
+                wr[it] = zero8<T>();
+                if (idx < 16 * WG8) wr[it] = load8<T>(wp + ((size_t)ch * 16 + r) * a.kchunk + g8 * 8);
+            }
+        };
+        f32x4 acc[4];
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) acc[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        issue(0);
+        for (int ch = 0; ch < nchunks; ++ch) {
+            __syncthreads();                                      // the previous chunk's fragments have been read
+#pragma unroll
+            for (int it = 0; it < NITX; ++it) {
+                const int idx = tid + it * 256;
+                if (idx < NPIX * 8) *reinterpret_cast<V8*>(smem + (idx >> 3) * PS + (idx & 7) * 8 * ESZ) = xr[it];
+            }
+#pragma unroll
+            for (int it = 0; it < NITW; ++it) {
+                const int idx = tid + it * 256;
+                const int r = idx / WG8, g8 = idx - r * WG8;
+                if (idx < 16 * WG8) *reinterpret_cast<V8*>(lds_w + r * WS + g8 * 8 * ESZ) = wr[it];
+            }
+            __syncthreads();
+            if (ch + 1 < nchunks) issue(ch + 1);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const unsigned char* p = pixp + koff[ks];
+                V8 bfrag[4];
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) bfrag[pt] = *reinterpret_cast<const V8*>(p + pt * TI * PS);
+                const V8 af = *reinterpret_cast<const V8*>(lds_w + lr * WS + (ks * 32 + lg * 8) * ESZ);
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[pt] = mma8(af, bfrag[pt], acc[pt]);
+            }
+        }
+        const int oyw = oy0 + wave * 4;
+        if (ox0 + lr < d.Wout && lg * 4 < d.Cout) {
+            char* y = static_cast<char*>(d.y) + ((long long)(b * d.Hout + oyw) * d.Wout + ox0 + lr) * a.out_px + lg * 4 * ESZ;
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                if (oyw + pt < d.Hout) {
+                    f32x4 v = acc[pt] + bv;
+                    if (d.flags & MSAU_CONV_RELU_OUT) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                    }
+                    V4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
+                    *reinterpret_cast<V4*>(y + (long long)pt * a.out_row) = o;
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, bool DOUT = false, bool SPLIT = false,
           int STRIDE = 1, int UPS = 1, int EPI = EPI_NONE, int EOP = -1, bool IDS = false>
 int launch_lean_e(hipStream_t s, const LeanArgs& a0) {
@@ -753,6 +861,43 @@ int msau_conv_lean_ids_capable(int dtype, const msau_conv_desc* d, int nchunks, 
 
 int msau_conv_lean_head_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
     return msau_conv_lean_applicable(dtype, d, nchunks, CT) && d->KH == 4 && CT == 1 && d->dil == 1;
+}
+
+// 1 = handled by conv_chunked_kernel, 0 = not this shape.  (cch / kchunk / nchunks: the generic geometry = the packed image.)
+int msau_conv_chunked_try(hipStream_t s, int dtype, const msau_conv_desc* d, int cch, int kchunk, int nchunks, int CT) {
+    static const bool off = std::getenv("MSAU_CONV_CHUNKED") && std::getenv("MSAU_CONV_CHUNKED")[0] == '0';
+    if (off || nchunks < 2 || cch != 64 || CT != 1 || d->C2 || d->KH != 3 || d->KW != 3 || d->dil != 1 || d->stride != 1 || d->ups != 1) return 0;
+    if (d->Hin != d->Hout || d->Win != d->Wout || d->pad_t < 0 || d->pad_l < 0 || d->pad_t > 2 || d->pad_l > 2) return 0;
+    if (d->flags & ~MSAU_CONV_RELU_OUT) return 0;
+    const int esz = dtype == MSAU_F32 ? 4 : 2;
+    if ((int64_t)d->Hin * d->Win * d->C1 * esz >= (1ll << 31)) return 0;              // 32-bit offsets inside an image
+    LeanArgs a;
+    a.d = *d;
+    a.kchunk = kchunk;
+    a.in_px1 = d->C1 * esz; a.in_row1 = d->Win * a.in_px1; a.in_px2 = a.in_row2 = 0;
+    a.out_px = d->Cout * esz; a.out_row = d->Wout * a.out_px;
+    a.tiles_x = cdiv(d->Wout, 16); a.tiles_y = cdiv(d->Hout, 16);
+    a.ntiles = d->B * a.tiles_x * a.tiles_y;
+    if (a.ntiles < 64 || a.ntiles >= (1 << 20) || a.tiles_x >= 4096 || a.tiles_y >= 4096) return 0;
+    a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
+    a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
+    a.per_xcd = 0; a.ct_total = 1;
+    const int lds = dtype == MSAU_F32 ? LeanCfg<float, 8, 1, 3, false>::LDS : LeanCfg<bf16_t, 8, 1, 3, false>::LDS;
+    static bool attr_set[2] = {false, false};
+    const void* fn = dtype == MSAU_F32 ? reinterpret_cast<const void*>(&conv_chunked_kernel<float>) : reinterpret_cast<const void*>(&conv_chunked_kernel<bf16_t>);
+    if (!attr_set[dtype == MSAU_F32] && lds > 60 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
+        if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_chunked: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set[dtype == MSAU_F32] = true;
+    }
+    int per_cu = MSAU_LDS_LIMIT / (lds + 256);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
+    int grid = 256 * per_cu;
+    if (grid > a.ntiles) grid = a.ntiles;
+    if (dtype == MSAU_F32) hipLaunchKernelGGL(conv_chunked_kernel<float>, dim3(grid), dim3(256), lds, s, a, nchunks);
+    else hipLaunchKernelGGL(conv_chunked_kernel<bf16_t>, dim3(grid), dim3(256), lds, s, a, nchunks);
+    MSAU_CHECK_LAUNCH("conv_chunked_kernel");
+    return 1;
 }
 
 int msau_conv_lean_try(hipStream_t s, int dtype, const msau_conv_desc* d, int kchunk, int nchunks, int CT) {

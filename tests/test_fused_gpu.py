@@ -236,3 +236,28 @@ def test_first_conv_weight_gradient_vs_autograd(dtype, cin, hw, B):
     assert err(y, yr.detach(), bf) < (3e-2 if bf else 1e-4)
     assert err(grads["w"], leaves["w"].grad, bf) < (3e-2 if bf else 1e-4)
     assert err(grads["b"], leaves["b"].grad, bf) < (3e-2 if bf else 1e-4)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cin,cout,hw,B", [(128, 8, (65, 63), 4), (192, 16, (33, 70), 5), (768, 8, (48, 64), 6)])
+def test_chunked_first_conv_vs_autograd(dtype, cin, cout, hw, B):
+    """many input channels -> one 16-row tile, 3x3 (the 768 -> 8 first conv of cfg 4): conv_chunked_kernel walks the 64-channel
+    chunks of the packed image with the accumulators in registers; forward against autograd, the weight gradient too"""
+    torch.manual_seed(17)
+    H, W = hw
+    x = torch.randn(B, cin, H, W)
+    p = {"w": 0.05 * torch.randn(cout, cin, 3, 3), "b": 0.1 * torch.randn(cout)}
+    gy = torch.randn(B, cout, H, W)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    yr = O.conv_same(x, leaves["w"], leaves["b"])
+    yr.backward(gy)
+
+    def build(plan):
+        y = Act(plan, "y", H, W, cout)
+        ConvOp(plan, "c", plan.x_in, None, "w", "b", y, 3)
+        plan.logits = y
+    y, _, _, grads = run_graph(build, p, x, gy, dtype)
+    bf = dtype == L.BF16
+    assert err(y, yr.detach(), bf) < (3e-2 if bf else 1e-4)
+    assert err(grads["w"], leaves["w"].grad, bf) < (3e-2 if bf else 1e-4)
+    assert err(grads["b"], leaves["b"].grad, bf) < (3e-2 if bf else 1e-4)
