@@ -140,7 +140,7 @@ int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d);
 /* which template instance msau_conv2d launches for this descriptor (for profiling / roofline):
  * info[0] = CT (16-row output-channel tiles), info[1] = PT (pixel tiles per wave: tile = 4*PT x 16),
  * info[2] = dynamic LDS bytes, info[3] = workgroups, info[4] = channel chunk, info[5] = chunks,
- * info[6] = 1 if a compile-time-specialised "lean" instance (conv_lean.hip) takes the launch,
+ * info[6] = 1 if a compile-time-specialised "lean" instance (conv_lean.hip) takes the launch, 2 if the chunked-K instance does,
  * info[7] = bit 0: that instance implements MSAU_CONV_HEAD for this descriptor, bit 1: MSAU_CONV_DOUT,
  *           bit 2: MSAU_CONV_LRN, bit 3: MSAU_CONV_POOL, bit 4: MSAU_CONV_IDS */
 int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info8);

@@ -333,6 +333,7 @@ int msau_conv_lean_lrn_capable(int dtype, const msau_conv_desc* d, int nchunks, 
 int msau_conv_lean_pool_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT);
 int msau_conv_lean_ids_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT);
 int msau_conv_chunked_try(hipStream_t s, int dtype, const msau_conv_desc* d, int cch, int kchunk, int nchunks, int CT);
+int msau_conv_chunked_capable(int dtype, const msau_conv_desc* d, int cch, int nchunks, int CT);
 
 extern "C" int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info) {
     MSAU_CHECK_ARG(d && info, "conv2d_launch_info: null pointer");
@@ -341,6 +342,8 @@ extern "C" int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32
     if (rc) return rc;
     info[0] = g.CT; info[1] = PT; info[2] = t.total; info[3] = (int32_t)nb; info[4] = g.cch; info[5] = g.nchunks;
     info[6] = msau_conv_lean_applicable(dtype, d, g.nchunks, g.CT);
+    if (g.nslices == 1 && !(d->flags & (MSAU_CONV_HEAD | MSAU_CONV_DOUT | MSAU_CONV_LRN | MSAU_CONV_POOL | MSAU_CONV_IDS)) &&
+        msau_conv_chunked_capable(dtype, d, g.cch, g.nchunks, g.CT)) info[6] = 2;       // conv_chunked_kernel (conv_lean.hip)
     info[7] = msau_conv_lean_head_capable(dtype, d, g.nchunks, g.CT) | (msau_conv_lean_dout_capable(dtype, d, g.nchunks, g.CT) << 1) |
               (msau_conv_lean_lrn_capable(dtype, d, g.nchunks, g.CT) << 2) | (msau_conv_lean_pool_capable(dtype, d, g.nchunks, g.CT) << 3) |
               (msau_conv_lean_ids_capable(dtype, d, g.nchunks, g.CT) << 4);

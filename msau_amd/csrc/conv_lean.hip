@@ -864,13 +864,20 @@ int msau_conv_lean_head_capable(int dtype, const msau_conv_desc* d, int nchunks,
 }
 
 // 1 = handled by conv_chunked_kernel, 0 = not this shape.  (cch / kchunk / nchunks: the generic geometry = the packed image.)
-int msau_conv_chunked_try(hipStream_t s, int dtype, const msau_conv_desc* d, int cch, int kchunk, int nchunks, int CT) {
+int msau_conv_chunked_capable(int dtype, const msau_conv_desc* d, int cch, int nchunks, int CT) {
     static const bool off = std::getenv("MSAU_CONV_CHUNKED") && std::getenv("MSAU_CONV_CHUNKED")[0] == '0';
     if (off || nchunks < 2 || cch != 64 || CT != 1 || d->C2 || d->KH != 3 || d->KW != 3 || d->dil != 1 || d->stride != 1 || d->ups != 1) return 0;
     if (d->Hin != d->Hout || d->Win != d->Wout || d->pad_t < 0 || d->pad_l < 0 || d->pad_t > 2 || d->pad_l > 2) return 0;
     if (d->flags & ~MSAU_CONV_RELU_OUT) return 0;
     const int esz = dtype == MSAU_F32 ? 4 : 2;
     if ((int64_t)d->Hin * d->Win * d->C1 * esz >= (1ll << 31)) return 0;              // 32-bit offsets inside an image
+    const int64_t ntiles = (int64_t)d->B * cdiv(d->Wout, 16) * cdiv(d->Hout, 16);
+    return ntiles >= 64 && ntiles < (1 << 20) && cdiv(d->Wout, 16) < 4096 && cdiv(d->Hout, 16) < 4096;
+}
+
+int msau_conv_chunked_try(hipStream_t s, int dtype, const msau_conv_desc* d, int cch, int kchunk, int nchunks, int CT) {
+    if (!msau_conv_chunked_capable(dtype, d, cch, nchunks, CT)) return 0;
+    const int esz = dtype == MSAU_F32 ? 4 : 2;
     LeanArgs a;
     a.d = *d;
     a.kchunk = kchunk;
@@ -878,7 +885,6 @@ int msau_conv_chunked_try(hipStream_t s, int dtype, const msau_conv_desc* d, int
     a.out_px = d->Cout * esz; a.out_row = d->Wout * a.out_px;
     a.tiles_x = cdiv(d->Wout, 16); a.tiles_y = cdiv(d->Hout, 16);
     a.ntiles = d->B * a.tiles_x * a.tiles_y;
-    if (a.ntiles < 64 || a.ntiles >= (1 << 20) || a.tiles_x >= 4096 || a.tiles_y >= 4096) return 0;
     a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
     a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
     a.per_xcd = 0; a.ct_total = 1;
