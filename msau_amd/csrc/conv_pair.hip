@@ -473,7 +473,9 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
         waves_per_simd = waves_per_simd > 8 ? 8 : waves_per_simd;
         const int by_regs = waves_per_simd / TW;               // a workgroup puts TW waves on every SIMD
         const int by_lds = MSAU_LDS_LIMIT / (Cfg::LDS + Cfg::LDS_PAD + 256);
-        const int n = by_regs < by_lds ? by_regs : by_lds;
+        int n = by_regs < by_lds ? by_regs : by_lds;
+        static const int percu_max = std::getenv("MSAU_PAIR_PERCU") ? atoi(std::getenv("MSAU_PAIR_PERCU")) : 8;
+        n = n > percu_max ? percu_max : n;
         per_cu = n < 1 ? 1 : n;
     }
     int grid = 256 * per_cu;
