@@ -74,6 +74,17 @@ class GradSync:
         else:
             self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def start_whole(self):
+        """one all-reduce of the whole flat buffer (all gradients final on the current stream)"""
+        if not self.active:
+            return
+        if self._side is not None:
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                self._pending.append(dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._pending.append(dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def start_all(self):
         for i in range(len(self.buckets)):
             self.start(i)

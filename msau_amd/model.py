@@ -13,6 +13,8 @@ Two ways to train:
 """
 from __future__ import annotations
 
+import os
+
 import math
 from collections import OrderedDict
 from typing import Dict, Optional, Tuple
@@ -468,7 +470,9 @@ class TrainEngine:
     def _fwd_bwd(self, plan: Plan, x, labels, ids=None):
         plan.forward(self.model._flat, x, export=False, ids=ids)
         loss = plan.loss_grads(labels)
-        if self.sync.active and not self.use_graph:
+        # MSAU_DP_BUCKETS=1: ONE all-reduce of the whole flat gradient after the backward instead of a bucket per stage
+        # issued while the earlier stages' backward still runs (fewer launches and joins, no overlap)
+        if self.sync.active and not self.use_graph and os.environ.get("MSAU_DP_BUCKETS", "stage") != "1":
             # bucket i of GradSync = [end convs, last stage, ..., stage 0]; a stage's bucket is reduced over RCCL as
             # soon as that stage's slab reduction is enqueued, while the earlier stages' backward still runs
             nb = self.model.num_blocks
@@ -490,6 +494,8 @@ class TrainEngine:
         if self.sync.active:
             if getattr(self, "_ar_started", False):
                 self.sync.start(0)                       # the end-conv tail: final once every stage is done
+            elif os.environ.get("MSAU_DP_BUCKETS", "stage") == "1":
+                self.sync.start_whole()
             else:
                 self.sync.start_all()
             self.sync.finish()
