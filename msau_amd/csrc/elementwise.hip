@@ -627,7 +627,7 @@ __global__ void channel_sum_kernel(const T* __restrict__ g, int64_t npix, int Cs
 // =============================================================================================
 // global-norm clip + Adam (train_chargrid_funsd_msau.py:24-26,58-59)
 // =============================================================================================
-__global__ void sqsum_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partials) {
+__global__ void sqsum_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partials, float* __restrict__ state) {
     __shared__ float red[kThreads / 64];
     float s = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -641,31 +641,33 @@ __global__ void sqsum_kernel(const float* __restrict__ g, int64_t n, float* __re
         float t = 0.f;
         for (int i = 0; i < kThreads / 64; ++i) t += red[i];
         partials[blockIdx.x] = t;
+        if (blockIdx.x == 0 && state) state[0] += 1.f;             // the step counter: read by every workgroup of adam_kernel
     }
 }
 
-__global__ void adam_prep_kernel(const float* __restrict__ partials, int n, float* __restrict__ state,
-                                 float beta1, float beta2, float max_norm, float grad_scale) {
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 64) s += partials[i];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if (threadIdx.x == 0) {
-        float step = state[0] + 1.f;
-        float norm = sqrtf(s) * grad_scale;
-        float coef = max_norm / (norm + 1e-6f);               // torch.nn.utils.clip_grad_norm_
-        state[0] = step;
-        state[1] = norm;
-        state[2] = coef < 1.f ? coef : 1.f;
-        state[3] = (float)(1.0 - pow((double)beta1, (double)step));
-        state[4] = (float)(1.0 - pow((double)beta2, (double)step));
-    }
-}
-
+// clip coefficient and bias corrections are derived by every workgroup from the sqsum partials (fixed order: the same bits
+// everywhere) instead of by a one-wave kernel in between: one dependent launch less at the tail of the step
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            const float* __restrict__ state, int64_t n, float lr, float beta1, float beta2, float eps,
-                            float grad_scale) {
-    const float gs = state[2] * grad_scale;
-    const float bc1 = state[3], bc2s = sqrtf(state[4]);
+                            float* __restrict__ state, const float* __restrict__ partials, int npart, int64_t n, float lr,
+                            float beta1, float beta2, float eps, float max_norm, float grad_scale) {
+    __shared__ float sh[4];
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < npart; i += 64) s += partials[i];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (threadIdx.x == 0) {
+            const float step = state[0];                              // already advanced by sqsum_kernel
+            const float norm = sqrtf(s) * grad_scale;
+            const float coef = max_norm / (norm + 1e-6f);               // torch.nn.utils.clip_grad_norm_
+            sh[0] = coef < 1.f ? coef : 1.f;
+            sh[1] = (float)(1.0 - pow((double)beta1, (double)step));
+            sh[2] = (float)(1.0 - pow((double)beta2, (double)step));
+            if (blockIdx.x == 0) { state[1] = norm; state[2] = sh[0]; state[3] = sh[1]; state[4] = sh[2]; }
+        }
+    }
+    __syncthreads();
+    const float gs = sh[0] * grad_scale;
+    const float bc1 = sh[1], bc2s = sqrtf(sh[2]);
     const float step_size = lr / bc1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float gi = g[i] * gs;
@@ -946,11 +948,9 @@ extern "C" int msau_clip_adam_step(void* stream, float* params, const float* gra
     MSAU_CHECK_ARG(params && grads && m && v && state && ws && n > 0, "clip_adam: bad args");
     hipStream_t s = static_cast<hipStream_t>(stream);
     int nb = adam_blocks(n);
-    hipLaunchKernelGGL(sqsum_kernel, dim3(nb), dim3(kThreads), 0, s, grads, n, ws);
+    hipLaunchKernelGGL(sqsum_kernel, dim3(nb), dim3(kThreads), 0, s, grads, n, ws, state);
     MSAU_CHECK_LAUNCH("sqsum");
-    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, ws, nb, state, beta1, beta2, max_norm, grad_scale);
-    MSAU_CHECK_LAUNCH("adam_prep");
-    hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(kThreads), 0, s, params, grads, m, v, state, n, lr, beta1, beta2, eps, grad_scale);
+    hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(kThreads), 0, s, params, grads, m, v, state, ws, nb, n, lr, beta1, beta2, eps, max_norm, grad_scale);
     MSAU_CHECK_LAUNCH("adam");
     return 0;
 }

@@ -6,6 +6,7 @@ set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02
 mkdir -p "$O" && cd "$R" || exit 1
 python -m pytest tests -m gpu -q > "$O/tests.log" 2>&1; echo "pytest rc=$?" | tee -a "$O/tests.log"; tail -3 "$O/tests.log"
+python __graft_entry__.py smoke 2>&1 | tail -1 | tee -a "$O/tests.log"
 # PMC traffic first (it stamps profiles/r02_traffic.json with this tree's kernel hash), then the bench line that reads it
 python tools/make_traffic.py > "$O/traffic.log" 2>&1 || { tail -5 "$O/traffic.log"; exit 1; }
 python bench.py --dump-kernels "$O/r02_final_hip_events.csv" > "$O/r02_final_bench.json" 2> "$O/bench.err" || { tail -5 "$O/bench.err"; exit 1; }
