@@ -45,13 +45,22 @@ struct WLeanCfg {
     // multiple of 4 (8 -> 8 channels 3x3: 5 k-tiles, wave 0 does 2 and sets the pace; 1x1: 1 k-tile, three waves idle)
     // and makes every wave read the same g fragments.  The four partial sums meet once, in LDS, after the last tile.
     static constexpr bool PS = ESZ == 2 && NKT * CTN <= MSAU_WPS_MAX;
+    // W2 ("two wave sets", the bf16 instances too big for PS): 8 waves per workgroup -- waves 0-3 take the first four 32-pixel
+    // blocks of the tile, waves 4-7 the other four, each set split over the k-tiles as before.  The level-2/3 launches have
+    // 64-107 workgroups, i.e. one per CU with ONE wave per SIMD: every fragment read -> MFMA chain ran fully exposed
+    // (PMC: 27.7 us for an 11 MB layer).  The two partial sums meet in LDS after the last tile (fixed order).
+#ifndef MSAU_WGRAD_W2
+#define MSAU_WGRAD_W2 1
+#endif
+    static constexpr bool W2 = MSAU_WGRAD_W2 && ESZ == 2 && !PS;
+    static constexpr int NTH = W2 ? 512 : 256;
     static constexpr int RED_BYTES = PS ? 4 * NKT * CTN * 1024 : 0;
     static constexpr int TILE_BYTES = X_BYTES + G_BYTES + 64;
     static constexpr int LDS = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
 };
 
 template <typename T, int C8, int CO8, int KS, int DIL = 1, int STRIDE = 1>
-__global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanMulti m) {
+__global__ __launch_bounds__((WLeanCfg<T, C8, CO8, KS, DIL, STRIDE>::NTH)) void wgrad_lean_kernel(const WLeanMulti m) {
     const WLeanArgs a = m.a[blockIdx.z];                               // by value: one scalar load of the layer's descriptor
     using Cfg = WLeanCfg<T, C8, CO8, KS, DIL, STRIDE>;
     typedef typename Vec8<T>::type V8;
@@ -62,8 +71,13 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanMulti m) {
     constexpr int ONES = Cfg::X_BYTES + Cfg::G_BYTES;            // {1,0,0,0,0,0,0,0} of T
 
     const msau_wgrad_desc& d = a.d;
+    constexpr int NTH = Cfg::NTH;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // k-tile owner and (W2) pixel-block half.  The 4-wave instances keep `wave = readfirstlane(tid >> 6)` to the letter: with
+    // `& 3` added (a no-op there) the fp32 16 -> 8 3x3 instance returned wrong sums in k-tiles 6 and 7 (tests/test_ops_gpu.py
+    // conv3lin / conv3c13) -- not understood, so those instances are left exactly as they were validated.
+    const int wave = Cfg::W2 ? __builtin_amdgcn_readfirstlane((tid >> 6) & 3) : __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wset = Cfg::W2 ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;
     const int li = lane & 15, lg = lane >> 4;
     const int chunk = blockIdx.y;
     const bool relu_in = d.flags & MSAU_CONV_RELU_IN;
@@ -107,7 +121,7 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanMulti m) {
     // software pipeline: the global loads of tile t+1 are issued (into registers) before the MFMA phase of
     // tile t and written to LDS at the top of the next iteration -- a persistent workgroup has only
     // 2 waves per SIMD, so without this every tile pays the full HBM latency.
-    constexpr int NITX = (TI * TI * C8 + 255) / 256, NITG = CO8;
+    constexpr int NITX = (TI * TI * C8 + NTH - 1) / NTH, NITG = (256 * CO8 + NTH - 1) / NTH;
     // beyond 8 staging registers usually cost more than they hide; the exception is the network's first conv
     // (64 -> 8 channels: 11 + 1), whose weight gradient is the tail of the backward sweep (105.8 -> 96.7 us)
     constexpr bool PIPE = NITX + NITG <= 8 || (C8 == 8 && CO8 == 1);
@@ -124,9 +138,9 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanMulti m) {
             const char* base = xsrc + (long long)b * d.Hin * in_row + cb;
 #pragma unroll
             for (int it = 0; it < NITX; ++it) {
-                const int idx = tid + it * 256;
+                const int idx = tid + it * NTH;
                 xr[it] = zero8<T>();
-                if ((it + 1) * 256 <= NITEMS || idx < NITEMS) {
+                if ((it + 1) * NTH <= NITEMS || idx < NITEMS) {
                     const int pix = idx / C8, cg = idx - pix * C8;
                     const int iy = pix / TI, ix = pix - iy * TI;
                     const int vy = vy0 + iy, vx = vx0 + ix;
@@ -139,11 +153,11 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanMulti m) {
             const char* base = static_cast<const char*>(d.g) + (long long)b * d.Hout * g_row;
 #pragma unroll
             for (int it = 0; it < NITG; ++it) {
-                const int idx = tid + it * 256;
+                const int idx = tid + it * NTH;
                 const int m = idx / CO8, cg = idx - m * CO8;
                 const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
                 gr[it] = zero8<T>();                                 // pixels outside the image contribute 0
-                if (oy < d.Hout && ox < d.Wout) gr[it] = *reinterpret_cast<const V8*>(base + (unsigned)(oy * g_row + ox * g_px + cg * 8 * ESZ));
+                if (idx < 256 * CO8 && oy < d.Hout && ox < d.Wout) gr[it] = *reinterpret_cast<const V8*>(base + (unsigned)(oy * g_row + ox * g_px + cg * 8 * ESZ));
             }
         }
     };
@@ -156,8 +170,8 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanMulti m) {
             constexpr int NITEMS = TI * TI * C8;
 #pragma unroll
             for (int it = 0; it < NITX; ++it) {
-                const int idx = tid + it * 256;
-                if ((it + 1) * 256 <= NITEMS || idx < NITEMS) {
+                const int idx = tid + it * NTH;
+                if ((it + 1) * NTH <= NITEMS || idx < NITEMS) {
                     const int pix = idx / C8, cg = idx - pix * C8;
                     V8 v = xr[it];
                     if (relu_in) v = relu8<T>(v);
@@ -166,9 +180,9 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanMulti m) {
             }
 #pragma unroll
             for (int it = 0; it < NITG; ++it) {
-                const int idx = tid + it * 256;
+                const int idx = tid + it * NTH;
                 const int m = idx / CO8, cg = idx - m * CO8;
-                *reinterpret_cast<V8*>(lds_g + m * PSG + cg * 8 * ESZ) = gr[it];
+                if (idx < 256 * CO8) *reinterpret_cast<V8*>(lds_g + m * PSG + cg * 8 * ESZ) = gr[it];
             }
         }
         __syncthreads();
@@ -207,8 +221,10 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanMulti m) {
             }
         } else if constexpr (sizeof(T) == 2) {
             const int q = li >> 2, p = li & 3;
+            constexpr int NBLK = Cfg::W2 ? 4 : 8;
 #pragma unroll
-            for (int blk = 0; blk < 8; ++blk) {
+            for (int bq = 0; bq < NBLK; ++bq) {
+                const int blk = Cfg::W2 ? wset * 4 + bq : bq;
                 // pixels m0 = blk*32 + lg*8 + q (+4): row = blk*2 + (lg>>1), col = (lg&1)*8 + q (+4)
                 const int row = blk * 2 + (lg >> 1), col = (lg & 1) * 8 + q;
                 const unsigned char* ga = lds_g + (row * 16 + col) * PSG + 4 * p * 2;
@@ -283,6 +299,30 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(const WLeanMulti m) {
             }
         }
         return;
+    }
+    if constexpr (Cfg::W2) {
+        // the second wave set parks its partial sums in LDS (as many k-tile rows per round as the tile area holds)
+        constexpr int PER = Cfg::TILE_BYTES / (4 * CTN * 1024) < 1 ? 1 : Cfg::TILE_BYTES / (4 * CTN * 1024);
+        f32x4* red = reinterpret_cast<f32x4*>(smem);                  // [wave][i in round][ct][lane]
+        for (int i0 = 0; i0 < NKW; i0 += PER) {
+            __syncthreads();
+            if (wset == 1) {
+#pragma unroll
+                for (int i = 0; i < NKW; ++i)
+                    if (i >= i0 && i < i0 + PER)
+#pragma unroll
+                        for (int ct = 0; ct < CTN; ++ct) red[((wave * PER + (i - i0)) * CTN + ct) * 64 + lane] = acc[i][ct];
+            }
+            __syncthreads();
+            if (wset == 0) {
+#pragma unroll
+                for (int i = 0; i < NKW; ++i)
+                    if (i >= i0 && i < i0 + PER)
+#pragma unroll
+                        for (int ct = 0; ct < CTN; ++ct) acc[i][ct] += red[((wave * PER + (i - i0)) * CTN + ct) * 64 + lane];
+            }
+        }
+        if (wset == 1) return;
     }
 #pragma unroll
     for (int i = 0; i < NKW; ++i) {
@@ -525,7 +565,7 @@ int launch_wlean(hipStream_t s, const WLeanMulti& m, int n) {
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "wgrad_lean: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_lean_kernel<T, C8, CO8, KS, DIL, STRIDE>), dim3(a.d.nslabs, a.nchunks, n), dim3(256), Cfg::LDS, s, m);
+    hipLaunchKernelGGL((wgrad_lean_kernel<T, C8, CO8, KS, DIL, STRIDE>), dim3(a.d.nslabs, a.nchunks, n), dim3(Cfg::NTH), Cfg::LDS, s, m);
     MSAU_CHECK_LAUNCH("wgrad_lean_kernel");
     return 1;
 }

@@ -261,3 +261,41 @@ def test_chunked_first_conv_vs_autograd(dtype, cin, cout, hw, B):
     assert err(y, yr.detach(), bf) < (3e-2 if bf else 1e-4)
     assert err(grads["w"], leaves["w"].grad, bf) < (3e-2 if bf else 1e-4)
     assert err(grads["b"], leaves["b"].grad, bf) < (3e-2 if bf else 1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,k,hw", [(32, 32, 3, (42, 32)), (64, 64, 3, (21, 16)), (64, 64, 1, (21, 16)), (16, 32, 3, (84, 64)), (32, 64, 3, (33, 20)),
+                                           (8, 8, 3, (64, 80)), (16, 16, 3, (50, 37))])
+@pytest.mark.parametrize("dtype", DT)
+def test_weight_gradient_slabs_vs_fp32_autograd_on_the_same_rounded_inputs(cin, cout, k, hw, dtype):
+    """bf16 x bf16 products are exact in fp32, so the lean weight-gradient instances (pixel-split, two-wave-set, plain) must
+    agree with an fp32 autograd weight gradient of the SAME bf16-rounded tensors up to summation order: 2e-5 of the largest
+    entry -- three orders of magnitude tighter than the bf16 network tolerances, tight enough to see a lost or doubled tile"""
+    torch.manual_seed(18)
+    lib = L.load()
+    s = torch.cuda.current_stream().cuda_stream
+    B, (H, W) = 3, hw
+    td = torch.bfloat16 if dtype == L.BF16 else torch.float32
+    x = (torch.randn(B, H, W, cin, device="cuda") * 0.5).to(td)
+    g = (torch.randn(B, H, W, cout, device="cuda") * 0.5).to(td)
+    probe = _wdesc(x, g, x, cin, cout, k, 1)
+    geom = L.WgradGeom()
+    L.check(lib.msau_wgrad_geometry(dtype, C.byref(probe), C.byref(geom)), "geometry")
+    if not (geom.lean and geom.nchunks == 1):
+        pytest.skip("fp32 stages this shape in several K chunks (generic kernel: covered by the golden op tests)")
+    nslabs = min(geom.max_slabs, 40)
+    slab_elems = geom.slab_bytes // 4
+    slabs = torch.full((nslabs * slab_elems,), float("nan"), device="cuda")
+    d = _wdesc(x, g, slabs, cin, cout, k, nslabs)
+    L.check(lib.msau_conv2d_wgrad(s, dtype, C.byref(d)), "wgrad")
+    torch.cuda.synchronize()
+    tot = slabs.view(nslabs, cout, geom.kext).sum(0).cpu()
+    assert not torch.isnan(tot[:, :k * k * cin + 1]).any()
+    xr = x.float().permute(0, 3, 1, 2).cpu()
+    gr = g.float().permute(0, 3, 1, 2).cpu()
+    w = torch.zeros(cout, cin, k, k, requires_grad=True)
+    b = torch.zeros(cout, requires_grad=True)
+    O.conv_same(xr, w, b).backward(gr)
+    got_w = tot[:, :k * k * cin].view(cout, k * k, cin).permute(0, 2, 1).reshape(cout, cin, k, k)      # slab k = [tap][channel]
+    got_b = tot[:, k * k * cin]
+    assert float((got_w - w.grad).abs().max()) < 2e-5 * float(w.grad.abs().max())
+    assert float((got_b - b.grad).abs().max()) < 2e-5 * float(b.grad.abs().max())
