@@ -405,11 +405,14 @@ def main():
         cpu = cpu_baseline(args, n_class)
 
     if rank == 0:
-        out = {"metric": "chargrid tiles/sec (train fwd+bwd), 336x256x64 3-stage MSAU", "value": round(value, 2),
+        headline = (args.height, args.width, args.channels, args.stages) == (336, 256, 64, 3)
+        shape = f"{args.height}x{args.width}x{args.channels} {args.stages}-stage MSAU"
+        cfg = "configs[1]: one-hot" if headline else ("configs[3]: BERT-embedding" if args.channels == 768 else "non-headline")
+        out = {"metric": f"chargrid tiles/sec (train fwd+bwd), {shape}", "value": round(value, 2),
                "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": f"configs[1]: one-hot chargrid {args.height}x{args.width}x{args.channels}, "
+               "config": {"workload": f"{cfg} chargrid {args.height}x{args.width}x{args.channels}, "
                                       f"{args.stages}-stage MSAU (featRoot 8, 4 scales, res_depth 2), "
                                       f"batch {args.batch}/GPU, fwd+masked-CE+bwd+clip+Adam"
                                       + (", RCCL all-reduce" if world > 1 else ""),

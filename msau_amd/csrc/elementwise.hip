@@ -66,15 +66,28 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_tiled_kernel(const float* __
 // Register form (HW % 4 == 0): a thread owns 4 consecutive pixels x 8 consecutive channels -- eight 16-byte plane loads in
 // flight, an 8 x 4 transpose in registers, four 16-byte (bf16) pixel stores; the Cs/8 lanes of a pixel quad write whole
 // pixels (Cs * sizeof(T) contiguous bytes), lanes Cs/8 apart read 16-byte neighbours of one plane.  No LDS, no barrier.
-template <typename T>
+template <typename T, bool WIDE>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_reg_kernel(const float* __restrict__ src, T* __restrict__ dst,
                                                                int C, int Cs, int64_t HW, int64_t total) {
     const int cgs = Cs >> 3;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;        // (image, pixel quad, channel group), group fastest
     if (i >= total) return;
-    const int cg = (int)(i % cgs);
-    const int64_t r = i / cgs;
     const int64_t quads = HW >> 2;
+    int cg;
+    int64_t r;
+    if (WIDE) {
+        // many channels (cgs % 8 == 0, quads % 8 == 0): a wave owns 8 quads x 8 groups, so that its eight lanes of one
+        // plane read a whole 128-byte line; with the group fastest across all of Cs those eight quads sit in eight
+        // different waves (three blocks at 768 channels) and every XCD's L2 fetches the line for itself
+        const int64_t w = i >> 6;
+        const int lane = (int)(i & 63);
+        const int cgb = cgs >> 3;
+        cg = (int)(w % cgb) * 8 + (lane >> 3);
+        r = (w / cgb) * 8 + (lane & 7);
+    } else {
+        cg = (int)(i % cgs);
+        r = i / cgs;
+    }
     const int64_t b = r / quads, q = r - b * quads;
     f32x4 v[8];
 #pragma unroll
@@ -749,9 +762,16 @@ extern "C" int msau_nchw_to_nhwc(void* stream, int dtype, const float* src, void
         const int64_t total = (int64_t)B * (HW / 4) * (Cs / 8);
         MSAU_CHECK_ARG(cdiv64(total, 256) < (1ll << 31), "nchw_to_nhwc: grid too large");
         const int grid = (int)cdiv64(total, 256);
-        DISPATCH_T(dtype,
-                   hipLaunchKernelGGL(nchw_to_nhwc_reg_kernel<float>, dim3(grid), dim3(256), 0, s, src, static_cast<float*>(dst), C, Cs, HW, total),
-                   hipLaunchKernelGGL(nchw_to_nhwc_reg_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, src, static_cast<bf16_t*>(dst), C, Cs, HW, total));
+        static const bool wide_off = getenv("MSAU_NCHW_WIDE") && atoi(getenv("MSAU_NCHW_WIDE")) == 0;
+        if (!wide_off && Cs > 64 && (Cs / 8) % 8 == 0 && (HW / 4) % 8 == 0) {
+            DISPATCH_T(dtype,
+                       hipLaunchKernelGGL((nchw_to_nhwc_reg_kernel<float, true>), dim3(grid), dim3(256), 0, s, src, static_cast<float*>(dst), C, Cs, HW, total),
+                       hipLaunchKernelGGL((nchw_to_nhwc_reg_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, s, src, static_cast<bf16_t*>(dst), C, Cs, HW, total));
+        } else {
+            DISPATCH_T(dtype,
+                       hipLaunchKernelGGL((nchw_to_nhwc_reg_kernel<float, false>), dim3(grid), dim3(256), 0, s, src, static_cast<float*>(dst), C, Cs, HW, total),
+                       hipLaunchKernelGGL((nchw_to_nhwc_reg_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, s, src, static_cast<bf16_t*>(dst), C, Cs, HW, total));
+        }
         MSAU_CHECK_LAUNCH("nchw_to_nhwc_reg");
         return 0;
     }

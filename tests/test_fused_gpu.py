@@ -299,3 +299,23 @@ def test_weight_gradient_slabs_vs_fp32_autograd_on_the_same_rounded_inputs(cin, 
     got_b = tot[:, k * k * cin]
     assert float((got_w - w.grad).abs().max()) < 2e-5 * float(w.grad.abs().max())
     assert float((got_b - b.grad).abs().max()) < 2e-5 * float(b.grad.abs().max())
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c,cs,hw", [(64, 64, (16, 24)), (768, 768, (8, 16)), (100, 128, (8, 8)), (300, 320, (16, 8)), (13, 16, (6, 6)),
+                                     (72, 72, (8, 8)), (128, 128, (5, 7)), (7, 8, (4, 4))])
+def test_nchw_to_nhwc_every_mapping(dtype, c, cs, hw):
+    """the NCHW fp32 -> NHWC conversion at the boundary (train_chargrid_funsd_msau.py:50-53 hands over NCHW fp32): the
+    narrow and the many-channel ("wide") thread mappings of the register kernel, the LDS-tiled kernel (H*W % 4 != 0) and
+    the scalar one, with and without padded channels -- a cast and a transpose, so bit-exact"""
+    torch.manual_seed(5)
+    B, (H, W) = 3, hw
+    x = torch.randn(B, c, H, W)
+    tdt = torch.float32 if dtype == L.F32 else torch.bfloat16
+    out = torch.full((B, H, W, cs), 7.0, dtype=tdt, device="cuda")
+    xd = x.cuda()
+    L.call("msau_nchw_to_nhwc", torch.cuda.current_stream().cuda_stream, dtype, xd.data_ptr(), out.data_ptr(), B, c, cs, H, W)
+    torch.cuda.synchronize()
+    want = torch.zeros(B, H, W, cs, dtype=tdt)
+    want[..., :c] = x.permute(0, 2, 3, 1).to(tdt)
+    assert torch.equal(out.cpu(), want)
