@@ -73,10 +73,15 @@ __global__ __launch_bounds__((WLeanCfg<T, C8, CO8, KS, DIL, STRIDE>::NTH)) void 
     const msau_wgrad_desc& d = a.d;
     constexpr int NTH = Cfg::NTH;
     const int tid = threadIdx.x, lane = tid & 63;
-    // k-tile owner and (W2) pixel-block half.  The 4-wave instances keep `wave = readfirstlane(tid >> 6)` to the letter: with
-    // `& 3` added (a no-op there) the fp32 16 -> 8 3x3 instance returned wrong sums in k-tiles 6 and 7 (tests/test_ops_gpu.py
-    // conv3lin / conv3c13) -- not understood, so those instances are left exactly as they were validated.
-    const int wave = Cfg::W2 ? __builtin_amdgcn_readfirstlane((tid >> 6) & 3) : __builtin_amdgcn_readfirstlane(tid >> 6);
+    // k-tile owner (and, W2, pixel-block half).  Waves that own no k-tile in round i (wave + 4 i >= NKT) still issue that
+    // round's MFMAs, on an all-zero column group: NO branch surrounds an MFMA of the tile loop.  With wave-uniform
+    // `if (wave + 4 * i < NKT)` around the MFMAs, hipcc (ROCm 7.2) moved the accumulators between AGPRs and VGPRs at
+    // every branch, and in one layout of the fp32 16 -> 8 3x3 instance the taken edge of such a branch reached
+    // `v_accvgpr_read_b32 a7` four issue slots after the `v_mfma_f32_16x16x4_f32 a[4:7]` that writes it -- the 8-pass
+    // MFMA needs 11; the fall-through edge had another MFMA in between and was fine -- so waves 2 and 3 wrote back stale
+    // accumulators and k-tiles 6 and 7 came out short.  Straight-line code gives the hazard
+    // recogniser nothing to miss, keeps the accumulators in AGPRs, and costs nothing: the waves that own every round set the pace.
+    const int wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
     const int wset = Cfg::W2 ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;
     const int li = lane & 15, lg = lane >> 4;
     const int chunk = blockIdx.y;
@@ -102,7 +107,8 @@ __global__ __launch_bounds__((WLeanCfg<T, C8, CO8, KS, DIL, STRIDE>::NTH)) void 
         const int nkt = PS ? i : wave + 4 * i;
         const int k = nkt * 16 + (sizeof(T) == 2 ? (li & 3) * 4 : (li >> 2) * 4);     // first k of the lane's 4-column group
         int off;
-        if (k < Cfg::KREAL) {
+        if (!PS && nkt >= NKT) off = WL_ABS | (ONES + 4 * ESZ);        // not this wave's round: the four zeros after the one
+        else if (k < Cfg::KREAL) {
             const int tap = k / (C8 * 8), c = k - tap * (C8 * 8);
             const int ky = tap / KS, kx = tap - ky * KS;
             off = (ky * DIL * TI + kx * DIL) * PSX + c * ESZ;
@@ -237,18 +243,16 @@ __global__ __launch_bounds__((WLeanCfg<T, C8, CO8, KS, DIL, STRIDE>::NTH)) void 
                 }
                 const int pb0 = (row * STRIDE * TI + col * STRIDE) * PSX;
 #pragma unroll
-                for (int i = 0; i < NKW; ++i) {
-                    if (wave + 4 * i < NKT) {                          // wave-uniform
-                        const int e = coloff[i];
-                        const int o0 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + e;
-                        const int o1 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + 4 * STRIDE * PSX + e;
-                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o0));
-                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o1));
-                        bf16x8 bfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                for (int i = 0; i < NKW; ++i) {                        // rounds this wave does not own read zeros (see `wave`)
+                    const int e = coloff[i];
+                    const int o0 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + e;
+                    const int o1 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + 4 * STRIDE * PSX + e;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o0));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o1));
+                    bf16x8 bfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-                        for (int ct = 0; ct < CTN; ++ct)
-                            acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[ct], bfrag, acc[i][ct], 0, 0, 0);
-                    }
+                    for (int ct = 0; ct < CTN; ++ct)
+                        acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[ct], bfrag, acc[i][ct], 0, 0, 0);
                 }
             }
         } else {
@@ -260,13 +264,11 @@ __global__ __launch_bounds__((WLeanCfg<T, C8, CO8, KS, DIL, STRIDE>::NTH)) void 
                 const int pb = ((m >> 4) * STRIDE * TI + (m & 15) * STRIDE) * PSX;
 #pragma unroll
                 for (int i = 0; i < NKW; ++i) {
-                    if (wave + 4 * i < NKT) {
-                        const int e = coloff[i];
-                        const float bv = *reinterpret_cast<const float*>(smem + ((e & WL_ABS) ? (e & ~WL_ABS) : pb + e));
+                    const int e = coloff[i];
+                    const float bv = *reinterpret_cast<const float*>(smem + ((e & WL_ABS) ? (e & ~WL_ABS) : pb + e));
 #pragma unroll
-                        for (int ct = 0; ct < CTN; ++ct)
-                            acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ct], bv, acc[i][ct], 0, 0, 0);
-                    }
+                    for (int ct = 0; ct < CTN; ++ct)
+                        acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ct], bv, acc[i][ct], 0, 0, 0);
                 }
             }
         }
