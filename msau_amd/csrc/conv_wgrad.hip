@@ -52,7 +52,7 @@ int wgrad_geom(int dtype, const msau_wgrad_desc* d, WGeom* out) {
         int nkw = cdiv(kext / 16, 4);
         if (nkw * g.CTN > 40 || nkw > 10) continue;           // accumulator registers per wave
         int xb = roundup(g.TIH * g.TIW * pix_stride(c, g.esz), 16);
-        if (xb + g.g_bytes + (kext / 4) * 4 + 64 > 150 * 1024) continue;
+        if (xb + g.g_bytes + 640 + 64 > 150 * 1024) continue;   // 640: the column table at its largest (below)
         best = c; break;
     }
     if (!best) return msau_set_error(MSAU_ERR_LDS, "wgrad: no chunk fits (Cin %d Cout %d k %dx%d dil %d)", Cin, d->Cout, d->KH, d->KW, d->dil);
@@ -65,7 +65,7 @@ int wgrad_geom(int dtype, const msau_wgrad_desc* d, WGeom* out) {
     g.NKW = nkw <= 1 ? 1 : nkw <= 2 ? 2 : nkw <= 3 ? 3 : nkw <= 5 ? 5 : 10;
     g.PSx = pix_stride(best, g.esz);
     g.x_bytes = roundup(g.TIH * g.TIW * g.PSx, 16);
-    g.tab_bytes = roundup((g.kextc / 4) * 4, 16);
+    g.tab_bytes = 64 * g.NKW;                                  // 4 waves x NKW rounds of k-tiles, 4 column groups each (>= kextc / 4 entries)
     g.total = g.x_bytes + g.g_bytes + g.tab_bytes + 64;
     *out = g;
     return 0;
@@ -98,8 +98,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
     const int chunk = blockIdx.y;
     const int cg_per_chunk = a.cch >> 3;
 
-    // column-group table: byte offset (relative to the pixel's slot in lds_x) of 4 consecutive k
-    for (int c4 = tid; c4 < a.kextc / 4; c4 += 256) {
+    // column-group table: byte offset (relative to the pixel's slot in lds_x) of 4 consecutive k.  It covers all 4 * NKW
+    // k-tiles of the instance, the ones past kextc as zero columns: a wave issues every round's MFMAs and NO branch
+    // surrounds an MFMA of the tile loop (wgrad_lean.hip has the reason: a missed MFMA -> accvgpr_read wait on a branch edge)
+    for (int c4 = tid; c4 < 16 * NKW; c4 += 256) {
         int k = c4 * 4, off;
         if (k < a.kreal) {
             int tap = k / a.cch, c = k - tap * a.cch;
@@ -186,33 +188,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
                 const int pb1 = (((m1 >> 4) * d.stride) * a.TIW + (m1 & 15) * d.stride) * a.PSx;
 #pragma unroll
                 for (int i = 0; i < NKW; ++i) {
-                    const int nkt = wave + 4 * i;
-                    if (nkt < a.NKT) {                                // wave-uniform
-                        const int e = tab[nkt * 4 + p];
-                        const int o0 = (e & TAB_ABS) ? (e & ~TAB_ABS) : pb0 + e;
-                        const int o1 = (e & TAB_ABS) ? (e & ~TAB_ABS) : pb1 + e;
-                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o0));
-                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o1));
-                        bf16x8 bfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const int e = tab[(wave + 4 * i) * 4 + p];        // k-tiles past NKT: zero columns
+                    const int o0 = (e & TAB_ABS) ? (e & ~TAB_ABS) : pb0 + e;
+                    const int o1 = (e & TAB_ABS) ? (e & ~TAB_ABS) : pb1 + e;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o0));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o1));
+                    bf16x8 bfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-                        for (int ct = 0; ct < CTN; ++ct)
-                            acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[ct], bfrag, acc[i][ct], 0, 0, 0);
-                    }
+                    for (int ct = 0; ct < CTN; ++ct)
+                        acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[ct], bfrag, acc[i][ct], 0, 0, 0);
                 }
             }
         } else {
             // ---- fp32: 64 steps of 4 pixels; lane (li, lg) supplies pixel 4*step + lg
             int colofs[NKW];
 #pragma unroll
-            for (int i = 0; i < NKW; ++i) {
-                const int nkt = wave + 4 * i;
-                int e = 0;
-                if (nkt < a.NKT) {
-                    e = tab[nkt * 4 + (li >> 2)];
-                    e += (li & 3) * 4;
-                }
-                colofs[i] = e;
-            }
+            for (int i = 0; i < NKW; ++i) colofs[i] = tab[(wave + 4 * i) * 4 + (li >> 2)] + (li & 3) * 4;
             for (int step = 0; step < 64; ++step) {
                 const int m = step * 4 + lg;
                 float afrag[CTN];
@@ -222,15 +213,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
                 const int pb = (((m >> 4) * d.stride) * a.TIW + (m & 15) * d.stride) * a.PSx;
 #pragma unroll
                 for (int i = 0; i < NKW; ++i) {
-                    const int nkt = wave + 4 * i;
-                    if (nkt < a.NKT) {
-                        const int e = colofs[i];
-                        const int o = (e & TAB_ABS) ? (e & ~TAB_ABS) : pb + e;
-                        const float bv = *reinterpret_cast<const float*>(smem + o);
+                    const int e = colofs[i];
+                    const int o = (e & TAB_ABS) ? (e & ~TAB_ABS) : pb + e;
+                    const float bv = *reinterpret_cast<const float*>(smem + o);
 #pragma unroll
-                        for (int ct = 0; ct < CTN; ++ct)
-                            acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ct], bv, acc[i][ct], 0, 0, 0);
-                    }
+                    for (int ct = 0; ct < CTN; ++ct)
+                        acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ct], bv, acc[i][ct], 0, 0, 0);
                 }
             }
         }
