@@ -228,7 +228,10 @@ __global__ __launch_bounds__((WLeanCfg<T, C8, CO8, KS, DIL, STRIDE>::NTH)) void 
         } else if constexpr (sizeof(T) == 2) {
             const int q = li >> 2, p = li & 3;
             constexpr int NBLK = Cfg::W2 ? 4 : 8;
-#pragma unroll
+            // 64 -> 64 3x3 (160 accumulator registers of the 256 a wave of a 512-thread group has): unrolled over the pixel
+            // blocks the scheduler hoists the next block's fragment reads and spills 98 registers (20 -> 52 us); rolled: 243, none
+            constexpr int UNR = NKW * CTN >= 40 ? 1 : NBLK;
+#pragma unroll UNR
             for (int bq = 0; bq < NBLK; ++bq) {
                 const int blk = Cfg::W2 ? wset * 4 + bq : bq;
                 // pixels m0 = blk*32 + lg*8 + q (+4): row = blk*2 + (lg>>1), col = (lg&1)*8 + q (+4)
