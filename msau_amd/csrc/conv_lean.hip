@@ -265,27 +265,37 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
             if (ox0 + lr < d.Wout) {
                 const long long off0 = ((long long)(b * d.Hout + oyw)) * a.out_row + (long long)ox0 * a.out_px +
                                        lr * a.out_px + (lg & 1) * (CT * 4) * ESZ;
+                // operand loads of all four rows first, then arithmetic and stores: with load -> wait -> store per row (the
+                // stores may alias the next row's loads as far as the compiler knows) a launch paid up to 4 x 3 memory
+                // round trips in a row at the end of every tile
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
+                    V4 r_add[4], r_acc[4], r_mb[4];
+#pragma unroll
+                    for (int pt = 0; pt < 4; ++pt) {
+                        if (oyw + pt < d.Hout) {                   // scalar
+                            const long long o = off0 + ct * 4 * ESZ + (long long)pt * a.out_row;
+                            if (lfl & MSAU_CONV_ADD) r_add[pt] = *reinterpret_cast<const V4*>(ad + o);
+                            if (lfl & MSAU_CONV_ACCUM) r_acc[pt] = *reinterpret_cast<const V4*>(yb + o);
+                            if (lfl & MSAU_CONV_MASK_B) r_mb[pt] = *reinterpret_cast<const V4*>(mb + o);
+                        }
+                    }
 #pragma unroll
                     for (int pt = 0; pt < 4; ++pt) {
                         if (oyw + pt < d.Hout) {                   // scalar
                             const long long o = off0 + ct * 4 * ESZ + (long long)pt * a.out_row;
                             f32x4 v = acc[ct][pt] + bv[ct];
                             if (lfl & MSAU_CONV_ADD) {
-                                V4 r = *reinterpret_cast<const V4*>(ad + o);
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                                for (int j = 0; j < 4; ++j) v[j] += (float)r_add[pt][j];
                             }
                             if (lfl & MSAU_CONV_ACCUM) {
-                                V4 r = *reinterpret_cast<const V4*>(yb + o);
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                                for (int j = 0; j < 4; ++j) v[j] += (float)r_acc[pt][j];
                             }
                             if (lfl & MSAU_CONV_MASK_B) {
-                                V4 m = *reinterpret_cast<const V4*>(mb + o);
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : 0.f;
+                                for (int j = 0; j < 4; ++j) v[j] = ((float)r_mb[pt][j] > 0.f) ? v[j] : 0.f;
                             }
                             V4 ov;
 #pragma unroll
