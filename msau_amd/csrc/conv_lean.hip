@@ -91,13 +91,6 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks)
                 afr[ct][ks] = load8<T>(wp + ((size_t)(ks / NKSH) * (CT * 16) + ct * 16 + lr) * a.kchunk + (ks % NKSH) * 32 + lg * 8);
-    } else {
-        unsigned char* lds_w = smem + Cfg::IN_BYTES;
-        constexpr int WG8 = NKSH * 4;                          // 8-element groups per (chunk, row)
-        for (int idx = tid; idx < Cfg::NCH * CT * 16 * WG8; idx += NT) {
-            int r = idx / WG8, g8 = idx - r * WG8;             // r = chunk * rows + row: the packed image order
-            *reinterpret_cast<V8*>(lds_w + r * Cfg::WS + g8 * 8 * ESZ) = load8<T>(wp + (size_t)r * a.kchunk + g8 * 8);
-        }
     }
 
     // ---- per-lane LDS offsets of the k-groups this lane feeds (lane group lg of every k-step)
@@ -220,6 +213,34 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
         tstep = gridDim.x >> 3;
     }
     if (PIPE && tile0 < tend) issue_loads(tile0);
+    if constexpr (!Cfg::WREG) {
+        // weights -> LDS, behind the first tile's loads and up to 8 loads in flight per thread.  As a plain loop this was
+        // load -> wait -> write per 256 x 16 bytes BEFORE the first tile was even requested: 3 (32 -> 16 rows, 3x3) to 18
+        // (64 -> 64) serial memory round trips at the head of kernels that run 5-10 us in all.
+        unsigned char* lds_w = smem + Cfg::IN_BYTES;
+        constexpr int WG8 = NKSH * 4;                          // 8-element groups per (chunk, row)
+        constexpr int WTOT = Cfg::NCH * CT * 16 * WG8, NWIT = (WTOT + NT - 1) / NT, WB = NWIT < 8 ? NWIT : 8;
+#pragma unroll
+        for (int it0 = 0; it0 < NWIT; it0 += WB) {
+            V8 wr[WB];
+#pragma unroll
+            for (int j = 0; j < WB; ++j) {
+                const int idx = tid + (it0 + j) * NT;
+                if (it0 + j < NWIT && idx < WTOT) {
+                    const int r = idx / WG8, g8 = idx - r * WG8;   // r = chunk * rows + row: the packed image order
+                    wr[j] = load8<T>(wp + (size_t)r * a.kchunk + g8 * 8);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < WB; ++j) {
+                const int idx = tid + (it0 + j) * NT;
+                if (it0 + j < NWIT && idx < WTOT) {
+                    const int r = idx / WG8, g8 = idx - r * WG8;
+                    *reinterpret_cast<V8*>(lds_w + r * Cfg::WS + g8 * 8 * ESZ) = wr[j];
+                }
+            }
+        }
+    }
 
     for (int tile = tile0; tile < tend; tile += tstep) {
         int b, oy0, ox0;
