@@ -116,6 +116,8 @@ struct ConvArgs {
     int TIH, TIW, PS, WS;
     int in_bytes, w_bytes;
     int tiles_x, tiles_y;
+    int ct_total, rows_total;                    // channel tiles / packed rows of the whole (slice of the) conv; a workgroup takes CT of
+                                                 // them, blockIdx.y picks which (row split: see msau_conv2d)
 };
 
 template <typename T, int CT, int PT>
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     constexpr int TH = 4 * PT;
+    const int ct0 = blockIdx.y * CT, CTT = a.ct_total;           // this workgroup's channel tiles [ct0, ct0 + CT) of CTT
 
     int bid = blockIdx.x;
     const int txi = bid % a.tiles_x; bid /= a.tiles_x;
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
             *reinterpret_cast<V8*>(lds_in + pix * a.PS + cg * 8 * (int)sizeof(T)) = v;
         }
         // ---- stage this chunk's packed weights: global [chunk][row][kchunk] -> LDS rows of WS bytes
-        const T* wsrc = wp + (size_t)chunk * rows * a.kchunk;
+        const T* wsrc = wp + ((size_t)chunk * a.rows_total + ct0 * 16) * a.kchunk;
         for (int idx = tid; idx < rows * wg_per_row; idx += 256) {
             int r = idx / wg_per_row, g8 = idx - r * wg_per_row;
             *reinterpret_cast<V8*>(lds_w + r * a.WS + g8 * 8 * (int)sizeof(T)) = load8<T>(wsrc + (size_t)r * a.kchunk + g8 * 8);
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
         const size_t pbase = (((size_t)b * d.Hout + oy) * d.Wout + ox) * a.ystride;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            const int co = lg * (CT * 4) + ct * 4;
+            const int co = lg * (CTT * 4) + (ct0 + ct) * 4;
             if (co >= Cout) continue;
             f32x4 v = acc[ct][pt];
             if (d.bias) {
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
 }
 
 template <typename T, int CT, int PT>
-int launch_conv(hipStream_t s, const ConvArgs& a, int nblocks, int lds) {
+int launch_conv(hipStream_t s, const ConvArgs& a, int nblocks, int nsplit, int lds) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, CT, PT>),
@@ -287,27 +290,27 @@ int launch_conv(hipStream_t s, const ConvArgs& a, int nblocks, int lds) {
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_kernel<T, CT, PT>), dim3(nblocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_kernel<T, CT, PT>), dim3(nblocks, nsplit), dim3(256), lds, s, a);
     MSAU_CHECK_LAUNCH("conv_kernel");
     return 0;
 }
 
 template <typename T, int CT>
-int launch_conv_pt(hipStream_t s, const ConvArgs& a, int PT, int nblocks, int lds) {
+int launch_conv_pt(hipStream_t s, const ConvArgs& a, int PT, int nblocks, int nsplit, int lds) {
     switch (PT) {
-        case 4: return launch_conv<T, CT, 4>(s, a, nblocks, lds);
-        case 2: return launch_conv<T, CT, 2>(s, a, nblocks, lds);
-        default: return launch_conv<T, CT, 1>(s, a, nblocks, lds);
+        case 4: return launch_conv<T, CT, 4>(s, a, nblocks, nsplit, lds);
+        case 2: return launch_conv<T, CT, 2>(s, a, nblocks, nsplit, lds);
+        default: return launch_conv<T, CT, 1>(s, a, nblocks, nsplit, lds);
     }
 }
 
 template <typename T>
-int launch_conv_ct(hipStream_t s, const ConvArgs& a, int CT, int PT, int nblocks, int lds) {
+int launch_conv_ct(hipStream_t s, const ConvArgs& a, int CT, int PT, int nblocks, int nsplit, int lds) {
     switch (CT) {
-        case 1: return launch_conv_pt<T, 1>(s, a, PT, nblocks, lds);
-        case 2: return launch_conv_pt<T, 2>(s, a, PT, nblocks, lds);
-        case 4: return launch_conv_pt<T, 4>(s, a, PT, nblocks, lds);
-        default: return launch_conv_pt<T, 8>(s, a, PT, nblocks, lds);
+        case 1: return launch_conv_pt<T, 1>(s, a, PT, nblocks, nsplit, lds);
+        case 2: return launch_conv_pt<T, 2>(s, a, PT, nblocks, nsplit, lds);
+        case 4: return launch_conv_pt<T, 4>(s, a, PT, nblocks, nsplit, lds);
+        default: return launch_conv_pt<T, 8>(s, a, PT, nblocks, nsplit, lds);
     }
 }
 
@@ -419,6 +422,14 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
     if (d->flags & MSAU_CONV_DOUT) return msau_set_error(MSAU_ERR_ARG, "conv2d: DOUT launch was not taken by a lean instance");
     MSAU_CHECK_ARG(g.nslices == 1 || !(d->flags & MSAU_CONV_HEAD), "conv2d: HEAD with more than 128 output channels");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // row split: with few pixel tiles (the 21 x 16 and 11 x 8 pixel levels of the reference's constructor defaults: 48-96
+    // tiles for 256 CUs) a workgroup takes only `cts` of the CT channel tiles and blockIdx.y the rest -- every workgroup
+    // staged all 128 rows of every K chunk (147 KB per chunk at 64 channels x 3x3) for 16 pixels of work per wave: 60 us per
+    // launch for a 0.3 MB tensor.  The packed image and the channel order do not change.
+    static const int split_wgs = getenv("MSAU_CONV_ROWSPLIT") ? atoi(getenv("MSAU_CONV_ROWSPLIT")) : 768;    // workgroups aimed for; 0 = off
+    int cts = g.CT;
+    while (cts > 1 && nb * g.nslices * (g.CT / cts) < split_wgs) cts >>= 1;
+    const int w_bytes = roundup(cts * 16 * t.WS, 16), lds_total = t.in_bytes + w_bytes + t.tab_bytes;
     for (int sl = 0; sl < g.nslices; ++sl) {
         ConvArgs a;
         a.d = *d;
@@ -435,9 +446,11 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
             if (d->mask_b) a.d.mask_b = static_cast<const char*>(d->mask_b) + co0 * esz;
         }
         a.cch = g.cch; a.nchunks = g.nchunks; a.kchunk = g.kchunk; a.ngroups = g.ngroups;
-        a.TIH = t.TIH; a.TIW = t.TIW; a.PS = t.PS; a.WS = t.WS; a.in_bytes = t.in_bytes; a.w_bytes = t.w_bytes;
+        a.TIH = t.TIH; a.TIW = t.TIW; a.PS = t.PS; a.WS = t.WS; a.in_bytes = t.in_bytes; a.w_bytes = w_bytes;
         a.tiles_x = cdiv(d->Wout, 16); a.tiles_y = cdiv(d->Hout, 4 * PT);
-        rc = dtype == MSAU_F32 ? launch_conv_ct<float>(s, a, g.CT, PT, (int)nb, t.total) : launch_conv_ct<bf16_t>(s, a, g.CT, PT, (int)nb, t.total);
+        a.ct_total = g.CT; a.rows_total = g.rows;
+        rc = dtype == MSAU_F32 ? launch_conv_ct<float>(s, a, cts, PT, (int)nb, g.CT / cts, lds_total)
+                               : launch_conv_ct<bf16_t>(s, a, cts, PT, (int)nb, g.CT / cts, lds_total);
         if (rc) return rc;
     }
     return 0;
