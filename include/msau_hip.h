@@ -180,6 +180,15 @@ typedef struct {
 } msau_conv_pair_desc;
 int msau_conv_pair_applicable(int dtype, const msau_conv_pair_desc* d);
 int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc* d);
+/* bytes of ONE mask plane (bits_mid or bits_a) for this descriptor's shape.  The planes are private between the forward and
+ * the backward launch of one residual block and their layout follows the instance that takes the shape: a byte per
+ * (pixel, 8-channel group) for the tile kernels (conv_pair.hip), 32 bytes of lane ballots per (row, 30-column strip) for the
+ * row-streaming 8-channel bf16 kernel (conv_rows.hip).  Allocate with this, never from the layout comment above. */
+int64_t msau_conv_pair_bits_bytes(int dtype, const msau_conv_pair_desc* d);
+/* The library reads its MSAU_* environment switches once.  msau_reload_env() makes the row-streaming kernel's switches
+ * (MSAU_PAIR_ROWS, MSAU_ROWS_SH, MSAU_ROWS_WAVES, MSAU_ROWS_MIN_TASKS) be read again on the next call: for tests and A/B
+ * tools that change them inside one process. */
+void msau_reload_env(void);
 
 /* ------------------------------------------------------------------------------------------
  * Weight / bias gradient of the same convolution (autograd of torch.nn.Conv2d reached from

@@ -116,6 +116,8 @@ _SIGNATURES = {
     "msau_conv2d_launch_info": (C.c_int, [C.c_int, C.POINTER(ConvDesc), C.POINTER(i32)]),
     "msau_conv_pair_applicable": (C.c_int, [C.c_int, C.POINTER(ConvPairDesc)]),
     "msau_conv_pair": (C.c_int, [vp, C.c_int, C.POINTER(ConvPairDesc)]),
+    "msau_conv_pair_bits_bytes": (C.c_int64, [C.c_int, C.POINTER(ConvPairDesc)]),
+    "msau_reload_env": (None, []),
     "msau_wgrad_geometry": (C.c_int, [C.c_int, C.POINTER(WgradDesc), C.POINTER(WgradGeom)]),
     "msau_conv2d_wgrad": (C.c_int, [vp, C.c_int, C.POINTER(WgradDesc)]),
     "msau_conv2d_wgrad_groupable": (C.c_int, [C.c_int, C.POINTER(WgradDesc), C.POINTER(WgradDesc)]),

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmsau_hip.so")
-SOURCES = ["pack.hip", "conv.hip", "conv_lean.hip", "conv_pair.hip", "conv_wgrad.hip", "wgrad_lean.hip", "elementwise.hip", "attention.hip", "attention_mfma.hip", "raster.hip", "boxconv.hip", "sequence.hip"]
+SOURCES = ["pack.hip", "conv.hip", "conv_lean.hip", "conv_pair.hip", "conv_rows.hip", "conv_wgrad.hip", "wgrad_lean.hip", "elementwise.hip", "attention.hip", "attention_mfma.hip", "raster.hip", "boxconv.hip", "sequence.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"] + os.environ.get("MSAU_EXTRA_HIPCC_FLAGS", "").split() + [
          "-ffp-contract=fast"]
 
@@ -20,7 +20,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # packed ops, 0 of 24 without); neither the IEEE division, nor the library sqrt sequences, nor the transcendental unit
 # (a VALU-only Newton variant deviated just the same) were the cause.  DESIGN.md section 2.  The host pass of hipcc prints
 # "'-packed-fp32-ops' is not a recognized feature" for it: harmless, the flag is for the gfx950 pass.
-EXTRA_FLAGS = {"elementwise.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
+EXTRA_FLAGS = {"elementwise.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
+               # MFMA results straight into VGPRs (gfx950 has one unified file): without it the row kernel's accumulators live in
+               # AGPRs and every epilogue starts with four v_accvgpr_read
+               "conv_rows.hip": (["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.environ.get("MSAU_ROWS_VGPR_FORM", "1") != "0" else [])
+                                + (["-DMSAU_ROWS_KEEPALIVE"] if os.environ.get("MSAU_ROWS_KEEPALIVE", "0") == "1" else [])}
 
 
 def _stale(target, deps):

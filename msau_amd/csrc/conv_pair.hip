@@ -516,12 +516,25 @@ extern "C" int msau_conv_pair_applicable(int dtype, const msau_conv_pair_desc* d
     if (fwd && (d->flags2 & MSAU_CONV_POOL) && !d->pool_y) return 0;
     if (!fwd && !bwd) return 0;
     if (d->add != d->x) return 0;                                  // the ADD operand is read back from the input tile
+    if (msau_rowpair_takes(dtype, d)) return 1;                    // 8 channels, bf16: the row-streaming kernel (conv_rows.hip)
     const int esz = dtype == MSAU_F32 ? 4 : 2;
     if ((int64_t)d->H * d->W * d->C * esz >= (1ll << 31)) return 0;             // 32-bit lane offsets inside an image
     const int tw = pair_tw(dtype, d);
     const int64_t tiles = (int64_t)d->B * cdiv(d->H, 14) * cdiv(d->W, 16 * tw - 2);
     if (tiles < 64 || tiles >= (1 << 20)) return 0;                            // small launches: the one-conv kernels
+    if (cdiv(d->H, 14) >= 4096 || cdiv(d->W, 16 * tw - 2) >= 4096) return 0;   // the tile decode (__umulhi) is exact below 2^12 tiles per axis
     return 1;
+}
+
+// bytes of ONE ReLU-mask plane (bits_mid / bits_a) for this descriptor: the tile kernels keep a byte per (pixel, 8-channel
+// group), the row-streaming kernel 32 bytes of lane ballots per (row, 30-column strip)
+extern "C" int64_t msau_conv_pair_bits_bytes(int dtype, const msau_conv_pair_desc* d) {
+    if (!d || d->C <= 0 || d->B <= 0 || d->H <= 0 || d->W <= 0) return 0;
+    msau_conv_pair_desc probe = *d;                                // "would it take this shape once it has planes?"
+    uint8_t one = 0;
+    probe.bits_mid = probe.bits_a = &one;
+    if (msau_rowpair_takes(dtype, &probe)) return msau_rowpair_plane_bytes(d);
+    return (int64_t)d->B * d->H * d->W * (d->C / 8);
 }
 
 extern "C" int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc* d) {
@@ -532,6 +545,7 @@ extern "C" int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc
     MSAU_CHECK_ARG(!bwd || (d->mask_mid && d->mask_a) || (d->bits_mid && d->bits_a), "conv_pair: backward without mask_mid / mask_a (tensors or bit planes)");
     MSAU_CHECK_ARG(!d->bits_mid == !d->bits_a, "conv_pair: bits_mid and bits_a come together");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (msau_rowpair_takes(dtype, d)) return msau_rowpair_launch(s, d);
     const int esz = dtype == MSAU_F32 ? 4 : 2;
     PairArgs a;
     a.d = *d;

@@ -1,0 +1,354 @@
+// Row-streaming form of the residual pair for the 8-channel layers (bf16): the two chained 3x3 SAME convs of
+// MultiConvResidualBlock (model/model.py:37-50) and their two data gradients, the same arithmetic as conv_pair.hip
+// (msau_conv_pair), restructured around what that kernel's counters showed (profiles/r02_pmc_conv_pair.txt: no wasted HBM
+// traffic, LDS 42 % busy, waves parked 41 % of the time, half of every MFMA padding):
+//
+//  * pixel-pair packing.  With 8 output channels a 16-row MFMA tile is half empty.  Here the 16 rows are (pixel parity p,
+//    channel co) and the 16 columns are pixel PAIRS (x = 2j + p): the pair reads a 3 x 4 x 8 = 96-element window, exactly
+//    the three 32-deep k-steps the 72 -> 96 padded K cost before, so the same three MFMAs give 32 pixels x 8 channels
+//    instead of 16 x 8.  A[(p, co)][(ky, kx4, ci)] = W[co][ci][ky][kx4 - p] (zero where kx4 - p is not a tap); it is built
+//    in registers from the image msau_pack_params already writes (one 16-byte load per k-step and lane), no new pack kind.
+//    Every lane of the result holds 4 channels of ONE pixel: no idle epilogue lanes, 8-byte stores, 512 contiguous bytes
+//    per wave-instruction.
+//  * a wave owns its tile; no workgroup barrier anywhere.  A wave walks down a strip of 30 output columns (32 lattice
+//    columns = 16 pixel pairs, 34 input columns) one image row at a time.  The B fragment of k-step ky is "pixel
+//    2*lr + lg of input row y + ky" -- a shape a global load can deliver directly, and the SAME registers serve as
+//    ky = 2, 1, 0 of three consecutive rows: one 16-byte load per lane and row (three rows ahead), no LDS staging of the
+//    input at all.  The intermediate row goes through LDS once (8-byte write in the result layout, 16-byte read in the
+//    fragment layout; LDS operations of one wave execute in order, so no barrier) and is then carried in registers the
+//    same way.  The residual operand (the input tensor itself) is fetched from the fragment registers of neighbour lanes
+//    with two ds_bpermute.  Per row and wave: 1 load, 2 stores, 6 MFMAs, 1 LDS write, 1 LDS read, 2 permutes.
+//    Waves drift apart and cover each other's latency.  The vertical halo is two rows per SEGMENT of rows.
+//  * the ReLU masks travel as BALLOTS: the forward stores, per (row, strip), the four 64-bit lane masks (v[jj] > 0) of its
+//    epilogue registers -- 32 bytes; the backward has the same lanes in the same places, loads the 32 bytes as scalars
+//    and applies them with v_cndmask on an SGPR pair: one VALU instruction per element, no bit extraction.
+//
+// Tasks are (image, row segment, strip); four horizontally adjacent strips share a workgroup (their column halos hit in
+// L1 / L2), consecutive workgroups of one XCD take consecutive tasks.
+#include "msau_common.h"
+#include <cstdlib>
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
+constexpr unsigned kOOB = 0x80000000u;
+
+constexpr int OW = 30, XW = 34;                   // output / input columns of a strip (lattice: 32)
+constexpr int MP = XW * 16;                       // an intermediate row in LDS: 34 pixels x 8 bf16
+constexpr int WAVE_LDS = 2 * MP;                  // two alternating slots per wave
+constexpr int UNR = 6;                            // rows per loop body: 3 rows in use + 3 in flight, all statically named
+
+struct RowArgs {
+    msau_conv_pair_desc d;
+    int nstrips, nseg, SH, ntasks, tasks_per_xcd;
+    int row_bytes;
+    unsigned img_bytes, plane_img;                // bytes of one image / of one image's ballot plane (H * nstrips * 32)
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+// v = lane's bit of `mask` ? a : 0 -- the mask is a wave-uniform 64-bit value in an SGPR pair: one v_cndmask_b32 with the
+// pair as its condition.  (A hand-written `asm("v_cndmask_b32 %0, 0, %1, %2")` computed wrong results here: the compiler
+// re-used one SGPR pair for consecutive masks and an s_cselect overwrote it right behind the v_cndmask that still read it;
+// the builtin leaves the scheduling and the hazards to the compiler.)
+__device__ __forceinline__ float keep_if(float a, u64 mask) {
+    return __builtin_amdgcn_inverse_ballot_w64(mask) ? a : 0.f;
+}
+__device__ __forceinline__ bf16x8 relu_bits(u32x4 v) { return relu8<bf16_t>(__builtin_bit_cast(bf16x8, v)); }
+template <int I> struct IC { static constexpr int value = I; };
+
+template <bool BWD, bool BITS>
+__global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
+    __shared__ __align__(16) unsigned char smem[4 * WAVE_LDS];
+    const msau_conv_pair_desc& d = a.d;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tloc = (blockIdx.x >> 3) * 4 + wave;
+    const int task = (blockIdx.x & 7) * a.tasks_per_xcd + tloc;
+    if (tloc >= a.tasks_per_xcd || task >= a.ntasks) return;              // wave-uniform; there is no barrier below
+    const int t1 = task / a.nstrips, strip = task - t1 * a.nstrips;
+    const int b = t1 / a.nseg, seg = t1 - b * a.nseg;
+    const int H = d.H, W = d.W;
+    const int x0 = strip * OW;
+    const int y0 = seg * a.SH, y1 = min(H, y0 + a.SH);
+
+    unsigned char* mr = smem + wave * WAVE_LDS;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int c0 = (lg & 1) * 4;                                          // this lane's 4 channels ...
+    const int j = 2 * lr + (lg >> 1);                                     // ... of lattice (phase 1) / output (phase 2) column j
+    const int q = 2 * lr + lg;                                            // B fragment: pixel q of a 34-pixel row
+    unsigned char* mwr = mr + j * 16 + c0 * 2;                            // result layout slot in an intermediate row
+    const unsigned char* mrd = mr + q * 16;                               // fragment layout slot
+
+    // ---- A fragments of both convs, in registers for the whole task
+    bf16x8 A1[3], A2[3];
+    {
+        const int co = lr & 7, kx = lg - (lr >> 3);
+        const bool tap = kx >= 0 && kx <= 2;
+        const bf16_t* w1 = static_cast<const bf16_t*>(d.w1) + co * 96 + (tap ? kx : 0) * 8;
+        const bf16_t* w2 = static_cast<const bf16_t*>(d.w2) + co * 96 + (tap ? kx : 0) * 8;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            A1[ky] = tap ? load8<bf16_t>(w1 + ky * 24) : zero8<bf16_t>();
+            A2[ky] = tap ? load8<bf16_t>(w2 + ky * 24) : zero8<bf16_t>();
+        }
+    }
+    f32x4 bias1 = {0.f, 0.f, 0.f, 0.f}, bias2 = bias1;
+    if constexpr (!BWD) {
+        if (d.b1) bias1 = *reinterpret_cast<const f32x4*>(d.b1 + c0);
+        if (d.b2) bias2 = *reinterpret_cast<const f32x4*>(d.b2 + c0);
+    }
+
+    const long long img = (long long)b * a.img_bytes;
+    const __amdgpu_buffer_rsrc_t rx = rsrc_of(static_cast<const char*>(d.x) + img, a.img_bytes);
+    const __amdgpu_buffer_rsrc_t rmid = rsrc_of(static_cast<char*>(d.mid) + img, a.img_bytes);
+    const __amdgpu_buffer_rsrc_t ry = rsrc_of(static_cast<char*>(d.y) + img, a.img_bytes);
+    const __amdgpu_buffer_rsrc_t rbm = rsrc_of(BITS ? d.bits_mid + (long long)b * a.plane_img : nullptr, BITS ? a.plane_img : 0u);
+    const __amdgpu_buffer_rsrc_t rba = rsrc_of(BITS ? d.bits_a + (long long)b * a.plane_img : nullptr, BITS ? a.plane_img : 0u);
+
+    // input row r in fragment layout: this lane's pixel is x0 - 2 + q; outside the image the offset is out of range -> 0
+    const int lx = x0 - 2 + q;
+    const unsigned lcol = (unsigned)lx < (unsigned)W ? (unsigned)(lx * 16) : kOOB;
+    const int ylast = min(H - 1, y1 + 1);                                 // last input row this task reads
+    auto load_row = [&](int r) -> u32x4 {
+        const bool ok = r >= 0 && r <= ylast;
+        return __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)(r * a.row_bytes) + lcol : kOOB, 0, 0);
+    };
+    // per-lane constants of the two epilogues
+    const int xl = x0 - 1 + j;                                            // image column of lattice column j
+    const float col_lim = (unsigned)xl < (unsigned)W ? INFINITY : 0.f;    // med3(v, 0, lim): ReLU inside the image, 0 outside
+    const unsigned mid_col = (j >= 1 && j <= OW && xl < W) ? (unsigned)(xl * 16 + c0 * 2) : kOOB;
+    const unsigned out_col = (j < OW && x0 + j < W) ? (unsigned)((x0 + j) * 16 + c0 * 2) : kOOB;
+    const unsigned bal_off = lane < 8 ? (unsigned)(strip * 32 + lane * 4) : kOOB;
+    const int plane_pitch = a.nstrips * 32;
+    // the residual operand x(t, x0 + j), channels c0..c0+3, is pixel j + 2 of the input row: lanes with lg < 2 offer dwords
+    // 0,1 (channels 0..3) of their pixel, lanes with lg >= 2 dwords 2,3; this lane fetches from the holder of its half
+    const bool offer_hi = lg >= 2;
+    const int res_src = ((lg & 1) ? lr + 16 * (2 + (lg >> 1)) : min(lr + 1, 15) + 16 * (lg >> 1)) * 4;
+
+    // lanes 0..7 carry the eight dwords of a row's four ballots to memory: v_writelane puts a scalar into one lane of a
+    // vector register (one VALU instruction per dword, straight-line; a `lane == k ? ... : ...` chain compiles to branches).
+    // No hazard to pad: the lane select is an immediate, and the s_nop covers a ballot written by the VALU just before.
+    auto lane_word = [&](const u64 (&bal)[4]) -> unsigned {
+        unsigned w = 0;
+        asm volatile("s_nop 1\n\t"
+                     "v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
+                     "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %8, 7"
+                     : "+v"(w)
+                     : "s"((unsigned)bal[0]), "s"((unsigned)(bal[0] >> 32)), "s"((unsigned)bal[1]), "s"((unsigned)(bal[1] >> 32)),
+                       "s"((unsigned)bal[2]), "s"((unsigned)(bal[2] >> 32)), "s"((unsigned)bal[3]), "s"((unsigned)(bal[3] >> 32)));
+        return w;
+    };
+
+    // ballot words of the backward: scalar loads from the planes (constant address space -> s_load_dwordx8)
+    typedef const __attribute__((address_space(4))) u64* cu64p;
+    const unsigned long long pm0 = BWD ? (unsigned long long)(d.bits_mid + (long long)b * a.plane_img + strip * 32) : 0ull;
+    const unsigned long long pa0 = BWD ? (unsigned long long)(d.bits_a + (long long)b * a.plane_img + strip * 32) : 0ull;
+    auto plane_row = [&](unsigned long long base, int r) -> cu64p {
+        const int rc = r < 0 ? 0 : (r >= H ? H - 1 : r);                  // rows outside the image: any valid row, the masks are cleared
+        return (cu64p)(base + (unsigned long long)(rc * plane_pitch));
+    };
+
+    // X[k]: input rows in fragment layout (raw until first used, ReLU'd after that in the forward); at iteration I row t + k
+    // lives in X[(I + k) % 6].  RS[k % 3]: the half of the RAW pixel this lane offers as residual operand.  M[k % 3]:
+    // intermediate rows in fragment layout.
+    u32x4 X[UNR];
+    u32x2 RS[3];
+    bf16x8 M[3];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) X[k] = load_row(y0 - 2 + k);
+    auto first_use = [&](u32x4& x, u32x2& rs) {
+        rs = offer_hi ? u32x2{x[2], x[3]} : u32x2{x[0], x[1]};
+        if constexpr (!BWD) x = __builtin_bit_cast(u32x4, relu_bits(x));                            // MSAU_PAIR_RELU_IN
+    };
+    first_use(X[0], RS[0]);
+    first_use(X[1], RS[1]);
+    // stores the hardware drops: with them the loop is entered in the state its back edge leaves behind (rows t+2..t+4 in
+    // flight, each followed by a row's stores), and the compiler's merged wait before the first rows is the steady-state
+    // vmcnt(9), not vmcnt(1) -- which would wait for ALL rows in flight once per trip
+    constexpr int kStoresPerRow = 2 + (!BWD && BITS ? 2 : 0);
+#pragma unroll
+    for (int k = 0; k < 3 * kStoresPerRow; ++k) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rmid, kOOB + 8u * k, 0, 0);   // (distinct: equal ones are merged)
+    M[0] = M[2] = zero8<bf16_t>();
+    u64 mm[2][4], ma[2][4];                                               // masks of iterations i (slot i & 1), two rows ahead
+    if constexpr (BWD) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            cu64p pm = plane_row(pm0, y0 - 1 + k), pa = plane_row(pa0, y0 - 2 + k);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) { mm[k][jj] = pm[jj]; ma[k][jj] = pa[jj]; }
+        }
+    }
+
+    // one image row: t = tg + I; every register array index below is a compile-time constant
+    auto step = [&](auto ic, const int tg) {
+        constexpr int I = decltype(ic)::value, P = I & 1;
+        const int t = tg + I, m = t + 1;                                  // output row, intermediate row of this iteration
+        X[(I + 5) % 6] = load_row(t + 5);
+        first_use(X[(I + 2) % 6], RS[(I + 2) % 3]);
+        const bool rowin = (unsigned)m < (unsigned)H;
+        // ================= phase 1: intermediate row m from input rows t, t+1, t+2; lattice columns 0..31 =================
+        {
+            f32x4 acc = bias1;
+            acc = mma8(A1[0], __builtin_bit_cast(bf16x8, X[I % 6]), acc);
+            acc = mma8(A1[1], __builtin_bit_cast(bf16x8, X[(I + 1) % 6]), acc);
+            acc = mma8(A1[2], __builtin_bit_cast(bf16x8, X[(I + 2) % 6]), acc);
+#ifdef MSAU_ROWS_KEEPALIVE
+            asm volatile("" :: "v"(X[I % 6]), "v"(X[(I + 1) % 6]), "v"(X[(I + 2) % 6]));
+#endif
+            f32x4 v;
+            if constexpr (!BWD) {
+                const float lim = rowin ? col_lim : 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) v[jj] = __builtin_amdgcn_fmed3f(acc[jj], 0.f, lim);   // MSAU_PAIR_RELU_MID; zero outside = the second conv's padding
+            } else {
+                const u64 rowmask = rowin ? ~0ull : 0ull;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) v[jj] = keep_if(acc[jj], mm[P][jj] & rowmask);       // MSAU_PAIR_MASK_MID (the planes are zero outside the image)
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) o[jj] = (bf16_t)v[jj];
+            *reinterpret_cast<bf16x4*>(mwr + P * MP) = o;
+            const bool ownrow = m >= y0 && m < y1;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rmid, ownrow ? (unsigned)(m * a.row_bytes) + mid_col : kOOB, 0, 0);
+            if constexpr (!BWD && BITS) {
+                // (mid > 0) as the four lane masks of this row: what the backward's phase 1 applies to the same lanes
+                u64 bal[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) bal[jj] = __builtin_amdgcn_ballot_w64((float)o[jj] > 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(lane_word(bal), rbm, ownrow ? (unsigned)(m * plane_pitch) + bal_off : kOOB, 0, 0);
+            }
+        }
+        M[(I + 1) % 3] = *reinterpret_cast<const bf16x8*>(mrd + P * MP);    // the row just written, in fragment layout
+        // ================= phase 2: output row t from intermediate rows t-1, t, t+1; columns x0 .. x0+29 =================
+        {
+            f32x4 acc = bias2;
+            acc = mma8(A2[0], M[(I + 2) % 3], acc);
+            acc = mma8(A2[1], M[I % 3], acc);
+            acc = mma8(A2[2], M[(I + 1) % 3], acc);
+#ifdef MSAU_ROWS_KEEPALIVE
+            asm volatile("" :: "v"(M[(I + 2) % 3]), "v"(M[I % 3]), "v"(M[(I + 1) % 3]));
+#endif
+            // residual (forward) / other-path gradient (backward): the raw input row t, from the neighbour lanes' registers
+            u32x2 rr;
+            rr[0] = (unsigned)__builtin_amdgcn_ds_bpermute(res_src, (int)RS[I % 3][0]);
+            rr[1] = (unsigned)__builtin_amdgcn_ds_bpermute(res_src, (int)RS[I % 3][1]);
+            const bf16x4 r = __builtin_bit_cast(bf16x4, rr);
+            f32x4 v;
+            if constexpr (!BWD) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) v[jj] = fmaxf(acc[jj] + (float)r[jj], 0.f);   // ADD, RELU_OUT
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) v[jj] = keep_if(acc[jj], ma[P][jj]) + (float)r[jj];   // MASK_A, ADD
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) o[jj] = (bf16_t)v[jj];
+            const bool ownrow = t >= y0 && t < y1;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ry, ownrow ? (unsigned)(t * a.row_bytes) + out_col : kOOB, 0, 0);
+            if constexpr (!BWD && BITS) {
+                u64 bal[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) bal[jj] = __builtin_amdgcn_ballot_w64((float)r[jj] > 0.f);      // (x > 0): MASK_A of the backward
+                __builtin_amdgcn_raw_buffer_store_b32(lane_word(bal), rba, ownrow ? (unsigned)(t * plane_pitch) + bal_off : kOOB, 0, 0);
+            }
+        }
+        if constexpr (BWD) {                                               // masks of iteration t + 2
+            cu64p pm = plane_row(pm0, m + 2), pa = plane_row(pa0, t + 2);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) { mm[P][jj] = pm[jj]; ma[P][jj] = pa[jj]; }
+        }
+        // rows stay in program order: hoisting a later row's MFMAs above this point makes the compiler wait for that row's
+        // load here, i.e. it would give the prefetch distance away
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    for (int tg = y0 - 2; tg < y1; tg += UNR) {
+        step(IC<0>{}, tg);
+        step(IC<1>{}, tg);
+        step(IC<2>{}, tg);
+        step(IC<3>{}, tg);
+        step(IC<4>{}, tg);
+        step(IC<5>{}, tg);
+    }
+}
+
+constexpr int kFwd1 = MSAU_PAIR_RELU_IN | MSAU_PAIR_RELU_MID, kFwd2 = MSAU_CONV_ADD | MSAU_CONV_RELU_OUT;
+constexpr int kBwd1 = MSAU_PAIR_MASK_MID, kBwd2 = MSAU_CONV_MASK_A | MSAU_CONV_ADD;
+
+// environment switches of this file, read once; msau_reload_env() makes the next call read them again (tests, A/B tools)
+struct RowsEnv { int on, sh, waves, min_tasks; };
+RowsEnv g_env;
+bool g_env_ok = false;
+const RowsEnv& rows_env() {
+    if (!g_env_ok) {
+        auto geti = [](const char* n, int dflt) { const char* v = std::getenv(n); return v && *v ? atoi(v) : dflt; };
+        g_env.on = geti("MSAU_PAIR_ROWS", 1);
+        g_env.sh = geti("MSAU_ROWS_SH", 0);                      // rows per segment (0: from MSAU_ROWS_WAVES)
+        g_env.waves = geti("MSAU_ROWS_WAVES", 3072);             // tasks (= waves) per launch to aim for
+        g_env.min_tasks = geti("MSAU_ROWS_MIN_TASKS", 256);
+        g_env_ok = true;
+    }
+    return g_env;
+}
+
+// segment height: a wave takes one task; aim for MSAU_ROWS_WAVES tasks in one round, at least 8 rows each.  Heights of the
+// form 6k - 2 make the row loop (6 rows per trip, two warm-up rows) come out even.
+int segment_rows(int B, int H, int nstrips) {
+    const RowsEnv& e = rows_env();
+    if (e.sh > 0) return e.sh < H ? e.sh : H;
+    int nseg = e.waves / (B * nstrips);
+    if (nseg < 1) nseg = 1;
+    int sh = cdiv(H, nseg);
+    if (sh < 10) sh = 10;
+    sh = cdiv(sh + 2, UNR) * UNR - 2;
+    return sh < H ? sh : H;
+}
+
+}  // namespace
+
+// which msau_conv_pair descriptors the row-streaming kernel takes: 8 channels, bf16, the residual block's forward flag set
+// (with or without ballot planes) or its data-gradient flag set WITH ballot planes
+int msau_rowpair_takes(int dtype, const msau_conv_pair_desc* d) {
+    if (!rows_env().on || dtype != MSAU_BF16 || d->C != 8) return 0;
+    const bool fwd = d->flags1 == kFwd1 && d->flags2 == kFwd2, bwd = d->flags1 == kBwd1 && d->flags2 == kBwd2;
+    if (!fwd && !bwd) return 0;
+    if (bwd && !(d->bits_mid && d->bits_a)) return 0;
+    if (d->add != d->x) return 0;
+    if ((int64_t)d->H * d->W * 16 >= (1ll << 31)) return 0;
+    const int nstrips = cdiv(d->W, OW);
+    if ((int64_t)d->H * nstrips * 32 >= (1ll << 31)) return 0;
+    if ((int64_t)d->B * nstrips * cdiv(d->H, 8) < rows_env().min_tasks) return 0;    // too little work to fill the device: the tile kernels
+    return 1;
+}
+
+extern "C" void msau_reload_env(void) { g_env_ok = false; }
+
+int64_t msau_rowpair_plane_bytes(const msau_conv_pair_desc* d) {
+    return (int64_t)d->B * d->H * cdiv(d->W, OW) * 32;
+}
+
+int msau_rowpair_launch(hipStream_t s, const msau_conv_pair_desc* d) {
+    RowArgs a;
+    a.d = *d;
+    a.nstrips = cdiv(d->W, OW);
+    a.SH = segment_rows(d->B, d->H, a.nstrips);
+    a.nseg = cdiv(d->H, a.SH);
+    a.ntasks = d->B * a.nstrips * a.nseg;
+    a.tasks_per_xcd = roundup(cdiv(a.ntasks, 8), 4);
+    a.row_bytes = d->W * 16;
+    a.img_bytes = (unsigned)d->H * (unsigned)a.row_bytes;
+    a.plane_img = (unsigned)d->H * (unsigned)a.nstrips * 32u;
+    const int grid = 8 * (a.tasks_per_xcd / 4);
+    const bool bwd = d->flags1 == kBwd1, bits = d->bits_mid && d->bits_a;
+    if (bwd) hipLaunchKernelGGL((rowpair_c8_kernel<true, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (bits) hipLaunchKernelGGL((rowpair_c8_kernel<false, true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((rowpair_c8_kernel<false, false>), dim3(grid), dim3(256), 0, s, a);
+    MSAU_CHECK_LAUNCH("rowpair_c8_kernel");
+    return 0;
+}

@@ -16,6 +16,11 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 int msau_set_error(int code, const char* fmt, ...);
 
+// conv_rows.hip: the row-streaming form of msau_conv_pair for the 8-channel bf16 layers (dispatched from conv_pair.hip)
+int msau_rowpair_takes(int dtype, const msau_conv_pair_desc* d);
+int64_t msau_rowpair_plane_bytes(const msau_conv_pair_desc* d);
+int msau_rowpair_launch(hipStream_t s, const msau_conv_pair_desc* d);
+
 #define MSAU_CHECK_ARG(cond, ...)                                   \
     do {                                                            \
         if (!(cond)) return msau_set_error(MSAU_ERR_ARG, __VA_ARGS__); \

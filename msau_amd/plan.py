@@ -555,13 +555,15 @@ class PairOp:
                     self.bdesc = b
                 self.bbytes = 5 * n * esz               # g (also the ADD operand), r1 mask, x0 mask read once; g_r1, dx written once
                 if self.bdesc is not None and os.environ.get("MSAU_PAIR_BITS", "1") != "0":
-                    # the two ReLU masks as bit planes: written by the forward launch, read by the backward launch
-                    self.bits_mid = torch.zeros((P.B, x0.H, x0.W, x0.Cs // 8), dtype=torch.uint8, device=P.device)
+                    # the two ReLU masks as bit planes: written by the forward launch, read by the backward launch; the
+                    # layout (and so the size) belongs to the instance that takes the shape (msau_conv_pair_bits_bytes)
+                    nbits = int(L.load().msau_conv_pair_bits_bytes(P.dtype, C.byref(b)))
+                    self.bits_mid = torch.zeros((nbits,), dtype=torch.uint8, device=P.device)
                     self.bits_a = torch.zeros_like(self.bits_mid)
                     for dsc in (f, b):
                         dsc.bits_mid, dsc.bits_a = _ptr(self.bits_mid), _ptr(self.bits_a)
-                    self.fbytes += 2 * (n // 8)
-                    self.bbytes = 3 * n * esz + 2 * (n // 8)
+                    self.fbytes += 2 * nbits
+                    self.bbytes = 3 * n * esz + 2 * nbits
         self.active = True
 
     def note(self):

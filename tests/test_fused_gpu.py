@@ -129,10 +129,16 @@ def test_relu_masks_as_bit_planes_give_the_same_gradients(monkeypatch, dtype, c,
         PairOp(plan, c1, c2)
         plan.logits = out
         plans.append(plan)
+    monkeypatch.setenv("MSAU_PAIR_ROWS", "0")      # the tile kernels in both modes (the row kernel has its own test below)
+    L.load().msau_reload_env()
     out = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("MSAU_PAIR_BITS", mode)
-        out[mode] = run_graph(build, p, x, gy, dtype)
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MSAU_PAIR_BITS", mode)
+            out[mode] = run_graph(build, p, x, gy, dtype)
+    finally:
+        monkeypatch.undo()
+        L.load().msau_reload_env()
     assert plans[0].pairs[0].bdesc is not None and plans[0].pairs[0].bdesc.bits_mid and not plans[1].pairs[0].bdesc.bits_mid
     for a, b in zip(out["1"], out["0"]):
         if isinstance(a, dict):
@@ -140,6 +146,69 @@ def test_relu_masks_as_bit_planes_give_the_same_gradients(monkeypatch, dtype, c,
                 assert torch.equal(a[n], b[n]), n
         elif a is not None:
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("hw,B,sh", [((57, 61), 3, 0), ((71, 250), 2, 0), ((33, 30), 2, 10), ((16, 91), 2, 4), ((90, 29), 2, 16), ((64, 64), 2, 22)])
+def test_row_streaming_pair_matches_the_tile_kernels_and_the_oracle(monkeypatch, hw, B, sh):
+    """conv_rows.hip (8 channels, bf16: pixel-pair packed MFMA rows, a wave walks a 30-column strip row by row, ReLU masks as
+    lane ballots) against the tile kernels of conv_pair.hip on the same rounded inputs, and both against the fp32 oracle:
+    forward, input gradient, weight / bias gradients; strips that end inside / at / beyond the image edge, segments of
+    every height (MSAU_ROWS_SH), images shorter than one segment."""
+    torch.manual_seed(21)
+    c, (H, W) = 8, hw
+    x = torch.randn(B, c, H, W)
+    p = {"w": 0.2 * torch.randn(c, c, 3, 3), "b": 0.1 * torch.randn(c), "w2": 0.2 * torch.randn(c, c, 3, 3), "b2": 0.1 * torch.randn(c)}
+    gy = torch.randn(B, c, H, W)
+    plans = []
+
+    def build(plan):
+        x0 = plan.x_in
+        r1 = Act(plan, "r1", H, W, c, relu_out=True)
+        c1 = ConvOp(plan, "c1", x0, None, "w", "b", r1, 3, relu_in=True, relu_out=True)
+        out = Act(plan, "out", H, W, c, relu_out=True)
+        c2 = ConvOp(plan, "c2", r1, None, "w2", "b2", out, 3, relu_out=True, fwd_add=x0)
+        c1.bwd_add = out
+        from msau_amd.plan import PairOp
+        PairOp(plan, c1, c2)
+        plan.logits = out
+        plans.append(plan)
+    monkeypatch.setenv("MSAU_ROWS_MIN_TASKS", "1")
+    if sh:
+        monkeypatch.setenv("MSAU_ROWS_SH", str(sh))
+    out = {}
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MSAU_PAIR_ROWS", mode)
+            L.load().msau_reload_env()
+            out[mode] = run_graph(build, p, x, gy, L.BF16)
+    finally:
+        monkeypatch.undo()
+        L.load().msau_reload_env()
+    assert plans[0].pairs[0].active and plans[0].pairs[0].bdesc is not None
+    # the planes follow the instance: 32 bytes of ballots per (row, 30-column strip) against a byte per pixel (small images:
+    # mode "0" has no tile instance either and runs the two convs as separate launches)
+    assert plans[0].pairs[0].bits_mid.numel() == B * H * -(-W // 30) * 32
+    assert not plans[1].pairs[0].active or plans[1].pairs[0].bits_mid.numel() == B * H * W
+    # fp32 reference on the bf16-rounded inputs and weights
+    xr = x.bfloat16().float().requires_grad_(True)
+    pr = {k: v.bfloat16().float().requires_grad_(True) for k, v in p.items()}
+    F = torch.nn.functional
+    r1 = F.relu(F.conv2d(F.relu(xr), pr["w"], pr["b"], padding=1))
+    ref = F.relu(F.conv2d(r1, pr["w2"], pr["b2"], padding=1) + xr)
+    ref.backward(gy.bfloat16().float())
+    for mode in ("1", "0"):
+        y, _, dx, gr = out[mode]
+        assert err(y, ref.detach(), True) < 2e-2, mode
+        assert err(dx, xr.grad, True) < 6e-2, mode
+        for n in p:
+            assert err(gr[n], pr[n].grad, True) < 6e-2, (mode, n)
+    # and against each other: the same products in another summation order, then the same rounding
+    for a, b in zip(out["1"], out["0"]):
+        if isinstance(a, dict):
+            for n in a:
+                assert err(a[n], b[n], True) < 2e-2, n
+        elif a is not None:
+            assert err(a, b, True) < 1e-2
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -43,6 +43,9 @@ for (H, W, Cc) in ((336, 256, 8), (168, 128, 16)):
     rows = max(16, Cc)
     w1 = (torch.randn(rows * kchunk, device=dev) * 0.05).to(torch.bfloat16)
     w2 = (torch.randn(rows * kchunk, device=dev) * 0.05).to(torch.bfloat16)
+    for w_ in (w1, w2):                  # as msau_pack_params writes it: the k padding and the rows beyond C are zero
+        w_.view(rows, kchunk)[:, 9 * Cc:] = 0
+        w_.view(rows, kchunk)[Cc:] = 0
     b1 = torch.zeros(rows, device=dev)
     b2 = torch.zeros(rows, device=dev)
 
@@ -59,7 +62,12 @@ for (H, W, Cc) in ((336, 256, 8), (168, 128, 16)):
         d.mask_b = mask_b.data_ptr() if mask_b is not None else None
         return d
 
-    bits_mid = torch.zeros(B, H, W, Cc // 8, dtype=torch.uint8, device=dev)     # ReLU masks as bit planes, as the plan runs it
+    probe = L.ConvPairDesc()
+    probe.B, probe.H, probe.W, probe.C = B, H, W, Cc
+    probe.flags1, probe.flags2 = L.PAIR_MASK_MID, L.CONV_MASK_A | L.CONV_ADD
+    probe.x = probe.add = g.data_ptr()
+    nbits = int(L.load().msau_conv_pair_bits_bytes(L.BF16, C.byref(probe)))
+    bits_mid = torch.zeros(nbits, dtype=torch.uint8, device=dev)     # ReLU masks as bit planes, as the plan runs it
     bits_a = torch.zeros_like(bits_mid)
 
     def pair_desc(fwd):
@@ -89,6 +97,24 @@ for (H, W, Cc) in ((336, 256, 8), (168, 128, 16)):
         L.check(lib.msau_conv2d(s, L.BF16, C.byref(a)))
         L.check(lib.msau_conv2d(s, L.BF16, C.byref(b)))
 
+    # the fused launches against the two launches they replace (same packed weights, same inputs)
+    def rel(a_, b_):
+        return float((a_.float() - b_.float()).abs().max() / b_.float().abs().max().clamp_min(1e-9))
+    two(f1, f2)
+    torch.cuda.synchronize()
+    r1_ref, out_ref = r1.clone(), out.clone()
+    r1.zero_(); out.zero_()
+    L.check(lib.msau_conv_pair(s, L.BF16, C.byref(pf)))
+    torch.cuda.synchronize()
+    print(f"  check fwd: mid rel {rel(r1, r1_ref):.2e} (equal {bool(torch.equal(r1, r1_ref))}), out rel {rel(out, out_ref):.2e} (equal {bool(torch.equal(out, out_ref))})")
+    r1.copy_(r1_ref)
+    two(d2, d1)
+    torch.cuda.synchronize()
+    gr1_ref, gx_ref = gr1.clone(), gx.clone()
+    gr1.zero_(); gx.zero_()
+    L.check(lib.msau_conv_pair(s, L.BF16, C.byref(pb)))
+    torch.cuda.synchronize()
+    print(f"  check bwd: gmid rel {rel(gr1, gr1_ref):.2e} (equal {bool(torch.equal(gr1, gr1_ref))}), gx rel {rel(gx, gx_ref):.2e} (equal {bool(torch.equal(gx, gx_ref))})")
     res = {}
     res["fwd 2 launches"] = timed(lambda: two(f1, f2))
     res["fwd pair"] = timed(lambda: L.check(lib.msau_conv_pair(s, L.BF16, C.byref(pf))))
