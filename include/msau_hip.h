@@ -157,7 +157,11 @@ int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info8);
  * w1 / w2 are the packed images msau_pack_params writes for a single-source 3x3 conv C -> C (forward or flipped
  * data-gradient image).  msau_conv_pair_applicable: 1 if an instance exists for the shape (C, enough tiles, LDS).
  * ------------------------------------------------------------------------------------------ */
-enum { MSAU_PAIR_RELU_IN = 1, MSAU_PAIR_RELU_MID = 2, MSAU_PAIR_MASK_MID = 4 };
+enum { MSAU_PAIR_RELU_IN = 1, MSAU_PAIR_RELU_MID = 2, MSAU_PAIR_MASK_MID = 4,
+       MSAU_PAIR_TILES = 8 };   /* take the tile kernels (conv_pair.hip) even where the row-streaming kernel has an instance: the
+                                   forward and the backward launch of one block must agree on the layout of the mask planes, so a
+                                   caller whose forward carries a flag only the tile kernels implement (MSAU_CONV_POOL) sets this on
+                                   both descriptors */
 typedef struct {
     int32_t B, H, W, C;
     int32_t flags1, flags2;
@@ -186,7 +190,7 @@ int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc* d);
  * row-streaming 8-channel bf16 kernel (conv_rows.hip).  Allocate with this, never from the layout comment above. */
 int64_t msau_conv_pair_bits_bytes(int dtype, const msau_conv_pair_desc* d);
 /* The library reads its MSAU_* environment switches once.  msau_reload_env() makes the row-streaming kernel's switches
- * (MSAU_PAIR_ROWS, MSAU_ROWS_SH, MSAU_ROWS_WAVES, MSAU_ROWS_MIN_TASKS) be read again on the next call: for tests and A/B
+ * (MSAU_PAIR_ROWS, MSAU_ROWS_SH, MSAU_ROWS_WAVES, MSAU_ROWS_MIN_TASKS, MSAU_ROWS_MAXC) be read again on the next call: for tests and A/B
  * tools that change them inside one process. */
 void msau_reload_env(void);
 

@@ -32,7 +32,7 @@ class ConvPairDesc(C.Structure):
                [(n, vp) for n in ("x", "w1", "b1", "mask_mid", "mid", "w2", "b2", "add", "mask_a", "mask_b", "y", "pool_y", "pool_idx", "bits_mid", "bits_a")]
 
 
-PAIR_RELU_IN, PAIR_RELU_MID, PAIR_MASK_MID = 1, 2, 4
+PAIR_RELU_IN, PAIR_RELU_MID, PAIR_MASK_MID, PAIR_TILES = 1, 2, 4, 8
 
 
 class BoxArgs(C.Structure):

@@ -223,6 +223,9 @@ __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
                 __builtin_amdgcn_raw_buffer_store_b32(lane_word(bal), rbm, ownrow ? (unsigned)(m * plane_pitch) + bal_off : kOOB, 0, 0);
             }
         }
+        // lanes exchange the row through LDS: to the compiler each lane is a thread whose own write and read may not even
+        // overlap, so without this (it emits nothing) the read can be hoisted above the write -- it was, at 16 channels
+        __builtin_amdgcn_wave_barrier();
         M[(I + 1) % 3] = *reinterpret_cast<const bf16x8*>(mrd + P * MP);    // the row just written, in fragment layout
         // ================= phase 2: output row t from intermediate rows t-1, t, t+1; columns x0 .. x0+29 =================
         {
@@ -278,11 +281,286 @@ __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The same walk for the 16-channel layers (level 1).  16 output channels fill the 16 MFMA rows, so columns are 16 single
+// pixels: a strip is 14 output columns (16 lattice, 18 input columns), a lane of the result holds channels 4*lg..4*lg+3 of
+// pixel lr.  K per input row is 3 taps x 16 channels = 6 eight-channel groups, run as two k-steps of 4 groups with the last
+// two groups' weights zero (the MFMA pipe is far from the bound; what matters is that a fragment is ROW-pure and can be
+// carried in registers while its row serves as ky = 2, 1, 0): fragment a = groups (kx 0, 1) x (channels 0-7, 8-15), i.e.
+// lane (lr, lg) holds pixel lr + (lg >> 1), channel group lg & 1; fragment b = kx 2, lane (lr, lg) holds pixel lr + 2,
+// channel group lg & 1 (lanes lg >= 2 meet zero weights; their copy of the pixel is what the residual fetch reads).
+// MSAU_CONV_POOL: rows arrive one at a time, so the 2x2 window is this row and the previous one (kept in registers) of
+// this lane and its neighbour column lr ^ 1 -- strips and segments start at even coordinates; same comparison order and
+// rounded values as msau_maxpool2x2_fwd.
+constexpr int OW16 = 14, XW16 = 18;
+constexpr int MP16 = XW16 * 32;
+constexpr int WAVE_LDS16 = 2 * MP16;
+
+template <bool BWD, bool BITS, bool POOL>
+__global__ __launch_bounds__(256) void rowpair_c16_kernel(const RowArgs a) {
+    static_assert(!(BWD && POOL), "the pooled output belongs to the forward launch");
+    __shared__ __align__(16) unsigned char smem[4 * WAVE_LDS16];
+    const msau_conv_pair_desc& d = a.d;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tloc = (blockIdx.x >> 3) * 4 + wave;
+    const int task = (blockIdx.x & 7) * a.tasks_per_xcd + tloc;
+    if (tloc >= a.tasks_per_xcd || task >= a.ntasks) return;              // wave-uniform; there is no barrier below
+    const int t1 = task / a.nstrips, strip = task - t1 * a.nstrips;
+    const int b = t1 / a.nseg, seg = t1 - b * a.nseg;
+    const int H = d.H, W = d.W;
+    const int x0 = strip * OW16;
+    const int y0 = seg * a.SH, y1 = min(H, y0 + a.SH);
+
+    unsigned char* mr = smem + wave * WAVE_LDS16;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int c0 = lg * 4;                                                // this lane's 4 channels of lattice / output column lr
+    unsigned char* mwr = mr + lr * 32 + c0 * 2;                           // result layout slot in an intermediate row
+    const unsigned char* mrd_a = mr + (lr + (lg >> 1)) * 32 + (lg & 1) * 16;
+    const unsigned char* mrd_b = mr + (lr + 2) * 32 + (lg & 1) * 16;
+    // columns 16, 17 of the intermediate rows are read (by lanes whose outputs are not stored) and never written: not NaN
+    for (int i = lane; i < WAVE_LDS16 / 16; i += 64) *reinterpret_cast<u32x4*>(mr + i * 16) = u32x4{0u, 0u, 0u, 0u};
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- A fragments: [conv][ky][a | b]
+    bf16x8 A1[3][2], A2[3][2];
+    {
+        const int kxa = lg >> 1, cg = lg & 1;
+        const bf16_t* w1 = static_cast<const bf16_t*>(d.w1) + lr * 160 + cg * 8;
+        const bf16_t* w2 = static_cast<const bf16_t*>(d.w2) + lr * 160 + cg * 8;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            A1[ky][0] = load8<bf16_t>(w1 + (ky * 3 + kxa) * 16);
+            A2[ky][0] = load8<bf16_t>(w2 + (ky * 3 + kxa) * 16);
+            A1[ky][1] = lg < 2 ? load8<bf16_t>(w1 + (ky * 3 + 2) * 16) : zero8<bf16_t>();
+            A2[ky][1] = lg < 2 ? load8<bf16_t>(w2 + (ky * 3 + 2) * 16) : zero8<bf16_t>();
+        }
+    }
+    f32x4 bias1 = {0.f, 0.f, 0.f, 0.f}, bias2 = bias1;
+    if constexpr (!BWD) {
+        if (d.b1) bias1 = *reinterpret_cast<const f32x4*>(d.b1 + c0);
+        if (d.b2) bias2 = *reinterpret_cast<const f32x4*>(d.b2 + c0);
+    }
+
+    const long long img = (long long)b * a.img_bytes;
+    const __amdgpu_buffer_rsrc_t rx = rsrc_of(static_cast<const char*>(d.x) + img, a.img_bytes);
+    const __amdgpu_buffer_rsrc_t rmid = rsrc_of(static_cast<char*>(d.mid) + img, a.img_bytes);
+    const __amdgpu_buffer_rsrc_t ry = rsrc_of(static_cast<char*>(d.y) + img, a.img_bytes);
+    const __amdgpu_buffer_rsrc_t rbm = rsrc_of(BITS ? d.bits_mid + (long long)b * a.plane_img : nullptr, BITS ? a.plane_img : 0u);
+    const __amdgpu_buffer_rsrc_t rba = rsrc_of(BITS ? d.bits_a + (long long)b * a.plane_img : nullptr, BITS ? a.plane_img : 0u);
+
+    // input row r in fragment layout (two 16-byte loads per lane); outside the image the offset is out of range -> 0
+    const int lxa = x0 - 2 + lr + (lg >> 1), lxb = x0 - 2 + lr + 2;
+    const unsigned lcol_a = (unsigned)lxa < (unsigned)W ? (unsigned)(lxa * 32 + (lg & 1) * 16) : kOOB;
+    const unsigned lcol_b = (unsigned)lxb < (unsigned)W ? (unsigned)(lxb * 32 + (lg & 1) * 16) : kOOB;
+    const int ylast = min(H - 1, y1 + 1);
+    // per-lane constants of the two epilogues
+    const int xl = x0 - 1 + lr;                                           // image column of lattice column lr
+    const float col_lim = (unsigned)xl < (unsigned)W ? INFINITY : 0.f;
+    const unsigned mid_col = (lr >= 1 && lr <= OW16 && xl < W) ? (unsigned)(xl * 32 + c0 * 2) : kOOB;
+    const bool out_ok = lr < OW16 && x0 + lr < W;
+    const unsigned out_col = out_ok ? (unsigned)((x0 + lr) * 32 + c0 * 2) : kOOB;
+    const unsigned bal_off = lane < 8 ? (unsigned)(strip * 32 + lane * 4) : kOOB;
+    const int plane_pitch = a.nstrips * 32;
+    // the residual operand x(t, x0 + lr), channels c0..c0+3 = half (lg & 1) of channel group (lg >> 1) of input pixel lr + 2:
+    // fragment b of the row; lanes lg' < 2 offer dwords 0,1 of their group lg' & 1, lanes lg' >= 2 dwords 2,3
+    const bool offer_hi = lg >= 2;
+    const int res_src = (lr + 16 * ((lg >> 1) + 2 * (lg & 1))) * 4;
+
+    auto lane_word = [&](const u64 (&bal)[4]) -> unsigned {
+        unsigned w = 0;
+        asm volatile("s_nop 1\n\t"
+                     "v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
+                     "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %8, 7"
+                     : "+v"(w)
+                     : "s"((unsigned)bal[0]), "s"((unsigned)(bal[0] >> 32)), "s"((unsigned)bal[1]), "s"((unsigned)(bal[1] >> 32)),
+                       "s"((unsigned)bal[2]), "s"((unsigned)(bal[2] >> 32)), "s"((unsigned)bal[3]), "s"((unsigned)(bal[3] >> 32)));
+        return w;
+    };
+    typedef const __attribute__((address_space(4))) u64* cu64p;
+    const unsigned long long pm0 = BWD ? (unsigned long long)(d.bits_mid + (long long)b * a.plane_img + strip * 32) : 0ull;
+    const unsigned long long pa0 = BWD ? (unsigned long long)(d.bits_a + (long long)b * a.plane_img + strip * 32) : 0ull;
+    auto plane_row = [&](unsigned long long base, int r) -> cu64p {
+        const int rc = r < 0 ? 0 : (r >= H ? H - 1 : r);
+        return (cu64p)(base + (unsigned long long)(rc * plane_pitch));
+    };
+
+    // XA / XB[k]: input rows in fragment layout; at iteration I row t + k lives in slot (I + k) % 6.  Rows are loaded two ahead.
+    constexpr int NXR = 6;
+    u32x4 XA[NXR], XB[NXR];
+    u32x2 RS[3];
+    bf16x8 MA[3], MB[3];
+    auto load_row = [&](int r, u32x4& xa, u32x4& xb) {
+        const bool ok = r >= 0 && r <= ylast;
+        const unsigned ro = (unsigned)(r * a.row_bytes);
+        xa = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? ro + lcol_a : kOOB, 0, 0);
+        xb = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? ro + lcol_b : kOOB, 0, 0);
+    };
+#pragma unroll
+    for (int k = 0; k < 5; ++k) load_row(y0 - 2 + k, XA[k], XB[k]);
+    auto first_use = [&](u32x4& xa, u32x4& xb, u32x2& rs) {
+        rs = offer_hi ? u32x2{xb[2], xb[3]} : u32x2{xb[0], xb[1]};
+        if constexpr (!BWD) {                                              // MSAU_PAIR_RELU_IN
+            xa = __builtin_bit_cast(u32x4, relu_bits(xa));
+            xb = __builtin_bit_cast(u32x4, relu_bits(xb));
+        }
+    };
+    first_use(XA[0], XB[0], RS[0]);
+    first_use(XA[1], XB[1], RS[1]);
+    constexpr int kStoresPerRow = 2 + (!BWD && BITS ? 2 : 0);            // see rowpair_c8_kernel
+#pragma unroll
+    for (int k = 0; k < 3 * kStoresPerRow; ++k)
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rmid, kOOB + 8u * k, 0, 0);
+    MA[0] = MA[2] = MB[0] = MB[2] = zero8<bf16_t>();
+    u64 mm[2][4], ma[2][4];
+    if constexpr (BWD) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            cu64p pm = plane_row(pm0, y0 - 1 + k), pa = plane_row(pa0, y0 - 2 + k);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) { mm[k][jj] = pm[jj]; ma[k][jj] = pa[jj]; }
+        }
+    }
+    bf16x4 prev_out = {};                                                 // POOL: the even row of the current window
+    const int Wo = (W + 1) >> 1, Ho = (H + 1) >> 1;
+    const unsigned pimg = POOL ? (unsigned)Ho * (unsigned)Wo * 32u : 0u;
+    const __amdgpu_buffer_rsrc_t rp = rsrc_of(POOL ? static_cast<char*>(d.pool_y) + (long long)b * pimg : nullptr, pimg);
+    const __amdgpu_buffer_rsrc_t ri = rsrc_of(POOL && d.pool_idx ? d.pool_idx + (long long)b * (pimg / 2) : nullptr, POOL && d.pool_idx ? pimg / 2 : 0u);
+
+    auto step = [&](auto ic, const int tg) {
+        constexpr int I = decltype(ic)::value, P = I & 1;
+        const int t = tg + I, m = t + 1;
+        load_row(t + 5, XA[(I + 5) % 6], XB[(I + 5) % 6]);
+        first_use(XA[(I + 2) % 6], XB[(I + 2) % 6], RS[(I + 2) % 3]);
+        const bool rowin = (unsigned)m < (unsigned)H;
+        // ================= phase 1: intermediate row m =================
+        {
+            f32x4 acc = bias1;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                acc = mma8(A1[ky][0], __builtin_bit_cast(bf16x8, XA[(I + ky) % 6]), acc);
+                acc = mma8(A1[ky][1], __builtin_bit_cast(bf16x8, XB[(I + ky) % 6]), acc);
+            }
+            f32x4 v;
+            if constexpr (!BWD) {
+                const float lim = rowin ? col_lim : 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) v[jj] = __builtin_amdgcn_fmed3f(acc[jj], 0.f, lim);
+            } else {
+                const u64 rowmask = rowin ? ~0ull : 0ull;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) v[jj] = keep_if(acc[jj], mm[P][jj] & rowmask);
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) o[jj] = (bf16_t)v[jj];
+            *reinterpret_cast<bf16x4*>(mwr + P * MP16) = o;
+            const bool ownrow = m >= y0 && m < y1;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rmid, ownrow ? (unsigned)(m * a.row_bytes) + mid_col : kOOB, 0, 0);
+            if constexpr (!BWD && BITS) {
+                u64 bal[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) bal[jj] = __builtin_amdgcn_ballot_w64((float)o[jj] > 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(lane_word(bal), rbm, ownrow ? (unsigned)(m * plane_pitch) + bal_off : kOOB, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                                  // see rowpair_c8_kernel: the write above, then the reads
+        MA[(I + 1) % 3] = *reinterpret_cast<const bf16x8*>(mrd_a + P * MP16);
+        MB[(I + 1) % 3] = *reinterpret_cast<const bf16x8*>(mrd_b + P * MP16);
+        // ================= phase 2: output row t =================
+        {
+            f32x4 acc = bias2;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                acc = mma8(A2[ky][0], MA[(I + 2 + ky) % 3], acc);
+                acc = mma8(A2[ky][1], MB[(I + 2 + ky) % 3], acc);
+            }
+            u32x2 rr;
+            rr[0] = (unsigned)__builtin_amdgcn_ds_bpermute(res_src, (int)RS[I % 3][0]);
+            rr[1] = (unsigned)__builtin_amdgcn_ds_bpermute(res_src, (int)RS[I % 3][1]);
+            const bf16x4 r = __builtin_bit_cast(bf16x4, rr);
+            f32x4 v;
+            if constexpr (!BWD) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) v[jj] = fmaxf(acc[jj] + (float)r[jj], 0.f);
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) v[jj] = keep_if(acc[jj], ma[P][jj]) + (float)r[jj];
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) o[jj] = (bf16_t)v[jj];
+            const bool ownrow = t >= y0 && t < y1;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ry, ownrow ? (unsigned)(t * a.row_bytes) + out_col : kOOB, 0, 0);
+            if constexpr (!BWD && BITS) {
+                u64 bal[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) bal[jj] = __builtin_amdgcn_ballot_w64((float)r[jj] > 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(lane_word(bal), rba, ownrow ? (unsigned)(t * plane_pitch) + bal_off : kOOB, 0, 0);
+            }
+            if constexpr (POOL) {
+                // rows t - 1 (even, in prev_out) and t (odd), columns lr and lr ^ 1; the window of the image's last row, when H
+                // is odd, sees zeros below (model/model.py:158-160: zero padding).  Values 0 where nothing is stored.
+                bf16x4 cur;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) cur[jj] = ownrow && out_ok ? o[jj] : (bf16_t)0.f;
+                const bool odd = (t & 1) != 0;                            // wave-uniform (y0 is even)
+                const bool last_even = !odd && t == H - 1;                // a window with no second row
+                if (odd || last_even) {
+                    const bf16x4 top = odd ? prev_out : cur, bot = odd ? cur : bf16x4{};
+                    typedef int dw2 __attribute__((ext_vector_type(2)));
+                    dw2 st = __builtin_bit_cast(dw2, top), sb = __builtin_bit_cast(dw2, bot), nt, nb;
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        nt[w] = __builtin_amdgcn_mov_dpp(st[w], 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]: column lr ^ 1
+                        nb[w] = __builtin_amdgcn_mov_dpp(sb[w], 0xB1, 0xf, 0xf, true);
+                    }
+                    const bf16x4 ntop = __builtin_bit_cast(bf16x4, nt), nbot = __builtin_bit_cast(bf16x4, nb);
+                    bf16x4 best;
+                    unsigned idx = 0;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        float bv = (float)top[jj];
+                        unsigned bi = 0;
+                        const float c1 = (float)ntop[jj], c2 = (float)bot[jj], c3 = (float)nbot[jj];
+                        if (c1 > bv) { bv = c1; bi = 1; }
+                        if (c2 > bv) { bv = c2; bi = 2; }
+                        if (c3 > bv) { bv = c3; bi = 3; }
+                        best[jj] = (bf16_t)bv;
+                        idx |= bi << (8 * jj);
+                    }
+                    const int ty = odd ? t - 1 : t;
+                    const bool pok = out_ok && !(lr & 1) && ty >= y0 && ty < y1;
+                    const unsigned e = (unsigned)(((ty >> 1) * Wo + ((x0 + lr) >> 1)) * 16 + c0);       // elements
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, best), rp, pok ? e * 2 : kOOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(idx, ri, pok ? e : kOOB, 0, 0);
+                }
+                prev_out = cur;
+            }
+        }
+        if constexpr (BWD) {
+            cu64p pm = plane_row(pm0, m + 2), pa = plane_row(pa0, t + 2);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) { mm[P][jj] = pm[jj]; ma[P][jj] = pa[jj]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    for (int tg = y0 - 2; tg < y1; tg += UNR) {
+        step(IC<0>{}, tg);
+        step(IC<1>{}, tg);
+        step(IC<2>{}, tg);
+        step(IC<3>{}, tg);
+        step(IC<4>{}, tg);
+        step(IC<5>{}, tg);
+    }
+}
+
 constexpr int kFwd1 = MSAU_PAIR_RELU_IN | MSAU_PAIR_RELU_MID, kFwd2 = MSAU_CONV_ADD | MSAU_CONV_RELU_OUT;
 constexpr int kBwd1 = MSAU_PAIR_MASK_MID, kBwd2 = MSAU_CONV_MASK_A | MSAU_CONV_ADD;
 
 // environment switches of this file, read once; msau_reload_env() makes the next call read them again (tests, A/B tools)
-struct RowsEnv { int on, sh, waves, min_tasks; };
+struct RowsEnv { int on, sh, waves, min_tasks, maxc; };
 RowsEnv g_env;
 bool g_env_ok = false;
 const RowsEnv& rows_env() {
@@ -292,6 +570,7 @@ const RowsEnv& rows_env() {
         g_env.sh = geti("MSAU_ROWS_SH", 0);                      // rows per segment (0: from MSAU_ROWS_WAVES)
         g_env.waves = geti("MSAU_ROWS_WAVES", 3072);             // tasks (= waves) per launch to aim for
         g_env.min_tasks = geti("MSAU_ROWS_MIN_TASKS", 256);
+        g_env.maxc = geti("MSAU_ROWS_MAXC", 16);                 // widest layer the row kernels take (8: the 16-channel pairs stay on the tile kernels)
         g_env_ok = true;
     }
     return g_env;
@@ -312,43 +591,56 @@ int segment_rows(int B, int H, int nstrips) {
 
 }  // namespace
 
-// which msau_conv_pair descriptors the row-streaming kernel takes: 8 channels, bf16, the residual block's forward flag set
-// (with or without ballot planes) or its data-gradient flag set WITH ballot planes
+// which msau_conv_pair descriptors the row-streaming kernels take: 8 or 16 channels, bf16, the residual block's forward flag
+// set (with or without ballot planes; at 16 channels also with MSAU_CONV_POOL) or its data-gradient flag set WITH ballot planes
 int msau_rowpair_takes(int dtype, const msau_conv_pair_desc* d) {
-    if (!rows_env().on || dtype != MSAU_BF16 || d->C != 8) return 0;
-    const bool fwd = d->flags1 == kFwd1 && d->flags2 == kFwd2, bwd = d->flags1 == kBwd1 && d->flags2 == kBwd2;
+    const RowsEnv& e = rows_env();
+    if (!e.on || dtype != MSAU_BF16 || (d->C != 8 && d->C != 16) || d->C > e.maxc || (d->flags1 & MSAU_PAIR_TILES)) return 0;
+    const int pool_ok = d->C == 16 ? MSAU_CONV_POOL : 0;
+    const bool fwd = d->flags1 == kFwd1 && (d->flags2 & ~pool_ok) == kFwd2, bwd = d->flags1 == kBwd1 && d->flags2 == kBwd2;
     if (!fwd && !bwd) return 0;
+    if (fwd && (d->flags2 & MSAU_CONV_POOL) && !d->pool_y) return 0;
     if (bwd && !(d->bits_mid && d->bits_a)) return 0;
     if (d->add != d->x) return 0;
-    if ((int64_t)d->H * d->W * 16 >= (1ll << 31)) return 0;
-    const int nstrips = cdiv(d->W, OW);
+    if ((int64_t)d->H * d->W * d->C * 2 >= (1ll << 31)) return 0;
+    const int nstrips = cdiv(d->W, d->C == 8 ? OW : OW16);
     if ((int64_t)d->H * nstrips * 32 >= (1ll << 31)) return 0;
-    if ((int64_t)d->B * nstrips * cdiv(d->H, 8) < rows_env().min_tasks) return 0;    // too little work to fill the device: the tile kernels
+    if ((int64_t)d->B * nstrips * cdiv(d->H, 8) < e.min_tasks) return 0;    // too little work to fill the device: the tile kernels
     return 1;
 }
 
 extern "C" void msau_reload_env(void) { g_env_ok = false; }
 
 int64_t msau_rowpair_plane_bytes(const msau_conv_pair_desc* d) {
-    return (int64_t)d->B * d->H * cdiv(d->W, OW) * 32;
+    return (int64_t)d->B * d->H * cdiv(d->W, d->C == 8 ? OW : OW16) * 32;
 }
 
 int msau_rowpair_launch(hipStream_t s, const msau_conv_pair_desc* d) {
     RowArgs a;
     a.d = *d;
-    a.nstrips = cdiv(d->W, OW);
+    const bool c8 = d->C == 8;
+    const bool bwd = d->flags1 == kBwd1, bits = d->bits_mid && d->bits_a, pool = !bwd && (d->flags2 & MSAU_CONV_POOL);
+    a.nstrips = cdiv(d->W, c8 ? OW : OW16);
     a.SH = segment_rows(d->B, d->H, a.nstrips);
+    if (pool && (a.SH & 1) && a.SH < d->H) ++a.SH;                          // 2x2 windows do not straddle segments
     a.nseg = cdiv(d->H, a.SH);
     a.ntasks = d->B * a.nstrips * a.nseg;
     a.tasks_per_xcd = roundup(cdiv(a.ntasks, 8), 4);
-    a.row_bytes = d->W * 16;
+    a.row_bytes = d->W * d->C * 2;
     a.img_bytes = (unsigned)d->H * (unsigned)a.row_bytes;
     a.plane_img = (unsigned)d->H * (unsigned)a.nstrips * 32u;
-    const int grid = 8 * (a.tasks_per_xcd / 4);
-    const bool bwd = d->flags1 == kBwd1, bits = d->bits_mid && d->bits_a;
-    if (bwd) hipLaunchKernelGGL((rowpair_c8_kernel<true, true>), dim3(grid), dim3(256), 0, s, a);
-    else if (bits) hipLaunchKernelGGL((rowpair_c8_kernel<false, true>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((rowpair_c8_kernel<false, false>), dim3(grid), dim3(256), 0, s, a);
-    MSAU_CHECK_LAUNCH("rowpair_c8_kernel");
+    const dim3 grid(8 * (a.tasks_per_xcd / 4)), block(256);
+    if (c8) {
+        if (bwd) hipLaunchKernelGGL((rowpair_c8_kernel<true, true>), grid, block, 0, s, a);
+        else if (bits) hipLaunchKernelGGL((rowpair_c8_kernel<false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((rowpair_c8_kernel<false, false>), grid, block, 0, s, a);
+    } else {
+        if (bwd) hipLaunchKernelGGL((rowpair_c16_kernel<true, true, false>), grid, block, 0, s, a);
+        else if (bits && pool) hipLaunchKernelGGL((rowpair_c16_kernel<false, true, true>), grid, block, 0, s, a);
+        else if (bits) hipLaunchKernelGGL((rowpair_c16_kernel<false, true, false>), grid, block, 0, s, a);
+        else if (pool) hipLaunchKernelGGL((rowpair_c16_kernel<false, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((rowpair_c16_kernel<false, false, false>), grid, block, 0, s, a);
+    }
+    MSAU_CHECK_LAUNCH("rowpair_kernel");
     return 0;
 }

@@ -558,6 +558,11 @@ class PairOp:
                     # the two ReLU masks as bit planes: written by the forward launch, read by the backward launch; the
                     # layout (and so the size) belongs to the instance that takes the shape (msau_conv_pair_bits_bytes)
                     nbits = int(L.load().msau_conv_pair_bits_bytes(P.dtype, C.byref(b)))
+                    if nbits != int(L.load().msau_conv_pair_bits_bytes(P.dtype, C.byref(f))):
+                        # the two launches would go to different instances (a forward flag only the tile kernels have)
+                        f.flags1 |= L.PAIR_TILES
+                        b.flags1 |= L.PAIR_TILES
+                        nbits = int(L.load().msau_conv_pair_bits_bytes(P.dtype, C.byref(b)))
                     self.bits_mid = torch.zeros((nbits,), dtype=torch.uint8, device=P.device)
                     self.bits_a = torch.zeros_like(self.bits_mid)
                     for dsc in (f, b):

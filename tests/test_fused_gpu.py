@@ -94,9 +94,18 @@ def test_pool_in_the_residual_pair_epilogue_is_bit_exact(monkeypatch, dtype, C8,
         plan.logits = q
     out = {}
     monkeypatch.setenv("MSAU_PAIR_POOL_MINC", "8")          # the 8-channel pooled pair instance is off by default (slower than the pool launch)
-    for mode in ("1", "0"):
-        monkeypatch.setenv("MSAU_FUSE_POOL", mode)
-        out[mode] = run_graph(build, p, x, gy, dtype)
+    if c == 8:
+        # only the tile kernels pool at 8 channels; without this the un-pooled mode would run the row-streaming kernel, which
+        # sums in another order (16 channels: the row kernel pools too, both modes run it)
+        monkeypatch.setenv("MSAU_PAIR_ROWS", "0")
+        L.load().msau_reload_env()
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MSAU_FUSE_POOL", mode)
+            out[mode] = run_graph(build, p, x, gy, dtype)
+    finally:
+        monkeypatch.undo()
+        L.load().msau_reload_env()
     pool1, plan1 = took[0]
     assert plan1.pairs[0].active and pool1.fused_into is plan1.pairs[0] and took[1][0].fused_into is None
     for a, b in zip(out["1"], out["0"]):
@@ -148,14 +157,16 @@ def test_relu_masks_as_bit_planes_give_the_same_gradients(monkeypatch, dtype, c,
             assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("hw,B,sh", [((57, 61), 3, 0), ((71, 250), 2, 0), ((33, 30), 2, 10), ((16, 91), 2, 4), ((90, 29), 2, 16), ((64, 64), 2, 22)])
-def test_row_streaming_pair_matches_the_tile_kernels_and_the_oracle(monkeypatch, hw, B, sh):
-    """conv_rows.hip (8 channels, bf16: pixel-pair packed MFMA rows, a wave walks a 30-column strip row by row, ReLU masks as
-    lane ballots) against the tile kernels of conv_pair.hip on the same rounded inputs, and both against the fp32 oracle:
+@pytest.mark.parametrize("c", [8, 16])
+@pytest.mark.parametrize("hw,B,sh", [((57, 61), 3, 0), ((71, 250), 2, 0), ((33, 30), 2, 10), ((16, 91), 2, 4), ((90, 29), 2, 16), ((64, 64), 2, 22),
+                                     ((45, 14), 2, 0), ((40, 15), 1, 7)])
+def test_row_streaming_pair_matches_the_tile_kernels_and_the_oracle(monkeypatch, c, hw, B, sh):
+    """conv_rows.hip (8 / 16 channels, bf16: a wave walks a 30- / 14-column strip row by row, pixel-pair packed MFMA rows at 8
+    channels, ReLU masks as lane ballots) against the tile kernels of conv_pair.hip on the same rounded inputs, and both against the fp32 oracle:
     forward, input gradient, weight / bias gradients; strips that end inside / at / beyond the image edge, segments of
     every height (MSAU_ROWS_SH), images shorter than one segment."""
     torch.manual_seed(21)
-    c, (H, W) = 8, hw
+    H, W = hw
     x = torch.randn(B, c, H, W)
     p = {"w": 0.2 * torch.randn(c, c, 3, 3), "b": 0.1 * torch.randn(c), "w2": 0.2 * torch.randn(c, c, 3, 3), "b2": 0.1 * torch.randn(c)}
     gy = torch.randn(B, c, H, W)
@@ -187,7 +198,7 @@ def test_row_streaming_pair_matches_the_tile_kernels_and_the_oracle(monkeypatch,
     assert plans[0].pairs[0].active and plans[0].pairs[0].bdesc is not None
     # the planes follow the instance: 32 bytes of ballots per (row, 30-column strip) against a byte per pixel (small images:
     # mode "0" has no tile instance either and runs the two convs as separate launches)
-    assert plans[0].pairs[0].bits_mid.numel() == B * H * -(-W // 30) * 32
+    assert plans[0].pairs[0].bits_mid.numel() == B * H * -(-W // (30 if c == 8 else 14)) * 32
     assert not plans[1].pairs[0].active or plans[1].pairs[0].bits_mid.numel() == B * H * W
     # fp32 reference on the bf16-rounded inputs and weights
     xr = x.bfloat16().float().requires_grad_(True)
