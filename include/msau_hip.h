@@ -141,6 +141,7 @@ int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d);
  * info[0] = CT (16-row output-channel tiles), info[1] = PT (pixel tiles per wave: tile = 4*PT x 16),
  * info[2] = dynamic LDS bytes, info[3] = workgroups, info[4] = channel chunk, info[5] = chunks,
  * info[6] = 1 if a compile-time-specialised "lean" instance (conv_lean.hip) takes the launch, 2 if the chunked-K instance does,
+ *           3 if a row-streaming instance (conv_rows.hip) does,
  * info[7] = bit 0: that instance implements MSAU_CONV_HEAD for this descriptor, bit 1: MSAU_CONV_DOUT,
  *           bit 2: MSAU_CONV_LRN, bit 3: MSAU_CONV_POOL, bit 4: MSAU_CONV_IDS */
 int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info8);
@@ -190,7 +191,7 @@ int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc* d);
  * row-streaming 8-channel bf16 kernel (conv_rows.hip).  Allocate with this, never from the layout comment above. */
 int64_t msau_conv_pair_bits_bytes(int dtype, const msau_conv_pair_desc* d);
 /* The library reads its MSAU_* environment switches once.  msau_reload_env() makes the row-streaming kernel's switches
- * (MSAU_PAIR_ROWS, MSAU_ROWS_SH, MSAU_ROWS_WAVES, MSAU_ROWS_MIN_TASKS, MSAU_ROWS_MAXC) be read again on the next call: for tests and A/B
+ * (MSAU_PAIR_ROWS, MSAU_CONV_ROWS, MSAU_ROWS_SH, MSAU_ROWS_WAVES, MSAU_ROWS_MIN_TASKS, MSAU_ROWS_MAXC) be read again on the next call: for tests and A/B
  * tools that change them inside one process. */
 void msau_reload_env(void);
 

@@ -23,7 +23,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 EXTRA_FLAGS = {"elementwise.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
                # MFMA results straight into VGPRs (gfx950 has one unified file): without it the row kernel's accumulators live in
                # AGPRs and every epilogue starts with four v_accvgpr_read
-               "conv_rows.hip": (["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.environ.get("MSAU_ROWS_VGPR_FORM", "1") != "0" else [])
+               "conv_rows.hip": ["-std=c++20"] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.environ.get("MSAU_ROWS_VGPR_FORM", "1") != "0" else [])
                                 + (["-DMSAU_ROWS_KEEPALIVE"] if os.environ.get("MSAU_ROWS_KEEPALIVE", "0") == "1" else [])}
 
 

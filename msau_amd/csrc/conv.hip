@@ -345,11 +345,19 @@ extern "C" int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32
     if (rc) return rc;
     info[0] = g.CT; info[1] = PT; info[2] = t.total; info[3] = (int32_t)nb; info[4] = g.cch; info[5] = g.nchunks;
     info[6] = msau_conv_lean_applicable(dtype, d, g.nchunks, g.CT);
+    if (g.nslices == 1 && msau_rowconv_takes(dtype, d)) info[6] = 3;                         // rowconv8_kernel (conv_rows.hip)
     if (g.nslices == 1 && !(d->flags & (MSAU_CONV_HEAD | MSAU_CONV_DOUT | MSAU_CONV_LRN | MSAU_CONV_POOL | MSAU_CONV_IDS)) &&
         msau_conv_chunked_capable(dtype, d, g.cch, g.nchunks, g.CT)) info[6] = 2;       // conv_chunked_kernel (conv_lean.hip)
     info[7] = msau_conv_lean_head_capable(dtype, d, g.nchunks, g.CT) | (msau_conv_lean_dout_capable(dtype, d, g.nchunks, g.CT) << 1) |
               (msau_conv_lean_lrn_capable(dtype, d, g.nchunks, g.CT) << 2) | (msau_conv_lean_pool_capable(dtype, d, g.nchunks, g.CT) << 3) |
               (msau_conv_lean_ids_capable(dtype, d, g.nchunks, g.CT) << 4);
+    if (g.nslices == 1 && !(info[7] & 4)) {              // would a row-streaming instance take this launch with MSAU_CONV_LRN added?
+        msau_conv_desc p = *d;
+        p.flags |= MSAU_CONV_LRN;
+        if (!p.y2) p.y2 = p.y;
+        if (!(p.lrn_k > 0.f)) p.lrn_k = 1.f;
+        if (msau_rowconv_takes(dtype, &p)) info[7] |= 4;
+    }
     return 0;
 }
 
@@ -396,7 +404,7 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
     }
     if (d->flags & MSAU_CONV_LRN) {
         MSAU_CHECK_ARG(d->y2 && !(d->flags & ~(MSAU_CONV_LRN | MSAU_CONV_RELU_IN)) && d->lrn_k > 0.f, "conv2d: bad LRN arguments");
-        if (!msau_conv_lean_lrn_capable(dtype, d, g.nchunks, g.CT))
+        if (!msau_conv_lean_lrn_capable(dtype, d, g.nchunks, g.CT) && !(g.nslices == 1 && msau_rowconv_takes(dtype, d)))
             return msau_set_error(MSAU_ERR_ARG, "conv2d: MSAU_CONV_LRN is not implemented for this launch (see "
                                   "msau_conv2d_launch_info info[7]); run msau_lrn_fwd on y instead");
     }
@@ -411,6 +419,8 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
             return msau_set_error(MSAU_ERR_ARG, "conv2d: MSAU_CONV_POOL is not implemented for this launch (see "
                                   "msau_conv2d_launch_info info[7]); run msau_maxpool2x2_fwd on y instead");
     }
+    if (g.nslices == 1 && msau_rowconv_takes(dtype, d))                       // conv_rows.hip: row-streaming instances (level 0)
+        return msau_rowconv_launch(static_cast<hipStream_t>(stream), dtype, d, g.kchunk, g.rows);
     if (g.nslices == 1 && !(d->flags & (MSAU_CONV_HEAD | MSAU_CONV_DOUT | MSAU_CONV_LRN | MSAU_CONV_POOL | MSAU_CONV_IDS))) {
         rc = msau_conv_chunked_try(static_cast<hipStream_t>(stream), dtype, d, g.cch, g.kchunk, g.nchunks, g.CT);
         if (rc != 0) return rc < 0 ? rc : 0;

@@ -27,6 +27,7 @@
 // L1 / L2), consecutive workgroups of one XCD take consecutive tasks.
 #include "msau_common.h"
 #include <cstdlib>
+#include <utility>
 
 namespace {
 
@@ -556,11 +557,209 @@ __global__ __launch_bounds__(256) void rowpair_c16_kernel(const RowArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Single convolutions of the 8-channel level in the same form (msau_conv2d descriptors; dispatched from conv.hip before the
+// tile kernels): stride 1, 8 output channels pixel-pair packed, one or two 8-channel sources, 3x3 / 1x1 / 4x4.  A strip is
+// 32 output columns (16 pixel pairs); a pair's window is KW + 1 columns wide:
+//   3x3: one k-step per (source, tap row): lane group lg = window column; the B fragment is pixel x0 - pad + 2*lr + lg of
+//        the input row -- one 16-byte load per lane, row and source, carried in registers while the row serves as
+//        ky = KH-1 .. 0;
+//   1x1 over concat(x1, x2) (the coupling conv, model/model.py:143-148): ONE k-step per row: lane group lg = (source lg >> 1,
+//        pixel parity lg & 1);
+//   4x4 (the end conv, model/model.py:375-376,390, and its data gradient): window columns 0..3 as above plus a second
+//        k-step per tap row whose only live group is window column 4 (all lanes load pixel 2*lr + 4; the weights of lane
+//        groups 1..3 are zero) -- 8 MFMAs per row instead of the 5 a dense packing needs, but every fragment stays
+//        row-pure and the MFMA pipe is nowhere near the bound.
+// Epilogue operands (MASK_A, ADD, ACCUM, MASK_B: 8 bytes per lane in the result layout) are loaded two rows ahead.
+// MSAU_CONV_LRN: the 8 channels of a pixel sit in lanes l and l ^ 16; same arithmetic as the stand-alone pass.
+struct RowConvArgs {
+    msau_conv_desc d;
+    int nstrips, nseg, SH, ntasks, tasks_per_xcd;
+    int row_bytes, wrow, wchunk;                  // bytes of an image row; elements per packed weight row / per source chunk
+    unsigned img_bytes;
+};
+
+template <int NS, int KH, int KW, int EPI>
+__global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
+    static_assert((KW == 3 && (NS == 1 || NS == 2)) || (KW == 1 && NS == 2 && KH == 1) || (KW == 4 && NS == 1), "instances: 3x3, 1x1 dual, 4x4");
+    constexpr int XL = KW == 4 ? 2 : 1;                                    // loads per lane, row and source
+    constexpr int NSL = KW == 1 ? 1 : NS;                                  // source "slots" per row (1x1: the lane picks its source)
+    constexpr int NXR = KH == 4 ? 8 : KH + 3;                              // rows in registers: KH in use, the rest in flight
+    constexpr bool HAS_MA = (EPI & MSAU_CONV_MASK_A) != 0, HAS_ADD = (EPI & MSAU_CONV_ADD) != 0, HAS_ACC = (EPI & MSAU_CONV_ACCUM) != 0,
+                   HAS_MB = (EPI & MSAU_CONV_MASK_B) != 0, RELU_OUT = (EPI & MSAU_CONV_RELU_OUT) != 0, LRN = (EPI & MSAU_CONV_LRN) != 0;
+    const msau_conv_desc& d = a.d;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tloc = (blockIdx.x >> 3) * 4 + wave;
+    const int task = (blockIdx.x & 7) * a.tasks_per_xcd + tloc;
+    if (tloc >= a.tasks_per_xcd || task >= a.ntasks) return;
+    const int t1 = task / a.nstrips, strip = task - t1 * a.nstrips;
+    const int b = t1 / a.nseg, seg = t1 - b * a.nseg;
+    const int H = d.Hout, W = d.Wout;
+    const int x0 = strip * 32;
+    const int y0 = seg * a.SH, y1 = min(H, y0 + a.SH);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int c0 = (lg & 1) * 4;
+    const int j = 2 * lr + (lg >> 1);                                     // output column of this lane's result
+
+    // ---- A fragments
+    bf16x8 A[NSL][KH][XL];
+    {
+        const int co = lr & 7, pp = lr >> 3;
+        const bf16_t* w = static_cast<const bf16_t*>(d.wpack) + co * a.wrow;
+#pragma unroll
+        for (int s = 0; s < NSL; ++s)
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky) {
+                if constexpr (KW == 1) {
+                    const bool ok = (lg & 1) == pp;                        // this lane group's pixel is the row's pixel
+                    A[s][ky][0] = ok ? load8<bf16_t>(w + (lg >> 1) * a.wchunk) : zero8<bf16_t>();
+                } else {
+                    const int kx = lg - pp;
+                    const bool ok = kx >= 0 && kx < KW;
+                    A[s][ky][0] = ok ? load8<bf16_t>(w + s * a.wchunk + (ky * KW + (ok ? kx : 0)) * 8) : zero8<bf16_t>();
+                    if constexpr (KW == 4) {
+                        const bool ok4 = lg == 0 && pp == 1;               // window column 4 = tap column 3 of the odd pixel
+                        A[s][ky][1] = ok4 ? load8<bf16_t>(w + s * a.wchunk + (ky * KW + 3) * 8) : zero8<bf16_t>();
+                    }
+                }
+            }
+    }
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (d.bias) bias = *reinterpret_cast<const f32x4*>(d.bias + c0);
+
+    const long long img = (long long)b * a.img_bytes;
+    const __amdgpu_buffer_rsrc_t rx1 = rsrc_of(static_cast<const char*>(d.x1) + img, a.img_bytes);
+    const __amdgpu_buffer_rsrc_t rx2 = rsrc_of(NS == 2 && KW != 1 ? static_cast<const char*>(d.x2) + img : nullptr, NS == 2 && KW != 1 ? a.img_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t ry = rsrc_of(static_cast<char*>(d.y) + img, a.img_bytes);
+    const __amdgpu_buffer_rsrc_t ry2 = rsrc_of(LRN ? static_cast<char*>(d.y2) + img : nullptr, LRN ? a.img_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rma = rsrc_of(HAS_MA ? static_cast<const char*>(d.mask_a) + img : nullptr, HAS_MA ? a.img_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t radd = rsrc_of(HAS_ADD ? static_cast<const char*>(d.add) + img : nullptr, HAS_ADD ? a.img_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rmb = rsrc_of(HAS_MB ? static_cast<const char*>(d.mask_b) + img : nullptr, HAS_MB ? a.img_bytes : 0u);
+
+    // fragment loads of input row r
+    const int lxm = KW == 1 ? x0 + 2 * lr + (lg & 1) : x0 - d.pad_l + 2 * lr + lg;
+    const int lxe = x0 - d.pad_l + 2 * lr + 4;
+    const unsigned lcol_m = (unsigned)lxm < (unsigned)W ? (unsigned)(lxm * 16) : kOOB;
+    const unsigned lcol_e = (unsigned)lxe < (unsigned)W ? (unsigned)(lxe * 16) : kOOB;
+    const int rlast = min(H - 1, y1 - 1 - d.pad_t + KH - 1);
+    const bool b075 = d.lrn_beta == 0.75f;
+    u32x4 X[NSL][NXR][XL];
+    // 1x1 over two sources: lanes of groups 0,1 read x1, of groups 2,3 x2 -- ONE load with a per-lane base address.  No halo,
+    // so the only invalid lanes are pixels beyond the image width: they read (and never store) the pixel at the image edge.
+    const char* src1x1 = nullptr;
+    if constexpr (KW == 1) src1x1 = static_cast<const char*>(lg < 2 ? d.x1 : d.x2) + img + (lxm < W ? lxm : W - 1) * 16;
+    auto load_row = [&](int r, auto slot) {
+        constexpr int S = decltype(slot)::value;
+        const bool ok = r >= 0 && r <= rlast;
+        const unsigned ro = (unsigned)(r * a.row_bytes);
+        if constexpr (KW == 1) {
+            X[0][S][0] = *reinterpret_cast<const u32x4*>(src1x1 + (long long)(ok ? r : y0) * a.row_bytes);
+        } else {
+            X[0][S][0] = __builtin_amdgcn_raw_buffer_load_b128(rx1, ok ? ro + lcol_m : kOOB, 0, 0);
+            if constexpr (KW == 4) X[0][S][1] = __builtin_amdgcn_raw_buffer_load_b128(rx1, ok ? ro + lcol_e : kOOB, 0, 0);
+            if constexpr (NS == 2) X[1][S][0] = __builtin_amdgcn_raw_buffer_load_b128(rx2, ok ? ro + lcol_m : kOOB, 0, 0);
+        }
+    };
+    // epilogue operands of output row t (result layout), two rows ahead
+    const bool out_ok = x0 + j < W;
+    const unsigned out_col = out_ok ? (unsigned)((x0 + j) * 16 + c0 * 2) : kOOB;
+    u32x2 OPA[2], OPD[2], OPB[2], OPY[2];
+    auto load_ops = [&](int t, auto slot) {
+        constexpr int P = decltype(slot)::value;
+        const unsigned o = (t >= y0 && t < y1) ? (unsigned)(t * a.row_bytes) + out_col : kOOB;
+        if constexpr (HAS_MA) OPA[P] = __builtin_amdgcn_raw_buffer_load_b64(rma, o, 0, 0);
+        if constexpr (HAS_ADD) OPD[P] = __builtin_amdgcn_raw_buffer_load_b64(radd, o, 0, 0);
+        if constexpr (HAS_ACC) OPY[P] = __builtin_amdgcn_raw_buffer_load_b64(ry, o, 0, 0);
+        if constexpr (HAS_MB) OPB[P] = __builtin_amdgcn_raw_buffer_load_b64(rmb, o, 0, 0);
+    };
+
+    // prologue: rows r0 .. r0 + NXR - 2 of the first output row (r0 = y0 - pad_t); operands of rows y0, y0 + 1
+    {
+        const int r0 = y0 - d.pad_t;
+        [&]<int... K>(std::integer_sequence<int, K...>) { (load_row(r0 + K, IC<K>{}), ...); }(std::make_integer_sequence<int, NXR - 1>{});
+    }
+    load_ops(y0, IC<0>{});
+    load_ops(y0 + 1, IC<1>{});
+
+    auto step = [&](auto ic, const int tg) {
+        constexpr int I = decltype(ic)::value, P = I & 1;
+        const int t = tg + I;
+        load_row(t - d.pad_t + NXR - 1, IC<(I + NXR - 1) % NXR>{});
+        f32x4 acc = bias;
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+            for (int s = 0; s < NSL; ++s)
+#pragma unroll
+                for (int e = 0; e < XL; ++e) acc = mma8(A[s][ky][e], __builtin_bit_cast(bf16x8, X[s][(I + ky) % NXR][e]), acc);
+        f32x4 v = acc;
+        if constexpr (HAS_MA) {
+            const bf16x4 mk = __builtin_bit_cast(bf16x4, OPA[P]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) v[jj] = (float)mk[jj] > 0.f ? v[jj] : 0.f;
+        }
+        if constexpr (HAS_ADD) {
+            const bf16x4 ad = __builtin_bit_cast(bf16x4, OPD[P]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) v[jj] += (float)ad[jj];
+        }
+        if constexpr (HAS_ACC) {
+            const bf16x4 yo = __builtin_bit_cast(bf16x4, OPY[P]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) v[jj] += (float)yo[jj];
+        }
+        if constexpr (RELU_OUT) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) v[jj] = fmaxf(v[jj], 0.f);
+        }
+        if constexpr (HAS_MB) {
+            const bf16x4 mk = __builtin_bit_cast(bf16x4, OPB[P]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) v[jj] = (float)mk[jj] > 0.f ? v[jj] : 0.f;
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) o[jj] = (bf16_t)v[jj];
+        const unsigned oo = (t >= y0 && t < y1) ? (unsigned)(t * a.row_bytes) + out_col : kOOB;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ry, oo, 0, 0);
+        if constexpr (LRN) {
+            // y2 = y * (k + alpha/n * sum over [c - 4, c + 3] of y^2)^-beta from the rounded y (layers.py:145,161-162); lane l holds
+            // channels 4h..4h+3 (h = lg & 1), lane l ^ 16 the other half; window sums = differences of exclusive prefix sums
+            float x[4], Pf[4], run = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) { x[jj] = (float)o[jj]; run += x[jj] * x[jj]; Pf[jj] = run; }
+            const int h = lg & 1;
+            const float other = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, run), 0x401F));   // lane ^ 16
+            const float inc = h ? run + other : run;
+            const float E = inc - run;
+            const float tot = h ? inc : other + run;
+            bf16x4 o2;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float Xe = E + (jj ? Pf[jj - 1] : 0.f);
+                const float Xo = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, Xe), 0x401F));
+                const float win = h ? tot - Xo : Xo;
+                const float dd = d.lrn_k + d.lrn_alpha_over_n * win;
+                float dnb;
+                if (b075) { const float r = __builtin_amdgcn_rsqf(dd); dnb = r * __builtin_amdgcn_sqrtf(r); }
+                else dnb = __expf(-d.lrn_beta * __logf(dd));
+                o2[jj] = (bf16_t)(x[jj] * dnb);
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o2), ry2, oo, 0, 0);
+        }
+        load_ops(t + 2, IC<P>{});
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int tg = y0; tg < y1; tg += NXR)
+        [&]<int... K>(std::integer_sequence<int, K...>) { (step(IC<K>{}, tg), ...); }(std::make_integer_sequence<int, NXR>{});
+}
+
 constexpr int kFwd1 = MSAU_PAIR_RELU_IN | MSAU_PAIR_RELU_MID, kFwd2 = MSAU_CONV_ADD | MSAU_CONV_RELU_OUT;
 constexpr int kBwd1 = MSAU_PAIR_MASK_MID, kBwd2 = MSAU_CONV_MASK_A | MSAU_CONV_ADD;
 
 // environment switches of this file, read once; msau_reload_env() makes the next call read them again (tests, A/B tools)
-struct RowsEnv { int on, sh, waves, min_tasks, maxc; };
+struct RowsEnv { int on, sh, waves, min_tasks, maxc, conv; };
 RowsEnv g_env;
 bool g_env_ok = false;
 const RowsEnv& rows_env() {
@@ -570,6 +769,7 @@ const RowsEnv& rows_env() {
         g_env.sh = geti("MSAU_ROWS_SH", 0);                      // rows per segment (0: from MSAU_ROWS_WAVES)
         g_env.waves = geti("MSAU_ROWS_WAVES", 3072);             // tasks (= waves) per launch to aim for
         g_env.min_tasks = geti("MSAU_ROWS_MIN_TASKS", 256);
+        g_env.conv = geti("MSAU_CONV_ROWS", 1);                  // single convolutions of the 8-channel level on the row kernels
         g_env.maxc = geti("MSAU_ROWS_MAXC", 16);                 // widest layer the row kernels take (8: the 16-channel pairs stay on the tile kernels)
         g_env_ok = true;
     }
@@ -643,4 +843,74 @@ int msau_rowpair_launch(hipStream_t s, const msau_conv_pair_desc* d) {
     }
     MSAU_CHECK_LAUNCH("rowpair_kernel");
     return 0;
+}
+
+// ---- single convolutions (msau_conv2d descriptors)
+namespace {
+template <int NS, int KH, int KW, int EPI>
+int launch_rowconv8(hipStream_t s, const RowConvArgs& a) {
+    hipLaunchKernelGGL((rowconv8_kernel<NS, KH, KW, EPI>), dim3(8 * (a.tasks_per_xcd / 4)), dim3(256), 0, s, a);
+    MSAU_CHECK_LAUNCH("rowconv8_kernel");
+    return 0;
+}
+// instance index of a descriptor, 0 = none
+int rowconv_case(int dtype, const msau_conv_desc* d) {
+    const RowsEnv& e = rows_env();
+    if (!e.on || !e.conv || dtype != MSAU_BF16) return 0;
+    if (d->Cout != 8 || d->C1 != 8 || (d->C2 != 0 && d->C2 != 8) || d->stride != 1 || d->ups != 1 || d->dil != 1) return 0;
+    if (d->Hin != d->Hout || d->Win != d->Wout || d->KH != d->KW) return 0;
+    if ((int64_t)d->Hout * d->Wout * 16 >= (1ll << 31)) return 0;
+    if ((int64_t)d->B * cdiv(d->Wout, 32) * cdiv(d->Hout, 8) < e.min_tasks) return 0;
+    const int f = d->flags, k = d->KH, dual = d->C2 != 0;
+    if (k == 3 && !dual && d->pad_t == 1 && d->pad_l == 1) {
+        if (f == MSAU_CONV_LRN) return d->y2 && d->lrn_k > 0.f ? 1 : 0;
+        if (f == 0) return 2;
+        if (f == MSAU_CONV_ACCUM) return 3;
+    }
+    if (k == 3 && dual && d->pad_t == 1 && d->pad_l == 1 && f == 0) return 4;
+    if (k == 1 && dual && d->pad_t == 0 && d->pad_l == 0 && f == MSAU_CONV_RELU_OUT) return 5;
+    if (k == 4 && !dual && d->pad_t == 1 && d->pad_l == 1) {
+        if (f == 0) return 6;
+        if (f == MSAU_CONV_MASK_B) return 7;
+        if (f == (MSAU_CONV_ACCUM | MSAU_CONV_MASK_B)) return 8;
+    }
+    return 0;
+}
+}  // namespace
+
+int msau_rowconv_takes(int dtype, const msau_conv_desc* d) { return rowconv_case(dtype, d) != 0; }
+
+int msau_rowconv_launch(hipStream_t s, int dtype, const msau_conv_desc* d, int kchunk, int rows) {
+    const int which = rowconv_case(dtype, d);
+    RowConvArgs a;
+    a.d = *d;
+    a.nstrips = cdiv(d->Wout, 32);
+    const int unr = d->KH == 4 ? 8 : d->KH + 3;
+    {
+        const RowsEnv& e = rows_env();
+        int nseg = e.waves / (d->B * a.nstrips);
+        if (nseg < 1) nseg = 1;
+        int sh = e.sh > 0 ? e.sh : cdiv(d->Hout, nseg);
+        if (sh < 8) sh = 8;
+        sh = roundup(sh, unr);
+        a.SH = sh < d->Hout ? sh : d->Hout;
+    }
+    a.nseg = cdiv(d->Hout, a.SH);
+    a.ntasks = d->B * a.nstrips * a.nseg;
+    a.tasks_per_xcd = roundup(cdiv(a.ntasks, 8), 4);
+    a.row_bytes = d->Wout * 16;
+    a.img_bytes = (unsigned)d->Hout * (unsigned)a.row_bytes;
+    a.wrow = kchunk;
+    a.wchunk = rows * kchunk;
+    switch (which) {
+        case 1: return launch_rowconv8<1, 3, 3, MSAU_CONV_LRN>(s, a);
+        case 2: return launch_rowconv8<1, 3, 3, 0>(s, a);
+        case 3: return launch_rowconv8<1, 3, 3, MSAU_CONV_ACCUM>(s, a);
+        case 4: return launch_rowconv8<2, 3, 3, 0>(s, a);
+        case 5: return launch_rowconv8<2, 1, 1, MSAU_CONV_RELU_OUT>(s, a);
+        case 6: return launch_rowconv8<1, 4, 4, 0>(s, a);
+        case 7: return launch_rowconv8<1, 4, 4, MSAU_CONV_MASK_B>(s, a);
+        case 8: return launch_rowconv8<1, 4, 4, MSAU_CONV_ACCUM | MSAU_CONV_MASK_B>(s, a);
+    }
+    return msau_set_error(MSAU_ERR_ARG, "rowconv: no instance");
 }

@@ -20,6 +20,9 @@ int msau_set_error(int code, const char* fmt, ...);
 int msau_rowpair_takes(int dtype, const msau_conv_pair_desc* d);
 int64_t msau_rowpair_plane_bytes(const msau_conv_pair_desc* d);
 int msau_rowpair_launch(hipStream_t s, const msau_conv_pair_desc* d);
+// ... and of msau_conv2d for the single convolutions of the 8-channel level (dispatched from conv.hip)
+int msau_rowconv_takes(int dtype, const msau_conv_desc* d);
+int msau_rowconv_launch(hipStream_t s, int dtype, const msau_conv_desc* d, int kchunk, int rows);
 
 #define MSAU_CHECK_ARG(cond, ...)                                   \
     do {                                                            \

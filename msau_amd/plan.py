@@ -383,7 +383,9 @@ class ConvOp(Op):
                 ex1 = sum(1 for f in (L.CONV_ADD, L.CONV_ACCUM, L.CONV_MASK_B) if d.flags & f)
                 ex2 = sum(1 for f in (L.CONV_ACCUM, L.CONV_MASK_B) if d.flags2 & f)
                 return f"conv_lean_kernel<{T},CIN{d.C1},CT{info[0]},K{d.KH},dout>", (nin + half * (2 + ex1 + ex2)) * esz
-            if info[6] == 2:
+            if info[6] == 3:
+                name = f"rowconv_kernel<{T},CIN{d.C1 + d.C2},CO{d.Cout},K{d.KH}{',lrn' if d.flags & L.CONV_LRN else ''}>"
+            elif info[6] == 2:
                 name = f"conv_chunked_kernel<{T},CIN{d.C1},K{d.KH}>"
             elif info[6]:
                 var = ",dual" if d.C2 else ",ups2" if d.ups == 2 else ",s2" if d.stride == 2 else ""

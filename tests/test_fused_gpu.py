@@ -8,6 +8,7 @@ kernels.  Everything through the C ABI (msau_amd.plan -> msau_run_ops / direct c
   * the role-swapped 64 -> 8 weight gradient (the net's first conv) against autograd
 """
 import ctypes as C
+import os
 
 import pytest
 import torch
@@ -399,3 +400,87 @@ def test_nchw_to_nhwc_every_mapping(dtype, c, cs, hw):
     want = torch.zeros(B, H, W, cs, dtype=tdt)
     want[..., :c] = x.permute(0, 2, 3, 1).to(tdt)
     assert torch.equal(out.cpu(), want)
+
+
+def _pack_image(w, c1, c2, rows=16):
+    """OIHW weight [Co][c1 + c2][k][k] -> the packed image msau_pack_params writes: [chunk = source][row][k = tap * 8 + ci],
+    k padded to a multiple of 32, bf16 (one 8-channel chunk per source)"""
+    co, _, k, _ = w.shape
+    kchunk = -(-k * k * 8 // 32) * 32
+    nch = 1 if c2 == 0 else 2
+    img = torch.zeros(nch, rows, kchunk)
+    for s in range(nch):
+        ws = w[:, s * 8:(s + 1) * 8]                                  # [co][8][k][k]
+        img[s, :co, :k * k * 8] = ws.permute(0, 2, 3, 1).reshape(co, k * k * 8)
+    return img.to(torch.bfloat16).reshape(-1).cuda()
+
+
+@pytest.mark.parametrize("k,dual,flags", [(3, False, 0), (3, False, L.CONV_ACCUM), (3, False, L.CONV_LRN), (3, True, 0),
+                                          (1, True, L.CONV_RELU_OUT), (4, False, 0), (4, False, L.CONV_MASK_B),
+                                          (4, False, L.CONV_ACCUM | L.CONV_MASK_B)])
+@pytest.mark.parametrize("hw,B", [((40, 64), 2), ((37, 45), 3), ((9, 130), 2), ((130, 140), 4)])
+def test_row_streaming_single_convs_match_the_tile_kernels_and_torch(k, dual, flags, hw, B):
+    """rowconv8_kernel (conv_rows.hip): the 8-channel level's single convolutions -- 3x3 (plain, accumulate, LRN second output),
+    3x3 over concat(x1, x2), 1x1 over the concat + ReLU, 4x4 with the asymmetric SAME pad (plain, masked, accumulate + masked) --
+    through msau_conv2d, against the tile kernels on the same packed weights and against torch on the rounded operands"""
+    torch.manual_seed(5)
+    H, W = hw
+    lib = L.load()
+    s = torch.cuda.current_stream().cuda_stream
+    bf = lambda t: t.to(torch.bfloat16)
+    nhwc = lambda t: bf(t).permute(0, 2, 3, 1).contiguous().cuda()
+    x1, x2 = torch.randn(B, 8, H, W), torch.randn(B, 8, H, W)
+    w = 0.2 * torch.randn(8, 16 if dual else 8, k, k)
+    bias = 0.1 * torch.randn(8)
+    yold, mb = torch.randn(B, 8, H, W), torch.randn(B, 8, H, W)
+    d = L.ConvDesc()
+    d.B, d.Hin, d.Win, d.Hout, d.Wout = B, H, W, H, W
+    d.C1, d.C2, d.Cout, d.KH, d.KW, d.dil, d.stride, d.ups = 8, 8 if dual else 0, 8, k, k, 1, 1, 1
+    d.pad_t = d.pad_l = {1: 0, 3: 1, 4: 1}[k]
+    d.flags = flags
+    X1, X2, Wp = nhwc(x1), nhwc(x2), _pack_image(w, 8, 8 if dual else 0)
+    bias16 = torch.zeros(16); bias16[:8] = bias
+    Bd, MB = bias16.cuda(), nhwc(mb)
+    d.x1, d.x2, d.wpack, d.bias = X1.data_ptr(), (X2.data_ptr() if dual else None), Wp.data_ptr(), Bd.data_ptr()
+    d.mask_b = MB.data_ptr() if flags & L.CONV_MASK_B else None
+    d.lrn_alpha_over_n, d.lrn_beta, d.lrn_k = 1e-4 / 8, 0.75, 1.0
+    out = {}
+    try:
+        for mode in ("1", "0"):
+            os.environ["MSAU_CONV_ROWS"] = mode
+            os.environ["MSAU_ROWS_MIN_TASKS"] = "1"
+            lib.msau_reload_env()
+            Y, Y2 = nhwc(yold), torch.zeros(B, H, W, 8, dtype=torch.bfloat16, device="cuda")
+            d.y, d.y2 = Y.data_ptr(), (Y2.data_ptr() if flags & L.CONV_LRN else None)
+            info = (L.i32 * 8)()
+            L.check(lib.msau_conv2d_launch_info(L.BF16, C.byref(d), info))
+            assert (info[6] == 3) == (mode == "1"), (mode, list(info))
+            L.check(lib.msau_conv2d(s, L.BF16, C.byref(d)))
+            torch.cuda.synchronize()
+            out[mode] = (Y.float().cpu(), Y2.float().cpu())
+    finally:
+        os.environ.pop("MSAU_CONV_ROWS", None)
+        os.environ.pop("MSAU_ROWS_MIN_TASKS", None)
+        lib.msau_reload_env()
+    # torch on the rounded operands (SAME padding: 4x4 pads top/left 1, bottom/right 2 -- model/layers/utils.py:10-19)
+    F = torch.nn.functional
+    xin = torch.cat([bf(x1).float(), bf(x2).float()], 1) if dual else bf(x1).float()
+    pad = {1: (0, 0, 0, 0), 3: (1, 1, 1, 1), 4: (1, 2, 1, 2)}[k]
+    ref = F.conv2d(F.pad(xin, pad), bf(w).float(), bias)
+    if flags & L.CONV_ACCUM:
+        ref = ref + bf(yold).float()
+    if flags & L.CONV_RELU_OUT:
+        ref = ref.relu()
+    if flags & L.CONV_MASK_B:
+        ref = ref * (bf(mb).float() > 0)
+    ref = ref.permute(0, 2, 3, 1)
+    for mode in out:
+        assert err(out[mode][0], ref, True) < 1e-2, mode
+    if "0" in out:
+        assert err(out["1"][0], out["0"][0], True) < 5e-3
+    if flags & L.CONV_LRN:
+        yr = out["1"][0].permute(0, 3, 1, 2)
+        lrn = F.local_response_norm(yr, 8, alpha=1e-4, beta=0.75, k=1.0).permute(0, 2, 3, 1)
+        assert err(out["1"][1], lrn, True) < 1e-2
+        if "0" in out:
+            assert err(out["1"][1], out["0"][1], True) < 5e-3
