@@ -455,6 +455,8 @@ def test_row_streaming_single_convs_match_the_tile_kernels_and_torch(k, dual, fl
             info = (L.i32 * 8)()
             L.check(lib.msau_conv2d_launch_info(L.BF16, C.byref(d), info))
             assert (info[6] == 3) == (mode == "1"), (mode, list(info))
+            if mode == "0" and flags & L.CONV_LRN and not info[7] & 4:
+                continue                          # small image: no tile instance carries the LRN epilogue
             L.check(lib.msau_conv2d(s, L.BF16, C.byref(d)))
             torch.cuda.synchronize()
             out[mode] = (Y.float().cpu(), Y2.float().cpu())
