@@ -24,7 +24,7 @@ EXTRA_FLAGS = {"elementwise.hip": ["-Xclang", "-target-feature", "-Xclang", "-pa
                # MFMA results straight into VGPRs (gfx950 has one unified file): without it the row kernel's accumulators live in
                # AGPRs and every epilogue starts with four v_accvgpr_read
                "conv_rows.hip": ["-std=c++20"] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.environ.get("MSAU_ROWS_VGPR_FORM", "1") != "0" else [])
-                                + (["-DMSAU_ROWS_KEEPALIVE"] if os.environ.get("MSAU_ROWS_KEEPALIVE", "0") == "1" else [])}
+                                + (["-DMSAU_ROWCONV_PF=" + os.environ["MSAU_ROWCONV_PF"]] if os.environ.get("MSAU_ROWCONV_PF") else [])}
 
 
 def _stale(target, deps):

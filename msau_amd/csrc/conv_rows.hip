@@ -584,7 +584,10 @@ __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
     static_assert((KW == 3 && (NS == 1 || NS == 2)) || (KW == 1 && NS == 2 && KH == 1) || (KW == 4 && NS == 1), "instances: 3x3, 1x1 dual, 4x4");
     constexpr int XL = KW == 4 ? 2 : 1;                                    // loads per lane, row and source
     constexpr int NSL = KW == 1 ? 1 : NS;                                  // source "slots" per row (1x1: the lane picks its source)
-    constexpr int NXR = KH == 4 ? 8 : KH + 3;                              // rows in registers: KH in use, the rest in flight
+#ifndef MSAU_ROWCONV_PF
+#define MSAU_ROWCONV_PF 3
+#endif
+    constexpr int NXR = KH == 4 ? 8 : KH + MSAU_ROWCONV_PF;                // rows in registers: KH in use, the rest in flight (even: operand slots alternate)
     constexpr bool HAS_MA = (EPI & MSAU_CONV_MASK_A) != 0, HAS_ADD = (EPI & MSAU_CONV_ADD) != 0, HAS_ACC = (EPI & MSAU_CONV_ACCUM) != 0,
                    HAS_MB = (EPI & MSAU_CONV_MASK_B) != 0, RELU_OUT = (EPI & MSAU_CONV_RELU_OUT) != 0, LRN = (EPI & MSAU_CONV_LRN) != 0;
     const msau_conv_desc& d = a.d;
@@ -869,7 +872,7 @@ int rowconv_case(int dtype, const msau_conv_desc* d) {
     }
     if (k == 3 && dual && d->pad_t == 1 && d->pad_l == 1 && f == 0) return 4;
     if (k == 1 && dual && d->pad_t == 0 && d->pad_l == 0 && f == MSAU_CONV_RELU_OUT) return 5;
-    if (k == 4 && !dual && d->pad_t == 1 && d->pad_l == 1) {
+    if (k == 4 && !dual && d->pad_t == d->pad_l && (d->pad_t == 1 || d->pad_t == 2)) {    // forward: 1; data gradient (flipped image): 2
         if (f == 0) return 6;
         if (f == MSAU_CONV_MASK_B) return 7;
         if (f == (MSAU_CONV_ACCUM | MSAU_CONV_MASK_B)) return 8;
@@ -885,7 +888,7 @@ int msau_rowconv_launch(hipStream_t s, int dtype, const msau_conv_desc* d, int k
     RowConvArgs a;
     a.d = *d;
     a.nstrips = cdiv(d->Wout, 32);
-    const int unr = d->KH == 4 ? 8 : d->KH + 3;
+    const int unr = d->KH == 4 ? 8 : d->KH + MSAU_ROWCONV_PF;
     {
         const RowsEnv& e = rows_env();
         int nseg = e.waves / (d->B * a.nstrips);

@@ -553,10 +553,16 @@ class PairOp:
                 b.flags1, b.flags2 = L.PAIR_MASK_MID, d1.flags
                 b.x, b.w1, b.b1, b.mask_mid, b.mid = _ptr(out.grad), P.pack_ptr(c2.d_off[0]), None, d2.mask_b, _ptr(r1.grad)
                 b.w2, b.b2, b.add, b.mask_a, b.mask_b, b.y = P.pack_ptr(c1.d_off[0]), None, d1.add, d1.mask_a, d1.mask_b, d1.y
+                use_bits = os.environ.get("MSAU_PAIR_BITS", "1") != "0"
+                if use_bits:
+                    b.bits_mid = b.bits_a = 1       # placeholders (the planes are allocated below): the row-streaming instances
+                                                    # take the backward flag set only WITH planes, so the probe must carry them
                 if L.load().msau_conv_pair_applicable(P.dtype, C.byref(b)):     # MASK_A + ADD of the input tensor only
                     self.bdesc = b
+                else:
+                    b.bits_mid = b.bits_a = None
                 self.bbytes = 5 * n * esz               # g (also the ADD operand), r1 mask, x0 mask read once; g_r1, dx written once
-                if self.bdesc is not None and os.environ.get("MSAU_PAIR_BITS", "1") != "0":
+                if self.bdesc is not None and use_bits:
                     # the two ReLU masks as bit planes: written by the forward launch, read by the backward launch; the
                     # layout (and so the size) belongs to the instance that takes the shape (msau_conv_pair_bits_bytes)
                     nbits = int(L.load().msau_conv_pair_bits_bytes(P.dtype, C.byref(b)))

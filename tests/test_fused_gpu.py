@@ -200,7 +200,7 @@ def test_row_streaming_pair_matches_the_tile_kernels_and_the_oracle(monkeypatch,
     # the planes follow the instance: 32 bytes of ballots per (row, 30-column strip) against a byte per pixel (small images:
     # mode "0" has no tile instance either and runs the two convs as separate launches)
     assert plans[0].pairs[0].bits_mid.numel() == B * H * -(-W // (30 if c == 8 else 14)) * 32
-    assert not plans[1].pairs[0].active or plans[1].pairs[0].bits_mid.numel() == B * H * W
+    assert not plans[1].pairs[0].active or plans[1].pairs[0].bits_mid.numel() == B * H * W * (c // 8)
     # fp32 reference on the bf16-rounded inputs and weights
     xr = x.bfloat16().float().requires_grad_(True)
     pr = {k: v.bfloat16().float().requires_grad_(True) for k, v in p.items()}
@@ -213,7 +213,7 @@ def test_row_streaming_pair_matches_the_tile_kernels_and_the_oracle(monkeypatch,
         assert err(y, ref.detach(), True) < 2e-2, mode
         assert err(dx, xr.grad, True) < 6e-2, mode
         for n in p:
-            assert err(gr[n], pr[n].grad, True) < 6e-2, (mode, n)
+            assert err(gr[n], pr[n].grad, True) < 8e-2, (mode, n)      # sums through two ReLU masks of bf16-rounded gradients
     # and against each other: the same products in another summation order, then the same rounding
     for a, b in zip(out["1"], out["0"]):
         if isinstance(a, dict):

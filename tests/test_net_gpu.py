@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from msau_amd.model import MSAUWrapper, TrainEngine
-from tests.golden_util import NET_CASES, load_net_case, rel_err, summarize
+from tests.golden_util import NET_CASES, err, load_net_case, rel_err, summarize
 
 pytestmark = pytest.mark.gpu
 LOGIT_TOL = {"fp32": 2e-4, "bf16": 6e-2}
@@ -409,8 +409,19 @@ def test_fused_residual_pair_is_bit_identical_to_two_launches(monkeypatch, dtype
         del eng, m, plan
         torch.cuda.empty_cache()
     (l1, g1, p1, a1, q1), (l0, g0, p0, a0, q0) = outs
+    # fp32 storage (tile kernels on both sides): identical bits everywhere.  bf16: the 8- / 16-channel pairs run the
+    # row-streaming kernels (conv_rows.hip), whose forward reproduces the single launches bit for bit (same k order per
+    # output) while its data gradients sum the taps in another order -- activations identical, gradients within rounding.
+    exact = dtype == "fp32"
     for name in a0:
         assert torch.equal(a1[name][0], a0[name][0]), ("activation", name)
         if a0[name][1] is not None:
-            assert torch.equal(a1[name][1], a0[name][1]), ("gradient", name)
-    assert l1 == l0 and torch.equal(g1, g0) and torch.equal(p1, p0) and torch.equal(q1, q0)
+            if exact:
+                assert torch.equal(a1[name][1], a0[name][1]), ("gradient", name)
+            else:
+                assert err(a1[name][1].float().cpu(), a0[name][1].float().cpu(), True) < 2e-2, ("gradient", name)
+    assert l1 == l0 and torch.equal(q1, q0)
+    if exact:
+        assert torch.equal(g1, g0) and torch.equal(p1, p0)
+    else:
+        assert err(g1.cpu(), g0.cpu(), True) < 2e-2 and float((p1 - p0).abs().max()) < 5e-5
