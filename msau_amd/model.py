@@ -14,6 +14,7 @@ Two ways to train:
 from __future__ import annotations
 
 import os
+import weakref
 
 import math
 from collections import OrderedDict
@@ -465,6 +466,37 @@ class TrainEngine:
         # host had synchronised produced corrupted steps on ROCm 7.2 / gfx950 (nodes of consecutive launches
         # overlapping; found 2026-10-03 with tools/loss_trace.py) -- never launch these graphs into stream 0.
         self._gstream = torch.cuda.Stream(device=flat.device)
+        # Captured graphs are filed on the plan under this token.  It is never re-used (id(self) is, once an engine is
+        # freed: a second engine for the same model -- an lr sweep, a resume -- could then replay the dead engine's graphs,
+        # whose kernel arguments point at ITS freed moments and carry ITS hyper-parameters), and it changes whenever a
+        # by-value kernel argument of the captured optimiser step changes (_invalidate_graphs).
+        TrainEngine._tokens += 1
+        self._token = TrainEngine._tokens
+        weakref.finalize(self, TrainEngine._drop_graphs, weakref.ref(model), self._token)
+
+    _tokens = 0
+
+    @staticmethod
+    def _drop_graphs(model_ref, token):
+        model = model_ref()
+        if model is not None:
+            for plan in model._plans.values():
+                plan.__dict__.get("_tgraphs", {}).pop(token, None)
+
+    def _invalidate_graphs(self):
+        """lr / betas / eps / max_norm are by-value arguments of msau_clip_adam_step, frozen into a captured optimiser graph:
+        after changing them (load_state_dict, set_lr) the graphs of this engine are dropped and re-captured on the next step"""
+        TrainEngine._drop_graphs(weakref.ref(self.model), self._token)
+        TrainEngine._tokens += 1
+        self._token = TrainEngine._tokens
+
+    def set_hyper(self, lr=None, betas=None, eps=None, max_norm=None):
+        """change optimiser hyper-parameters between steps (the lr schedule of model/training/trainer.py:124)"""
+        if lr is not None: self.lr = float(lr)
+        if betas is not None: self.betas = tuple(betas)
+        if eps is not None: self.eps = float(eps)
+        if max_norm is not None: self.max_norm = float(max_norm)
+        self._invalidate_graphs()
 
     # -- pieces (each is a fixed launch sequence on the current stream) --
     def _fwd_bwd(self, plan: Plan, x, labels, ids=None):
@@ -513,7 +545,7 @@ class TrainEngine:
         # The captured graphs hold the plan's buffer addresses: they are stored ON the plan (as predict_nhwc does), so
         # that an evicted / rebuilt plan can never be replayed through a stale graph.
         graphs = plan.__dict__.setdefault("_tgraphs", {})
-        key = id(self)
+        key = self._token
         cur = torch.cuda.current_stream()
         gs = self._gstream
         gs.wait_stream(cur)
@@ -580,6 +612,7 @@ class TrainEngine:
             self.state[0] = float(sd["step"])
             self.lr, self.betas, self.eps = float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"])
             self.max_norm = float(sd.get("max_norm", self.max_norm))
+            self._invalidate_graphs()
             return
         groups, state = sd["param_groups"], sd["state"]
         order = [pid for g in groups for pid in g["params"]]
@@ -603,3 +636,4 @@ class TrainEngine:
         self.state[0] = float(step)
         g0 = groups[0]
         self.lr, self.betas, self.eps = float(g0["lr"]), tuple(g0["betas"]), float(g0["eps"])
+        self._invalidate_graphs()

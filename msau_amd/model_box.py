@@ -35,3 +35,17 @@ class BMSAUWrapper(MSAUWrapper):
     def _variant_cfg(self, kw: dict) -> dict:
         return dict(variant="box", num_box_convs=int(self.num_box_convs), num_box_per_channels=int(self.num_box_per_channels),
                     max_box_sizes=float(self.max_box_sizes))
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """Loads like MSAUWrapper -- and says what cannot be promised.  The stored box borders `x_min / x_max / y_min / y_max`
+        are read HERE as fractions of `max_box_sizes` (msau_box_params, oracle/box_oracle.py).  The `box_convolution` package
+        the reference imports keeps its parameters in its own re-parametrised units (reportedly scaled by the maximal input
+        size times a `reparametrization_factor`, default 8 -- the package is neither in the reference tree nor installed, so
+        this could not be checked): a checkpoint trained with the reference loads without error, but its boxes may come out at
+        a different scale.  PARITY UNPINNED; a warning is the honest interface until a fixture pins it."""
+        import warnings
+        if any(k.rsplit(".", 1)[-1] in ("x_min", "x_max", "y_min", "y_max") for k in state_dict):
+            warnings.warn("BMSAUWrapper.load_state_dict: box-border parameters are interpreted as fractions of max_box_sizes; "
+                          "the third-party BoxConv2d's own parameter units are unpinned here (no source, no fixture), so a "
+                          "reference-trained box checkpoint may not reproduce its boxes", RuntimeWarning, stacklevel=2)
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)

@@ -40,18 +40,29 @@ def save_checkpoint(model, optimizer, args, num_epochs: int = -1, isbest: bool =
     return filename
 
 
-def load_checkpoint(path: str, model=None, optimizer=None, map_location: Optional[str] = None) -> dict:
+def load_checkpoint(path: str, model=None, optimizer=None, map_location: Optional[str] = None, trusted: bool = False) -> dict:
     """Read a dict checkpoint (the reference's `load_ckpt`, io_utils.py:108-129, returns the dict and leaves the rest to
     the caller) and, when given, restore `model` (state_dict keys are the reference's) and `optimizer` (a torch
     optimizer or a `TrainEngine`; a reference-written Adam state is converted for the engine by parameter order).
-    A bare state_dict file (train_chargrid_funsd_msau.py:100-102 `torch.save(model.state_dict(), ...)`) is accepted too."""
+    A bare state_dict file (train_chargrid_funsd_msau.py:100-102 `torch.save(model.state_dict(), ...)`) is accepted too.
+    `trusted=True` allows the full unpickler for reference-written files (see below)."""
     from ..model import TrainEngine
     if not os.path.isfile(path):
         raise FileNotFoundError(f"checkpoint {path!r} does not exist")
     if map_location is None and model is not None:
         map_location = str(model.flat_parameters.device)
-    # the reference stores the pickled optimizer object next to the tensors: a plain weights-only load cannot read it
-    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    # Tensor-only files -- bare state_dicts and what save_checkpoint writes for a TrainEngine (optimizer = None) -- load with
+    # weights_only=True: no pickle code runs.  The reference's save_checkpoint also pickles the torch optimizer OBJECT
+    # (utils/io_utils.py:93-97); reading that needs the full unpickler, i.e. it executes whatever the file contains, and is
+    # therefore opt-in: trusted=True, for files you wrote yourself.
+    try:
+        ckpt = torch.load(path, map_location=map_location, weights_only=True)
+    except Exception as e:                       # pickle.UnpicklingError and friends: not a tensor-only file
+        if not trusted:
+            raise RuntimeError(f"{path!r} is not a tensor-only checkpoint (it pickles Python objects, as the reference's "
+                               f"save_checkpoint does for its optimizer); pass trusted=True to load_checkpoint to unpickle "
+                               f"it -- only for files from a source you trust") from e
+        ckpt = torch.load(path, map_location=map_location, weights_only=False)
     if "model_state" not in ckpt:
         ckpt = {"epoch": -1, "model_type": None, "optimizer": None, "model_state": ckpt, "optimizer_state": None, "cg": None}
     if model is not None:

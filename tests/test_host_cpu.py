@@ -196,7 +196,10 @@ def test_reference_written_checkpoint_loads(tmp_path):
     cfg = ast.literal_eval(str(meta["cfg"]))
     m = MSAUWrapper(cfg["channels"], cfg["n_class"], dict(scale_space_num=cfg["scale_space_num"], res_depth=cfg["res_depth"],
                                                          featRoot=cfg["featRoot"], final_act="softmax"))
-    ckpt = load_checkpoint(os.path.join(gdir, "ref_checkpoint.pth.tar"), model=m, map_location="cpu")
+    # the reference pickles its optimizer OBJECT: refused unless the caller vouches for the file
+    with pytest.raises(RuntimeError, match="trusted=True"):
+        load_checkpoint(os.path.join(gdir, "ref_checkpoint.pth.tar"), model=m, map_location="cpu")
+    ckpt = load_checkpoint(os.path.join(gdir, "ref_checkpoint.pth.tar"), model=m, map_location="cpu", trusted=True)
     assert set(ckpt) == {"epoch", "model_type", "optimizer", "model_state", "optimizer_state", "cg"}
     assert ckpt["epoch"] == 7 and ckpt["model_type"] == "msau" and ckpt["cg"] is None
     assert isinstance(ckpt["optimizer"], torch.optim.Adam)

@@ -162,7 +162,7 @@ def test_reference_checkpoint_resumes_on_the_engine(tmp_path):
     m = MSAUWrapper(cfg["channels"], cfg["n_class"], dict(scale_space_num=cfg["scale_space_num"], res_depth=cfg["res_depth"],
                                                          featRoot=cfg["featRoot"], final_act="softmax", dtype="fp32")).cuda()
     eng = TrainEngine(m, lr=3e-3)
-    ck = load_checkpoint(os.path.join(gdir, "ref_checkpoint.pth.tar"), model=m, optimizer=eng)
+    ck = load_checkpoint(os.path.join(gdir, "ref_checkpoint.pth.tar"), model=m, optimizer=eng, trusted=True)
     x = torch.from_numpy(meta["x"]).cuda()
     with torch.no_grad():
         _, logits, aux = m(x)
@@ -219,6 +219,43 @@ def test_train_graphs_die_with_their_plan():
         torch.cuda.synchronize()
         assert len(m._plans) <= 2
         res[use_graph] = (out, m.flat_parameters.clone())
+    assert res[False][0] == res[True][0], res
+    assert torch.equal(res[False][1], res[True][1])
+
+
+# ---- graphs keyed by id(engine), hyper-parameters frozen into the captured optimiser step -------------------------
+def test_train_graphs_belong_to_one_engine_and_follow_its_hyper_parameters():
+    """(1) a second TrainEngine for the same model never replays the first one's graphs, even when CPython hands it the
+    dead engine's id(): engines file their graphs under a counter, and a freed engine's entries are dropped;
+    (2) load_state_dict / set_hyper after a graph step re-capture the optimiser graph (lr, betas, eps, max_norm are by-value
+    kernel arguments): the graph engine keeps matching an eager engine through a change of lr and a state reload."""
+    g, cfg, sd, x, label = load_net_case("net_f4_c13_b2_64x48")
+    x, label = x.cuda(), label.cuda()
+    m = _model(cfg, sd, "fp32", deterministic=True)
+    e1 = TrainEngine(m, lr=1e-3, use_graph=True)
+    e1.step(x, label)
+    plan = m._plan_for(x, True)
+    tok1 = e1._token
+    assert tok1 in plan._tgraphs
+    del e1
+    import gc
+    gc.collect()
+    assert tok1 not in plan._tgraphs                      # a dead engine leaves nothing to replay
+    e2 = TrainEngine(m, lr=1e-5, use_graph=True)
+    assert e2._token != tok1
+    res = {}
+    for use_graph in (False, True):
+        mm = _model(cfg, sd, "fp32", deterministic=True)
+        eng = TrainEngine(mm, lr=1e-3, use_graph=use_graph)
+        losses = [float(eng.step(x, label)) for _ in range(2)]
+        eng.set_hyper(lr=1e-5)
+        losses += [float(eng.step(x, label)) for _ in range(2)]
+        st = eng.state_dict()
+        st["lr"] = 3e-4
+        eng.load_state_dict(st)
+        losses += [float(eng.step(x, label)) for _ in range(2)]
+        torch.cuda.synchronize()
+        res[use_graph] = (losses, mm.flat_parameters.clone())
     assert res[False][0] == res[True][0], res
     assert torch.equal(res[False][1], res[True][1])
 
