@@ -226,6 +226,26 @@ def secondary_measurements(args, L, MSAUWrapper, TrainEngine, dev, n_class):
             occ = x.sum(1) > 0
             ids = torch.where(occ, x.argmax(1), torch.full_like(x.argmax(1), -1)).to(torch.int32).contiguous()
         step = (lambda: eng.step_ids(ids, label)) if feed == "ids" else (lambda: eng.step(x, label))
+        if feed == "device-painted":
+            # the BERT chargrid as its loader builds it (data_generator_funsd_bert.py:64-93): one feature vector per text line
+            # painted over the line's box.  Box lists and the feature table live on the device; every step paints the grid
+            # into the plan's own NHWC buffer (msau_raster_dense) and the label mask (msau_raster_labels) -- no fp32 NCHW tensor,
+            # no conversion.  ~30 % of the pixels covered, as the dense entry's synthetic occupancy.
+            import numpy as np
+            rng = np.random.default_rng(7)
+            fb, lb = [], []
+            for b in range(batch):
+                for r in range(0, H - 6, 8):                       # a line of text every 8 rows, 3 rows high, several fields per line
+                    xx = int(rng.integers(0, 8))
+                    while xx < W - 8:
+                        w = int(rng.integers(24, 96))
+                        fb.append((b, r, r + 3, xx, min(W, xx + w), len(fb)))
+                        lb.append((b, r, r + 3, xx, min(W, xx + w), int(rng.integers(1, n_class))))
+                        xx += w + int(rng.integers(4, 24))
+            fbt = torch.from_numpy(np.asarray(fb, np.int32)).to(dev)
+            lbt = torch.from_numpy(np.asarray(lb, np.int32)).to(dev)
+            feats = torch.randn((len(fb), channels), device=dev)
+            step = lambda: eng.step_boxes(fbt, lbt, batch, H, W, feats=feats)
         for _ in range(5):
             step()
         torch.cuda.synchronize()
@@ -252,6 +272,9 @@ def secondary_measurements(args, L, MSAUWrapper, TrainEngine, dev, n_class):
         torch.cuda.empty_cache()
 
     run("cfg4: BERT-embedding chargrid 336x256x768, 2-stage (BASELINE configs[3])", 768, 2, "bf16", args.batch)
+    if hasattr(TrainEngine, "step_boxes"):
+        run("cfg4 fed from box lists: the embedding grid is painted on the device into the plan's NHWC input every step (no fp32 NCHW tensor, no boundary conversion; SURVEY 8f N1)",
+            768, 2, "bf16", args.batch, feed="device-painted")
     run("cfg2 in fp32 storage (the parity mode of the same kernels)", args.channels, args.stages, "fp32", args.batch)
     run("cfg5: model_box variant 512x384x64, 3-stage (BASELINE configs[4]; BoxConv2d is third-party: self-consistent only)", 64, 3,
         "bf16", args.batch, box=True, hw=(512, 384))

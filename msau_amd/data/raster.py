@@ -33,24 +33,45 @@ def document_boxes(doc: dict, sample: int = 0) -> Tuple[np.ndarray, np.ndarray, 
     return (np.asarray(chars, np.int32).reshape(-1, 6), np.asarray(labs, np.int32).reshape(-1, 6), geo["H"], geo["W"])
 
 
-def rasterize(char_boxes: np.ndarray, label_boxes: np.ndarray, B: int, H: int, W: int, C: int,
-              dtype: str = "bf16", device="cuda") -> Tuple[torch.Tensor, torch.Tensor]:
-    """-> (grid [B,H,W,Cs] one-hot in `dtype` storage, labels int64 [B,H,W]) on `device`"""
+def _dev_boxes(boxes, dev):
+    """box list -> (device int32 [n][6] tensor or None, n); numpy arrays are uploaded, device tensors taken as they are"""
+    if isinstance(boxes, torch.Tensor):
+        assert boxes.dtype == torch.int32 and boxes.is_contiguous() and boxes.device == dev
+        return (boxes if boxes.numel() else None), int(boxes.shape[0])
+    arr = np.ascontiguousarray(boxes, dtype=np.int32).reshape(-1, 6)
+    return (torch.from_numpy(arr).to(dev) if len(arr) else None), len(arr)
+
+
+def rasterize(char_boxes, label_boxes, B: int, H: int, W: int, C: int,
+              dtype: str = "bf16", device="cuda", out: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (grid [B,H,W,Cs] one-hot in `dtype` storage, labels int64 [B,H,W]) on `device`.  `out`: paint the grid into this
+    buffer (a plan's own input buffer: TrainEngine.input_nhwc) instead of a new tensor.  Box lists may be numpy arrays
+    (uploaded here) or int32 device tensors (nothing crosses PCIe, no host synchronisation)."""
     dt = L.BF16 if dtype in ("bf16", "bfloat16") else L.F32
     Cs = -(-C // 8) * 8
     dev = torch.device(device)
+    if dev.index is None and dev.type == "cuda":
+        dev = torch.device("cuda", torch.cuda.current_device())
     s = torch.cuda.current_stream(dev).cuda_stream
     owner = torch.empty((B, H, W), dtype=torch.int32, device=dev)
-    grid = torch.empty((B, H, W, Cs), dtype=torch.bfloat16 if dt == L.BF16 else torch.float32, device=dev)
+    tdt = torch.bfloat16 if dt == L.BF16 else torch.float32
+    grid = out if out is not None else torch.empty((B, H, W, Cs), dtype=tdt, device=dev)
+    assert tuple(grid.shape) == (B, H, W, Cs) and grid.dtype == tdt and grid.is_contiguous(), (grid.shape, grid.dtype)
     labels = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    keep = []
     for boxes, kind in ((char_boxes, "grid"), (label_boxes, "labels")):
-        bt = torch.from_numpy(np.ascontiguousarray(boxes, dtype=np.int32)).to(dev)
-        L.call("msau_raster_owner", s, bt.data_ptr() if len(boxes) else None, len(boxes), owner.data_ptr(), B, H, W)
+        bt, n = _dev_boxes(boxes, dev)
+        keep.append(bt)
+        L.call("msau_raster_owner", s, bt.data_ptr() if n else None, n, owner.data_ptr(), B, H, W)
         if kind == "grid":
-            L.call("msau_raster_onehot", s, dt, bt.data_ptr(), owner.data_ptr(), grid.data_ptr(), B, H, W, C, Cs)
+            L.call("msau_raster_onehot", s, dt, bt.data_ptr() if n else None, owner.data_ptr(), grid.data_ptr(), B, H, W, C, Cs)
         else:
-            L.call("msau_raster_labels", s, bt.data_ptr(), owner.data_ptr(), labels.data_ptr(), B, H, W)
-        torch.cuda.current_stream(dev).synchronize()          # `bt` must outlive the launches that read it
+            L.call("msau_raster_labels", s, bt.data_ptr() if n else None, owner.data_ptr(), labels.data_ptr(), B, H, W)
+    # uploaded box lists must outlive the launches that read them; torch's caching allocator frees stream-ordered, and the
+    # launches above are on torch's current stream -- record the tensors on it instead of synchronising the host
+    for t in keep + [owner]:
+        if t is not None:
+            t.record_stream(torch.cuda.current_stream(dev))
     return grid, labels
 
 
@@ -63,26 +84,38 @@ def document_line_boxes(doc: dict, sample: int = 0, feat_base: int = 0):
     return np.asarray(fb, np.int32).reshape(-1, 6), np.asarray(lb, np.int32).reshape(-1, 6), H, W
 
 
-def rasterize_dense(feat_boxes: np.ndarray, label_boxes: np.ndarray, feats: np.ndarray, B: int, H: int, W: int,
-                    dtype: str = "bf16", device="cuda") -> Tuple[torch.Tensor, torch.Tensor]:
+def rasterize_dense(feat_boxes, label_boxes, feats, B: int, H: int, W: int,
+                    dtype: str = "bf16", device="cuda", out: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """-> (grid [B,H,W,Cs] with feats[value] painted over each box in `dtype` storage, labels int64 [B,H,W]); only the
-    box list and the [n_lines, C] feature table cross PCIe (at 768 channels the dense fp32 grid is 264 MB per tile)"""
+    box list and the [n_lines, C] feature table cross PCIe (at 768 channels the dense fp32 grid is 264 MB per tile).  `out`,
+    device-tensor arguments: as `rasterize`."""
     dt = L.BF16 if dtype in ("bf16", "bfloat16") else L.F32
-    feats = np.ascontiguousarray(feats, dtype=np.float32)
-    C = feats.shape[1]
-    Cs = -(-C // 8) * 8
     dev = torch.device(device)
+    if dev.index is None and dev.type == "cuda":
+        dev = torch.device("cuda", torch.cuda.current_device())
+    if isinstance(feats, torch.Tensor):
+        assert feats.dtype == torch.float32 and feats.is_contiguous() and feats.device == dev
+        ft = feats
+    else:
+        ft = torch.from_numpy(np.ascontiguousarray(feats, dtype=np.float32)).to(dev)
+    C = int(ft.shape[1])
+    Cs = -(-C // 8) * 8
     s = torch.cuda.current_stream(dev).cuda_stream
     owner = torch.empty((B, H, W), dtype=torch.int32, device=dev)
-    grid = torch.empty((B, H, W, Cs), dtype=torch.bfloat16 if dt == L.BF16 else torch.float32, device=dev)
+    tdt = torch.bfloat16 if dt == L.BF16 else torch.float32
+    grid = out if out is not None else torch.empty((B, H, W, Cs), dtype=tdt, device=dev)
+    assert tuple(grid.shape) == (B, H, W, Cs) and grid.dtype == tdt and grid.is_contiguous(), (grid.shape, grid.dtype)
     labels = torch.empty((B, H, W), dtype=torch.int64, device=dev)
-    ft = torch.from_numpy(feats).to(dev)
+    keep = [ft]
     for boxes, kind in ((feat_boxes, "grid"), (label_boxes, "labels")):
-        bt = torch.from_numpy(np.ascontiguousarray(boxes, dtype=np.int32)).to(dev)
-        L.call("msau_raster_owner", s, bt.data_ptr() if len(boxes) else None, len(boxes), owner.data_ptr(), B, H, W)
+        bt, n = _dev_boxes(boxes, dev)
+        keep.append(bt)
+        L.call("msau_raster_owner", s, bt.data_ptr() if n else None, n, owner.data_ptr(), B, H, W)
         if kind == "grid":
-            L.call("msau_raster_dense", s, dt, bt.data_ptr(), owner.data_ptr(), ft.data_ptr(), grid.data_ptr(), B, H, W, C, Cs)
+            L.call("msau_raster_dense", s, dt, bt.data_ptr() if n else None, owner.data_ptr(), ft.data_ptr(), grid.data_ptr(), B, H, W, C, Cs)
         else:
-            L.call("msau_raster_labels", s, bt.data_ptr(), owner.data_ptr(), labels.data_ptr(), B, H, W)
-        torch.cuda.current_stream(dev).synchronize()          # `bt` / `ft` must outlive the launches that read them
+            L.call("msau_raster_labels", s, bt.data_ptr() if n else None, owner.data_ptr(), labels.data_ptr(), B, H, W)
+    for t in keep + [owner]:
+        if t is not None:
+            t.record_stream(torch.cuda.current_stream(dev))
     return grid, labels

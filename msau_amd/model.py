@@ -499,8 +499,8 @@ class TrainEngine:
         self._invalidate_graphs()
 
     # -- pieces (each is a fixed launch sequence on the current stream) --
-    def _fwd_bwd(self, plan: Plan, x, labels, ids=None):
-        plan.forward(self.model._flat, x, export=False, ids=ids)
+    def _fwd_bwd(self, plan: Plan, x, labels, ids=None, nhwc_ready=False):
+        plan.forward(self.model._flat, x, export=False, ids=ids, nhwc_ready=nhwc_ready)
         loss = plan.loss_grads(labels)
         # MSAU_DP_BUCKETS=1: ONE all-reduce of the whole flat gradient after the backward instead of a bucket per stage
         # issued while the earlier stages' backward still runs (fewer launches and joins, no overlap)
@@ -587,6 +587,44 @@ class TrainEngine:
         self._allreduce()
         self._optim()
         return loss
+
+    def input_nhwc(self, B: int, H: int, W: int) -> torch.Tensor:
+        """The training plan's own input buffer for this shape, [B][H][W][Cs] in the storage dtype: the zero-copy target of
+        a device-side producer (msau_amd.data.raster: `rasterize(..., out=...)`, `rasterize_dense(..., out=...)`)."""
+        return self.model._plan_for_shape(B, H, W, self.model._flat.device, True).input_nhwc
+
+    def step_nhwc(self, grid: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        """One optimisation step on a chargrid that is ALREADY on the device in the kernels' layout ([B][H][W][Cs], storage
+        dtype) -- what the device painters produce (data_generator_funsd_bert.py:64-93,240).  When `grid` is
+        the plan's own buffer (`input_nhwc(B, H, W)`) nothing is copied or converted; otherwise one device copy.  `step(x, l)`
+        on the same grid as fp32 NCHW spends a quarter of the 768-channel step (cfg 4) converting 4.2 GB: identical result."""
+        if self.use_graph:
+            raise RuntimeError("step_nhwc is an eager path (use_graph=False)")
+        B, H, W, Cs = grid.shape
+        plan = self.model._plan_for_shape(B, H, W, grid.device, True)
+        buf = plan.input_nhwc
+        if tuple(grid.shape) != tuple(buf.shape) or grid.dtype != buf.dtype:
+            raise ValueError(f"step_nhwc wants {tuple(buf.shape)} {buf.dtype} (channels padded to a multiple of 8), got {tuple(grid.shape)} {grid.dtype}")
+        if grid.data_ptr() != buf.data_ptr():
+            buf.copy_(grid)
+        labels = labels.reshape(B, H, W).contiguous().long()
+        loss = self._fwd_bwd(plan, None, labels, nhwc_ready=True)
+        self._allreduce()
+        self._optim()
+        return loss
+
+    def step_boxes(self, grid_boxes, label_boxes, B: int, H: int, W: int, feats=None) -> torch.Tensor:
+        """One optimisation step from BOX LISTS (int32 [n][6] = sample, y0, y1, x0, x1, value; msau_amd/data/raster.py): the
+        one-hot grid (feats None: value = character id) or the dense embedding grid (feats fp32 [n_vectors][channels]: value
+        = row of feats) and the label mask are painted on the device, the grid straight into the plan's input buffer.
+        Only the lists (KBs) and the feature table cross PCIe.  Arguments may be numpy arrays or device tensors."""
+        from .data import raster
+        buf = self.input_nhwc(B, H, W)
+        if feats is None:
+            _, labels = raster.rasterize(grid_boxes, label_boxes, B, H, W, self.model.channels, self.model.dtype_name, buf.device, out=buf)
+        else:
+            _, labels = raster.rasterize_dense(grid_boxes, label_boxes, feats, B, H, W, self.model.dtype_name, buf.device, out=buf)
+        return self.step_nhwc(buf, labels)
 
     @property
     def grad_norm(self) -> torch.Tensor:

@@ -1390,12 +1390,22 @@ class Plan:
                    self.head_argmax.data_ptr(), lg.npix, lg.C, lg.Cs)
         return self.head_probs, self.head_argmax
 
+    @property
+    def input_nhwc(self) -> torch.Tensor:
+        """The net's input buffer: [B][H][W][Cs] in the storage dtype, channels beyond `channels` zero.  A producer on the
+        device (the chargrid painters, msau_amd/data/raster.py) writes here and calls forward(..., nhwc_ready=True)."""
+        return self.x_in.data
+
     def forward(self, flat_params: torch.Tensor, x_nchw: Optional[torch.Tensor], export: bool = True,
-                ids: Optional[torch.Tensor] = None):
-        """`ids` (int32 [B,H,W] character ids, -1 = empty) instead of `x_nchw`: the one-hot grid is painted on the device"""
+                ids: Optional[torch.Tensor] = None, nhwc_ready: bool = False):
+        """`ids` (int32 [B,H,W] character ids, -1 = empty) instead of `x_nchw`: the one-hot grid is painted on the device.
+        `nhwc_ready`: the input buffer (`input_nhwc`) already holds the grid -- no boundary conversion at all."""
         s = self._stream()
         self.pack(flat_params)
-        if ids is not None:
+        if nhwc_ready:
+            assert x_nchw is None and ids is None
+            self._feed_ids(None)
+        elif ids is not None:
             assert ids.dtype == torch.int32 and ids.is_contiguous() and tuple(ids.shape) == (self.B, self.H, self.W), (ids.shape, ids.dtype)
             if not self._feed_ids(ids):
                 self.load_ids(ids)

@@ -167,3 +167,44 @@ def test_bmsau_trains_in_bf16_and_matches_fp32_storage():
         losses[dtype] = ls
         assert ls[-1] < ls[0], (dtype, ls)
     assert abs(losses["fp32"][0] - losses["bf16"][0]) < 3e-2 * losses["fp32"][0], losses
+
+
+def test_bmsau_at_the_size_of_baseline_config_5():
+    """BASELINE configs[4]: model/model_box.py at 512x384x64, 3 stages, the reference's constructor defaults for the box blocks
+    (3 box convs, 3 boxes per channel, max box 28) -- one tile in fp32 storage through BMSAUWrapper + TrainEngine against the
+    CPU restatement: logits, loss, global gradient norm and every parameter gradient.  (The smaller cases above cover the
+    arithmetic; this one covers the launch geometry of the full-size path: integral images of 393 x 513 entries, 24-, 48-,
+    96- and 192-channel box filters, the attention bottleneck at 64 x 48.)  PARITY UNPINNED, as everything in this file."""
+    cfg = dict(BO.DEFAULT_BOX_CFG, channels=64, n_class=5, scale_space_num=4, num_blocks=3)
+    sd = BO.init_params(cfg, seed=31)
+    x, label = O.synthetic_batch(1, 64, 512, 384, 5, seed=32)
+    m = BMSAUWrapper(64, 5, _kw(cfg, "fp32"))
+    m.load_state_dict(sd)
+    m = m.cuda()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lr, ar = BO.bmsau_forward(leaves, x, cfg)
+    ref_loss = O.msau_loss(lr, ar, label)
+    ref_loss.backward()
+    with torch.no_grad():
+        pred, logits, aux = m(x.cuda())
+    assert rel_err(logits.cpu(), lr.detach()) < 1e-3 and rel_err(aux.cpu(), ar.detach()) < 1e-3
+    eng = TrainEngine(m)
+    loss = eng.step(x.cuda(), label.cuda())
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref_loss.detach())) < 3e-4 * abs(float(ref_loss.detach()))
+    ref_flat = torch.zeros_like(eng.flat_grad).cpu()
+    for k, off in m._poff.items():
+        if leaves[k].grad is not None:
+            ref_flat[off:off + leaves[k].numel()] = leaves[k].grad.reshape(-1)
+    got = eng.flat_grad.cpu()
+    gn_ref, gn = float(ref_flat.norm()), float(got.norm())
+    assert abs(gn - gn_ref) < 5e-3 * gn_ref, (gn, gn_ref)
+    assert float((got - ref_flat).norm()) < 2e-2 * gn_ref
+    gmax = float(ref_flat.abs().max())
+    for k, off in m._poff.items():
+        n = leaves[k].numel()
+        r, g_ = ref_flat[off:off + n], got[off:off + n]
+        if leaves[k].grad is None:
+            assert float(g_.abs().max()) == 0.0, k
+        else:
+            assert float((g_ - r).abs().max()) < 3e-2 * (float(r.abs().max()) + 1e-3 * gmax), k

@@ -318,6 +318,52 @@ def test_device_dense_rasteriser_matches_cpu_painter(dtype, tmp_path):
         assert torch.equal(labels[0].cpu(), it["label"][0].long()), i
 
 
+@pytest.mark.parametrize("dtype,dense", [("fp32", True), ("bf16", True), ("bf16", False)])
+def test_training_from_box_lists_equals_the_step_on_the_painted_tensor(dtype, dense):
+    """TrainEngine.step_boxes / step_nhwc (N1; data_generator_funsd_bert.py:64-93,240): the box lists are painted on the device
+    straight into the plan's NHWC input buffer -- no fp32 NCHW tensor, no boundary conversion -- against TrainEngine.step on
+    the same grid handed over as the reference does (float [B,C,H,W]): every bit of loss, gradient and updated parameters.
+    dense: 24-d feature vectors per line box (the BERT painter); else one-hot character ids."""
+    from msau_amd.data.raster import rasterize, rasterize_dense
+    torch.manual_seed(3)
+    B, H, W, C, ncls = 3, 40, 56, 24, 5
+    rng = np.random.default_rng(11)
+    boxes, labs = [], []
+    for b in range(B):
+        for i in range(14):
+            y0, x0 = int(rng.integers(0, H - 4)), int(rng.integers(0, W - 6))
+            y1, x1 = y0 + int(rng.integers(1, 6)), x0 + int(rng.integers(2, 12))       # some reach over the edge: clipped
+            boxes.append((b, y0, y1, x0, x1, len(boxes) if dense else int(rng.integers(0, C))))
+            labs.append((b, y0, y1, x0, x1, int(rng.integers(1, ncls))))
+    boxes, labs = np.asarray(boxes, np.int32), np.asarray(labs, np.int32)
+    feats = rng.standard_normal((len(boxes), C)).astype(np.float32) if dense else None
+    kw = dict(scale_space_num=3, res_depth=2, featRoot=8, final_act="softmax", num_blocks=2, dtype=dtype, seed=4, deterministic=True)
+    res = {}
+    for mode in ("boxes", "tensor"):
+        m = MSAUWrapper(C, ncls, kw).cuda()
+        eng = TrainEngine(m)
+        if mode == "boxes":
+            losses = [float(eng.step_boxes(boxes, labs, B, H, W, feats=feats)) for _ in range(2)]
+            # the grid was painted into the plan's own buffer: same storage
+            assert eng.input_nhwc(B, H, W).data_ptr() == m._plan_for_shape(B, H, W, torch.device("cuda", 0), True).x_in.data.data_ptr()
+        else:
+            if dense:
+                grid, labels = rasterize_dense(boxes, labs, feats, B, H, W, dtype)
+            else:
+                grid, labels = rasterize(boxes, labs, B, H, W, C, dtype)
+            x = grid[..., :C].float().permute(0, 3, 1, 2).contiguous()      # what a host-side loader would hand over
+            losses = [float(eng.step(x, labels)) for _ in range(2)]
+            # ... and a foreign NHWC tensor (one device copy) is the same step again
+            m2 = MSAUWrapper(C, ncls, kw).cuda()
+            e2 = TrainEngine(m2)
+            l2 = [float(e2.step_nhwc(grid, labels)) for _ in range(2)]
+            assert l2 == losses and torch.equal(m2.flat_parameters, m.flat_parameters)
+        torch.cuda.synchronize()
+        res[mode] = (losses, eng.flat_grad.clone(), m.flat_parameters.clone())
+    assert res["boxes"][0] == res["tensor"][0]
+    assert torch.equal(res["boxes"][1], res["tensor"][1]) and torch.equal(res["boxes"][2], res["tensor"][2])
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_training_from_id_masks_equals_dense_one_hot_input(dtype):
     """TrainEngine.step_ids (N1: only the character-id mask crosses the boundary; the one-hot grid is synthesised in LDS by
