@@ -49,24 +49,47 @@ __global__ void raster_label_kernel(const int32_t* __restrict__ boxes, const int
 }
 
 // dense painter (data_generator_funsd_bert.py:64-93 get_box_mask_box_label): the owning box's feature vector
-// feats[value][0..C) (fp32, row stride C) at every covered pixel, zeros elsewhere and in the padded channels
+// feats[value][0..C) (fp32, row stride C) at every covered pixel, zeros elsewhere and in the padded channels.
+// A WAVE paints a pixel: owner and box value are wave-uniform (scalar loads, one dependent chain per pixel instead of one per
+// 16 bytes), lane l writes the 8-channel groups l, l + 64, ...: two 16-byte reads of the (cache-resident) feature row, one
+// 16-byte store, 128 contiguous bytes per 8 lanes.  Empty pixels (most of a chargrid) skip the reads.  Four pixels per trip
+// keep four stores and their reads in flight.  (First version: a thread per 16 bytes with a 64-bit division, three dependent
+// loads and eight scalar reads each -- 0.8 ms for the 2.1 GB grid of cfg 4; this one runs at the store bandwidth.)
 template <typename T>
-__global__ void raster_dense_kernel(const int32_t* __restrict__ boxes, const int32_t* __restrict__ owner,
-                                    const float* __restrict__ feats, T* __restrict__ grid, int64_t npix, int C, int Cs) {
+__global__ __launch_bounds__(256) void raster_dense_kernel(const int32_t* __restrict__ boxes, const int32_t* __restrict__ owner,
+                                                           const float* __restrict__ feats, T* __restrict__ grid, int64_t npix, int C, int Cs) {
     const int cgs = Cs >> 3;
-    const int64_t total = npix * cgs;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t p = i / cgs;
-        const int cg = (int)(i - p * cgs);
-        const int o = owner[p];
-        const int v = o >= 0 ? boxes[(size_t)o * 6 + 5] : -1;
-        typename Vec8<T>::type out;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const bool vec = (C & 3) == 0;                                    // rows of feats are 16-byte aligned
+    for (int64_t p0 = wave * 4; p0 < npix; p0 += nwaves * 4) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = cg * 8 + j;
-            out[j] = (T)((v >= 0 && c < C) ? feats[(size_t)v * C + c] : 0.0f);
+        for (int q = 0; q < 4; ++q) {
+            const int64_t p = p0 + q;
+            if (p >= npix) break;                                     // wave-uniform
+            const int o = owner[p];
+            const int v = o >= 0 ? boxes[(size_t)o * 6 + 5] : -1;
+            T* dst = grid + p * Cs;
+            if (v < 0) {
+                for (int cg = lane; cg < cgs; cg += 64) store8<T>(dst + cg * 8, zero8<T>());
+                continue;
+            }
+            const float* row = feats + (size_t)v * C;
+            for (int cg = lane; cg < cgs; cg += 64) {
+                typename Vec8<T>::type out;
+                const int c = cg * 8;
+                if (vec && c + 8 <= C) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(row + c), hi = *reinterpret_cast<const f32x4*>(row + c + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { out[j] = (T)lo[j]; out[4 + j] = (T)hi[j]; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) out[j] = (T)(c + j < C ? row[c + j] : 0.0f);
+                }
+                store8<T>(dst + c, out);
+            }
         }
-        store8<T>(grid + i * 8, out);
     }
 }
 
@@ -77,7 +100,7 @@ extern "C" int msau_raster_dense(void* stream, int dtype, const int32_t* boxes, 
     MSAU_CHECK_ARG(owner && grid && feats && B > 0 && H > 0 && W > 0 && C > 0 && Cs >= C && Cs % 8 == 0, "raster_dense: bad args");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t npix = (int64_t)B * H * W;
-    int64_t blocks = cdiv64(npix * (Cs / 8), 256);
+    int64_t blocks = cdiv64(npix, 16);                                // a wave takes 4 pixels per trip
     if (blocks > 8192) blocks = 8192;
     if (dtype == MSAU_F32)
         hipLaunchKernelGGL(raster_dense_kernel<float>, dim3((int)blocks), dim3(256), 0, s, boxes, owner, feats, static_cast<float*>(grid), npix, C, Cs);

@@ -202,7 +202,7 @@ def test_train_script_end_to_end_on_synthetic_funsd(tmp_path, monkeypatch):
         # epoch 0 and the final dict checkpoint share one file name (the reference's own quirk,
         # utils/io_utils.py:74-77: only epochs > 0 get a number): the final write wins
         from msau_amd.training import load_checkpoint
-        ck = load_checkpoint(T.ckpt_filename(args.ckptdir, args, 0))
+        ck = load_checkpoint(T.ckpt_filename(args.ckptdir, args, 0), trusted=True)      # written two lines above, by this process
         assert set(ck["model_state"].keys()) == set(m.state_dict().keys()) and ck["epoch"] == -1
         # the reference's keys (utils/io_utils.py:94-101); the engine loop stores its Adam moments as a tensor dict
         assert set(ck) == {"epoch", "model_type", "optimizer", "model_state", "optimizer_state", "cg"}
@@ -378,9 +378,9 @@ def test_bench_size_step_runs_in_both_storage_types():
     ("bf16", 32, 8, 45, 150),        # narrow images: the 14-pixel-tile instance of the 8-channel layers
 ])
 def test_fused_residual_pair_is_bit_identical_to_two_launches(monkeypatch, dtype, B, channels, H, W):
-    """msau_conv_pair (both convs of a residual block in one launch, forward and data gradient; csrc/conv_pair.hip) against
-    the one-conv-per-launch path: same MFMA sequences, same roundings -> identical bits in every activation, every
-    gradient and the updated parameters."""
+    """msau_conv_pair (both convs of a residual block in one launch, forward and data gradient) against the one-conv-per-launch
+    path.  Tile kernels (csrc/conv_pair.hip; fp32 storage here): same MFMA sequences, same roundings -> identical bits in every
+    activation, every gradient and the updated parameters.  Row-streaming kernels (bf16, 8 / 16 channels): see below."""
     from oracle import msau_oracle as O
     x, label = O.synthetic_batch(B, channels, H, W, 5, seed=5)
     x, label = x.cuda(), label.cuda()
@@ -410,18 +410,25 @@ def test_fused_residual_pair_is_bit_identical_to_two_launches(monkeypatch, dtype
         torch.cuda.empty_cache()
     (l1, g1, p1, a1, q1), (l0, g0, p0, a0, q0) = outs
     # fp32 storage (tile kernels on both sides): identical bits everywhere.  bf16: the 8- / 16-channel pairs run the
-    # row-streaming kernels (conv_rows.hip), whose forward reproduces the single launches bit for bit (same k order per
-    # output) while its data gradients sum the taps in another order -- activations identical, gradients within rounding.
+    # row-streaming kernels (conv_rows.hip).  Same products, but the bias enters as the MFMA's C operand and the taps are
+    # grouped by kernel row, so a result can land on the other side of a bf16 rounding boundary (about one element in 10^4
+    # per layer).  From there the two runs are two equally valid bf16 trajectories: a flipped ReLU moves single gradient
+    # elements by O(1), so the bounds below are those of the bf16-vs-reference parity tests, not of a
+    # bit comparison.  What pins the row kernels themselves are the op-level tests (test_fused_gpu.py: against the tile
+    # kernels and the fp32 oracle on the same rounded operands) and the net goldens in bf16.
     exact = dtype == "fp32"
     for name in a0:
-        assert torch.equal(a1[name][0], a0[name][0]), ("activation", name)
+        if exact:
+            assert torch.equal(a1[name][0], a0[name][0]), ("activation", name)
+        else:
+            assert err(a1[name][0].float().cpu(), a0[name][0].float().cpu(), True) < 3e-2, ("activation", name)
         if a0[name][1] is not None:
             if exact:
                 assert torch.equal(a1[name][1], a0[name][1]), ("gradient", name)
             else:
-                assert err(a1[name][1].float().cpu(), a0[name][1].float().cpu(), True) < 2e-2, ("gradient", name)
-    assert l1 == l0 and torch.equal(q1, q0)
+                assert err(a1[name][1].float().cpu(), a0[name][1].float().cpu(), True) < 4e-1, ("gradient", name)
     if exact:
-        assert torch.equal(g1, g0) and torch.equal(p1, p0)
+        assert l1 == l0 and torch.equal(q1, q0) and torch.equal(g1, g0) and torch.equal(p1, p0)
     else:
-        assert err(g1.cpu(), g0.cpu(), True) < 2e-2 and float((p1 - p0).abs().max()) < 5e-5
+        assert abs(l1 - l0) < 1e-3 * abs(l0) and err(q1.float().cpu(), q0.float().cpu(), True) < 3e-2
+        assert err(g1.cpu(), g0.cpu(), True) < 3e-1 and float((p1 - p0).abs().max()) < 2.5e-4      # Adam's first step is lr * sign(g)
