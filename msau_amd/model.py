@@ -480,8 +480,11 @@ class TrainEngine:
     def _drop_graphs(model_ref, token):
         model = model_ref()
         if model is not None:
-            for plan in model._plans.values():
-                plan.__dict__.get("_tgraphs", {}).pop(token, None)
+            doomed = [plan._tgraphs.pop(token) for plan in model._plans.values() if token in plan.__dict__.get("_tgraphs", {})]
+            if doomed and torch.cuda.is_available():
+                # a graph must not be destroyed while a replay of it is still running (ROCm 7.2: the process segfaults)
+                torch.cuda.synchronize()
+            del doomed
 
     def _invalidate_graphs(self):
         """lr / betas / eps / max_norm are by-value arguments of msau_clip_adam_step, frozen into a captured optimiser graph:

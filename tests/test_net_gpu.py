@@ -421,7 +421,7 @@ def test_fused_residual_pair_is_bit_identical_to_two_launches(monkeypatch, dtype
         if exact:
             assert torch.equal(a1[name][0], a0[name][0]), ("activation", name)
         else:
-            assert err(a1[name][0].float().cpu(), a0[name][0].float().cpu(), True) < 3e-2, ("activation", name)
+            assert err(a1[name][0].float().cpu(), a0[name][0].float().cpu(), True) < 5e-2, ("activation", name)
         if a0[name][1] is not None:
             if exact:
                 assert torch.equal(a1[name][1], a0[name][1]), ("gradient", name)
@@ -430,5 +430,5 @@ def test_fused_residual_pair_is_bit_identical_to_two_launches(monkeypatch, dtype
     if exact:
         assert l1 == l0 and torch.equal(q1, q0) and torch.equal(g1, g0) and torch.equal(p1, p0)
     else:
-        assert abs(l1 - l0) < 1e-3 * abs(l0) and err(q1.float().cpu(), q0.float().cpu(), True) < 3e-2
+        assert abs(l1 - l0) < 1e-3 * abs(l0) and err(q1.float().cpu(), q0.float().cpu(), True) < 5e-2
         assert err(g1.cpu(), g0.cpu(), True) < 3e-1 and float((p1 - p0).abs().max()) < 2.5e-4      # Adam's first step is lr * sign(g)
