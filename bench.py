@@ -278,6 +278,21 @@ def secondary_measurements(args, L, MSAUWrapper, TrainEngine, dev, n_class):
     run("cfg2 in fp32 storage (the parity mode of the same kernels)", args.channels, args.stages, "fp32", args.batch)
     run("cfg5: model_box variant 512x384x64, 3-stage (BASELINE configs[4]; BoxConv2d is third-party: self-consistent only)", 64, 3,
         "bf16", args.batch, box=True, hw=(512, 384))
+    # the reference's own operating point (train_chargrid_funsd_msau.py:45-59): batch 1, a different H x W per document
+    try:
+        import argparse as _ap
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import funsd_loop
+        r = funsd_loop.run(_ap.Namespace(docs=64, epochs=2, channels=args.channels, dtype="bf16"), False)
+        out.append({"name": "funsd-loop: batch 1, 64 documents of distinct FUNSD-like sizes (60-170 x 40-130), plans cached; the reference's "
+                            "training regime, launch-bound (tools/funsd_loop.py; DESIGN section 6)",
+                    "value": r["docs_per_s"], "unit": "docs/s", "ms_per_step": r["ms_per_doc"], "dtype": "bf16", "batch": 1, "feed": "dense",
+                    "host_ms_per_step": r["host_ms_per_doc"], "first_epoch_ms_per_doc": r["first_epoch_ms_per_doc"],
+                    "launches_per_step_median_doc": r["launches_per_step"], "workload": f"B=1, HxWx{args.channels}, {args.stages}-stage",
+                    "loss": r["loss"]})
+        torch.cuda.empty_cache()
+    except Exception as e:                                   # noqa: BLE001  (a secondary line never takes the headline down)
+        out.append({"name": "funsd-loop", "error": f"{e.__class__.__name__}: {e}"})
     if hasattr(TrainEngine, "step_ids"):
         run("cfg2 fed with character-id masks (the first conv and its weight gradient read the id mask and synthesise the one-hot tile in LDS: no dense input tensor at all; SURVEY 8f N1) -- NOT the headline input", args.channels,
             args.stages, "bf16", args.batch, feed="ids")
