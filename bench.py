@@ -313,6 +313,11 @@ def main():
         sys.exit(subprocess.call(cmd))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the MSAU HIP path has no CPU fallback)")
+    # stdout carries ONE JSON line.  Libraries write there too (RCCL prints a version banner when a communicator is created):
+    # everything but the final line goes to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
@@ -457,7 +462,10 @@ def main():
                           "global_batch": world * args.batch, "parallelism": f"dp{world}",
                           "graph": bool(args.graph), "loss": round(loss_val, 5)},
                "roofline": roof, "cpu_baseline": cpu, "secondary": secondary}
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if world > 1 or os.environ.get("MSAU_FORCE_DIST") == "1":
         import torch.distributed as dist
         dist.barrier()

@@ -40,7 +40,7 @@ int msau_version(void);
 /* sizeof() of the structs below as the library was compiled, for bindings that mirror them (a mirror that is too short
  * makes the library read past it): which = 0 msau_conv_desc, 1 msau_wgrad_desc, 2 msau_pack_entry, 3 msau_unpack_entry,
  * 4 msau_op, 5 msau_lrn_args, 6 msau_pool_args, 7 msau_attn_args, 8 msau_csum_args, 9 msau_reduce_args,
- * 10 msau_conv_pack_geom, 11 msau_wgrad_geom, 12 msau_conv_pair_desc, 13 msau_box_args; -1 for anything else. */
+ * 10 msau_conv_pack_geom, 11 msau_wgrad_geom, 12 msau_conv_pair_desc, 13 msau_box_args, 14 msau_allreduce_args; -1 for anything else. */
 int msau_sizeof(int which);
 
 /* ------------------------------------------------------------------------------------------
@@ -438,7 +438,8 @@ enum {
     MSAU_OP_WGRAD_REDUCE = 10, /* args: msau_reduce_args      */
     MSAU_OP_CONV_PAIR = 11,  /* args: msau_conv_pair_desc     */
     MSAU_OP_BOX_FWD = 12,    /* args: msau_box_args           */
-    MSAU_OP_BOX_BWD = 13     /* args: msau_box_args           */
+    MSAU_OP_BOX_BWD = 13,    /* args: msau_box_args           */
+    MSAU_OP_ALLREDUCE = 14   /* args: msau_allreduce_args     */
 };
 typedef struct { int32_t kind; int32_t dtype; const void* args; } msau_op;
 typedef struct { const void* a; const void* dy; void* out; int64_t npix; int32_t C, Cs, n; float alpha, beta, k; } msau_lrn_args;
@@ -447,6 +448,7 @@ typedef struct { const void* f; const void* g; const void* h; const void* x_or_d
                  void* df; void* dg; void* dh; float* ws; int32_t B, N, Ds, Cs; } msau_attn_args;
 typedef struct { const void* g; int64_t npix; int32_t Cs; float* partials; int32_t nblk; } msau_csum_args;
 typedef struct { const float* slab_arena; float* flat_grads; const msau_unpack_entry* table_dev; int32_t n_entries, max_elems; } msau_reduce_args;
+typedef struct { void* comm; float* buf; int64_t count; } msau_allreduce_args;
 int msau_run_ops(void* stream, const msau_op* ops, int n);
 /* As msau_run_ops, but ops whose kind carries MSAU_OP_SIDE are enqueued on `side_stream` after everything
  * enqueued so far on `stream` (event fork); `stream` waits for `side_stream` at the end (join).  Used for
@@ -462,10 +464,32 @@ int msau_run_ops_overlap(void* stream, void* side_stream, const msau_op* ops, in
  * plan's deterministic mode: the level-0 LRN backward then never shares the device with a weight-gradient kernel). */
 #define MSAU_OP_JOIN 0x800
 #define MSAU_OP_PROBE 0x200
+/* msau_run_ops_dp: as msau_run_ops_overlap, with a third stream for the gradient exchange.  An op carrying MSAU_OP_COMM
+ * (MSAU_OP_ALLREDUCE records: one bucket of the flat gradient, placed behind the slab reduction that completes it) is
+ * enqueued on `comm_stream` after everything enqueued so far on `side_stream` and on `stream`; the sweep goes on meanwhile.
+ * With join != 0 `stream` finally waits for both other streams: the optimiser step may follow.  msau_run_ops runs such ops
+ * in place on its one stream. */
+#define MSAU_OP_COMM 0x400
+int msau_run_ops_dp(void* stream, void* side_stream, void* comm_stream, const msau_op* ops, int n, int join);
 int msau_probe_read(float* us, int cap, int* n);
 /* cost of an event pair with nothing between its two records, averaged over `reps` pairs on `stream` (microseconds):
  * the part of a probed duration that is the probe itself */
 int msau_probe_overhead(void* stream, int reps, float* us);
+
+/* ------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange (SURVEY 8b "msau_allreduce_bucket", 8e): one process per GPU, RCCL over xGMI.  The
+ * reference has no distributed code; the exchange sits where a DDP hook would, between loss.backward() and
+ * optimizer.step() (train_chargrid_funsd_msau.py:57-59).
+ *   msau_comm_available   : 1 if librccl.so could be loaded (it is resolved at run time, not a link dependency)
+ *   msau_comm_unique_id   : rank 0 draws the 128-byte id of a new communicator; ship it to the other ranks
+ *   msau_comm_init        : collective -- every rank, with its device current, the same id; *comm_out is the handle
+ *   msau_allreduce_bucket : in-place fp32 SUM over ranks of buf[0..count) on `stream`; asynchronous like a kernel launch
+ * ------------------------------------------------------------------------------------------ */
+int msau_comm_available(void);
+int msau_comm_unique_id(void* id128_out, int bytes);
+int msau_comm_init(void** comm_out, int world, int rank, const void* id128, int bytes);
+int msau_comm_destroy(void* comm);
+int msau_allreduce_bucket(void* stream, void* comm, float* buf, int64_t count);
 
 /* misc */
 /* occupy the stream for ~microseconds (<= 200000) with a single sleeping wave: measurement aid only */

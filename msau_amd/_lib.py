@@ -99,9 +99,15 @@ class ReduceArgs(C.Structure):
     _fields_ = [("slab_arena", vp), ("flat_grads", vp), ("table_dev", vp), ("n_entries", i32), ("max_elems", i32)]
 
 
+class AllreduceArgs(C.Structure):
+    _fields_ = [("comm", vp), ("buf", vp), ("count", i64)]
+
+
 OP_SIDE = 0x100
 OP_PROBE = 0x200
+OP_COMM = 0x400
 OP_JOIN = 0x800
+OP_ALLREDUCE = 14
 OP_WGRAD_REDUCE = 10
 OP_CONV_PAIR = 11
 OP_BOX_FWD, OP_BOX_BWD = 12, 13
@@ -117,6 +123,12 @@ _SIGNATURES = {
     "msau_conv_pair_applicable": (C.c_int, [C.c_int, C.POINTER(ConvPairDesc)]),
     "msau_conv_pair": (C.c_int, [vp, C.c_int, C.POINTER(ConvPairDesc)]),
     "msau_conv_pair_bits_bytes": (C.c_int64, [C.c_int, C.POINTER(ConvPairDesc)]),
+    "msau_comm_available": (C.c_int, []),
+    "msau_comm_unique_id": (C.c_int, [vp, C.c_int]),
+    "msau_comm_init": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, vp, C.c_int]),
+    "msau_comm_destroy": (C.c_int, [vp]),
+    "msau_allreduce_bucket": (C.c_int, [vp, vp, vp, C.c_int64]),
+    "msau_run_ops_dp": (C.c_int, [vp, vp, vp, C.POINTER(Op), C.c_int, C.c_int]),
     "msau_reload_env": (None, []),
     "msau_wgrad_geometry": (C.c_int, [C.c_int, C.POINTER(WgradDesc), C.POINTER(WgradGeom)]),
     "msau_conv2d_wgrad": (C.c_int, [vp, C.c_int, C.POINTER(WgradDesc)]),
@@ -169,7 +181,7 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 # ctypes mirrors in the order of msau_sizeof(which): load() refuses a library whose structs have another size
 ABI_STRUCTS = (ConvDesc, WgradDesc, PackEntry, UnpackEntry, Op, LrnArgs, PoolArgs, AttnArgs, CsumArgs, ReduceArgs,
-               ConvPackGeom, WgradGeom, ConvPairDesc, BoxArgs)
+               ConvPackGeom, WgradGeom, ConvPairDesc, BoxArgs, AllreduceArgs)
 
 
 class MsauHipError(RuntimeError):

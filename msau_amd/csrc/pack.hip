@@ -33,6 +33,7 @@ extern "C" int msau_sizeof(int which) {
         case 11: return (int)sizeof(msau_wgrad_geom);
         case 12: return (int)sizeof(msau_conv_pair_desc);
         case 13: return (int)sizeof(msau_box_args);
+        case 14: return (int)sizeof(msau_allreduce_args);
         default: return -1;
     }
 }

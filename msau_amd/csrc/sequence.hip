@@ -73,7 +73,7 @@ extern "C" int msau_run_ops(void* stream, const msau_op* ops, int n) {
     MSAU_CHECK_ARG(ops || n == 0, "run_ops: null list");
     for (int i = 0; i < n; ++i) {
         msau_op o = ops[i];
-        o.kind &= ~(MSAU_OP_SIDE | MSAU_OP_JOIN);       // one stream: nothing to fork or join
+        o.kind &= ~(MSAU_OP_SIDE | MSAU_OP_JOIN | MSAU_OP_COMM);       // one stream: nothing to fork or join
         int rc = run_one(stream, o, i);
         if (rc) return rc;              // msau_last_error() holds the failing launch's message
     }
@@ -81,7 +81,12 @@ extern "C" int msau_run_ops(void* stream, const msau_op* ops, int n) {
 }
 
 extern "C" int msau_run_ops_overlap(void* stream, void* side_stream, const msau_op* ops, int n, int join) {
-    MSAU_CHECK_ARG((ops || n == 0) && side_stream && side_stream != stream, "run_ops_overlap: bad args");
+    return msau_run_ops_dp(stream, side_stream, nullptr, ops, n, join);
+}
+
+extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_stream, const msau_op* ops, int n, int join) {
+    MSAU_CHECK_ARG((ops || n == 0) && side_stream && side_stream != stream && (!comm_stream || (comm_stream != stream && comm_stream != side_stream)),
+                   "run_ops_overlap: bad args");
     static thread_local std::vector<hipEvent_t> pool;          // timing-disabled events, reused across calls
     hipStream_t ms = static_cast<hipStream_t>(stream), ss = static_cast<hipStream_t>(side_stream);
     size_t used = 0;
@@ -146,11 +151,30 @@ extern "C" int msau_run_ops_overlap(void* stream, void* side_stream, const msau_
             return msau_set_error(MSAU_ERR_HIP, "run_ops_overlap: join failed");
         return 0;
     };
+    hipStream_t cs = static_cast<hipStream_t>(comm_stream);
+    bool any_comm = false;
     for (int i = 0; i < n; ++i) {
         msau_op o = ops[i];
         const bool side = o.kind & MSAU_OP_SIDE;
         const bool join_first = o.kind & MSAU_OP_JOIN;
-        o.kind &= ~(MSAU_OP_SIDE | MSAU_OP_JOIN);
+        const bool comm = o.kind & MSAU_OP_COMM;
+        o.kind &= ~(MSAU_OP_SIDE | MSAU_OP_JOIN | MSAU_OP_COMM);
+        if (comm) {
+            // the exchange of a finished bucket: behind everything released so far on the side stream (the slab reduction
+            // that completed it) and on the main stream, on a stream of its own; the sweep goes on
+            if (!cs) return msau_set_error(MSAU_ERR_ARG, "run_ops_dp: op %d needs the comm stream", i);
+            int rc = flush();
+            if (rc) return rc;
+            hipEvent_t ev;
+            rc = next_event(&ev);
+            if (rc) return rc;
+            if (hipEventRecord(ev, any_side ? ss : ms) != hipSuccess || hipStreamWaitEvent(cs, ev, 0) != hipSuccess)
+                return msau_set_error(MSAU_ERR_HIP, "run_ops_dp: comm fork failed");
+            rc = run_one(comm_stream, o, i);
+            if (rc) return rc;
+            any_comm = true;
+            continue;
+        }
         if (side) {
             pending.emplace_back(o, i);
             if ((int)pending.size() >= fork_every || (o.kind & 0xff) == MSAU_OP_WGRAD_REDUCE) {
@@ -176,6 +200,13 @@ extern "C" int msau_run_ops_overlap(void* stream, void* side_stream, const msau_
     {
         int rc = flush();
         if (rc) return rc;
+    }
+    if (any_comm && join) {
+        hipEvent_t ev;
+        int rc = next_event(&ev);
+        if (rc) return rc;
+        if (hipEventRecord(ev, cs) != hipSuccess || hipStreamWaitEvent(ms, ev, 0) != hipSuccess)
+            return msau_set_error(MSAU_ERR_HIP, "run_ops_dp: comm join failed");
     }
     if (any_side && join) return join_side();
     return 0;
@@ -229,6 +260,11 @@ static int run_one_raw(void* stream, const msau_op& o, int i) {
             case MSAU_OP_WGRAD_REDUCE: {
                 const msau_reduce_args* a = static_cast<const msau_reduce_args*>(o.args);
                 rc = msau_wgrad_reduce(stream, a->slab_arena, a->flat_grads, a->table_dev, a->n_entries, a->max_elems);
+                break;
+            }
+            case MSAU_OP_ALLREDUCE: {
+                const msau_allreduce_args* a = static_cast<const msau_allreduce_args*>(o.args);
+                rc = msau_allreduce_bucket(stream, a->comm, a->buf, a->count);
                 break;
             }
             default: return msau_set_error(MSAU_ERR_ARG, "run_ops: op %d has unknown kind %d", i, o.kind);

@@ -462,6 +462,8 @@ class TrainEngine:
         self.sync = GradSync(self.flat_grad, stage_buckets(model._poff, model._total, model.num_blocks), process_group)
         self.world = self.sync.world
         self.use_graph = use_graph
+        self._comm = None
+        self._init_native_comm(process_group)
         # Graph replays run on a dedicated non-default stream.  Replaying on the legacy NULL stream after the
         # host had synchronised produced corrupted steps on ROCm 7.2 / gfx950 (nodes of consecutive launches
         # overlapping; found 2026-10-03 with tools/loss_trace.py) -- never launch these graphs into stream 0.
@@ -501,13 +503,49 @@ class TrainEngine:
         if max_norm is not None: self.max_norm = float(max_norm)
         self._invalidate_graphs()
 
+    def _init_native_comm(self, group):
+        """The gradient exchange through the C ABI (msau_allreduce_bucket over RCCL, csrc/comm.hip) when the process group is an
+        RCCL one: rank 0 draws the communicator id, the group broadcasts it, every rank joins.  Then the all-reduce of each
+        stage's bucket is a record of the native backward sequence (Plan.set_native_dp) -- no torch.distributed call, no
+        Python between the launches.  gloo groups (CPU tests, several ranks on one card) and MSAU_DP_NATIVE=0 keep
+        msau_amd/dp.py::GradSync."""
+        import torch.distributed as dist
+        if not self.sync.active or self.use_graph or os.environ.get("MSAU_DP_NATIVE", "1") == "0":
+            return
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != "nccl":
+            return
+        if not L.load().msau_comm_available():
+            return
+        import ctypes as C
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ident = torch.zeros(128, dtype=torch.uint8, device=self.model._flat.device)
+        if rank == 0:
+            buf = (C.c_ubyte * 128)()
+            L.call("msau_comm_unique_id", buf, 128)
+            ident.copy_(torch.tensor(list(buf), dtype=torch.uint8))
+        dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        raw = bytes(ident.cpu().tolist())
+        comm = C.c_void_p()
+        L.call("msau_comm_init", C.byref(comm), world, rank, raw, 128)
+        self._comm = comm.value
+        self._comm_stream = L.concurrent_stream(self.model._flat.device, index=1)
+        weakref.finalize(self, L.load().msau_comm_destroy, self._comm)
+
     # -- pieces (each is a fixed launch sequence on the current stream) --
     def _fwd_bwd(self, plan: Plan, x, labels, ids=None, nhwc_ready=False):
         plan.forward(self.model._flat, x, export=False, ids=ids, nhwc_ready=nhwc_ready)
         loss = plan.loss_grads(labels)
         # MSAU_DP_BUCKETS=1: ONE all-reduce of the whole flat gradient after the backward instead of a bucket per stage
         # issued while the earlier stages' backward still runs (fewer launches and joins, no overlap)
-        if self.sync.active and not self.use_graph and os.environ.get("MSAU_DP_BUCKETS", "stage") != "1":
+        self._ar_native = False
+        if self._comm is not None and self.sync.active and plan.overlap_wgrad:
+            if getattr(plan, "_dp_flat", None) != self.flat_grad.data_ptr() or getattr(plan, "_dp_comm", None) != self._comm:
+                plan.set_native_dp(self._comm, self._comm_stream, self.sync.buckets, self.flat_grad)
+                plan._dp_comm = self._comm
+            plan.backward(self.flat_grad, native_dp=True)      # stage buckets exchanged inside the native sequence, joined at its end
+            self._ar_started = False
+            self._ar_native = True
+        elif self.sync.active and not self.use_graph and os.environ.get("MSAU_DP_BUCKETS", "stage") != "1":
             # bucket i of GradSync = [end convs, last stage, ..., stage 0]; a stage's bucket is reduced over RCCL as
             # soon as that stage's slab reduction is enqueued, while the earlier stages' backward still runs
             nb = self.model.num_blocks
@@ -526,6 +564,8 @@ class TrainEngine:
                self.adam_ws.data_ptr(), n, self.lr, b1, b2, self.eps, self.max_norm, 1.0 / self.world)
 
     def _allreduce(self):
+        if getattr(self, "_ar_native", False):
+            return                                       # already in the backward sequence (msau_run_ops_dp)
         if self.sync.active:
             if getattr(self, "_ar_started", False):
                 self.sync.start(0)                       # the end-conv tail: final once every stage is done

@@ -1467,7 +1467,34 @@ class Plan:
                    1.0 / self.B)
         return self.loss_buf
 
-    def backward(self, flat_grads: torch.Tensor, on_stage_done=None):
+    def set_native_dp(self, comm: int, comm_stream, buckets, flat_grads: torch.Tensor):
+        """Data parallelism through the C ABI (msau_allreduce_bucket, csrc/comm.hip): rebuild the backward sequence with one
+        MSAU_OP_ALLREDUCE record behind each stage's slab reduction (bucket order = backward order: last stage first, the
+        end-conv tail last -- msau_amd/dp.py::stage_buckets) -- the whole sweep INCLUDING the gradient exchange is then one
+        call of msau_run_ops_dp.  `comm`: handle from msau_comm_init; `buckets`: [(lo, hi)] element ranges of `flat_grads`."""
+        assert self.training and self._bwd_seq is not None and self.overlap_wgrad
+        nb = len(self._bwd_segs)
+        assert len(buckets) == nb + 1, (len(buckets), nb)
+        arr, n, keep = self._bwd_seq
+        recs = [(arr[i].kind, arr[i].args) for i in range(n)]
+        self._dp_args = []
+        out = []
+        for i, (b, start, cnt) in enumerate(self._bwd_segs):
+            out += recs[start:start + cnt]
+            lo, hi = buckets[i + 1]                      # buckets[0] is the end-conv tail, final only after the last stage
+            self._dp_args.append(L.AllreduceArgs(comm, flat_grads.data_ptr() + 4 * lo, hi - lo))
+            out.append((L.OP_ALLREDUCE | L.OP_COMM, C.addressof(self._dp_args[-1])))
+        lo, hi = buckets[0]
+        self._dp_args.append(L.AllreduceArgs(comm, flat_grads.data_ptr() + 4 * lo, hi - lo))
+        out.append((L.OP_ALLREDUCE | L.OP_COMM, C.addressof(self._dp_args[-1])))
+        seq = (L.Op * len(out))()
+        for i, (kind, args) in enumerate(out):
+            seq[i].kind, seq[i].dtype, seq[i].args = kind, self.dtype, args
+        self._bwd_seq_dp = (seq, len(out), (keep, self._dp_args))
+        self._dp_stream = comm_stream
+        self._dp_flat = flat_grads.data_ptr()
+
+    def backward(self, flat_grads: torch.Tensor, on_stage_done=None, native_dp: bool = False):
         """Run the backward sweep (external gradients must already be in place) and write the flat fp32
         parameter gradient.  `on_stage_done(stage, side_stream)` is called after each stage's launches are
         enqueued (its slab reduction is the last thing on `side_stream`): the data-parallel engine starts that
@@ -1496,6 +1523,11 @@ class Plan:
         if self._side is None:
             self._side = L.concurrent_stream(self.device)      # a stream that demonstrably overlaps with this one
         side = self._side.cuda_stream
+        if native_dp:
+            seq, m, _ = self._bwd_seq_dp
+            assert flat_grads.data_ptr() == self._dp_flat, "set_native_dp was given another gradient buffer"
+            L.call("msau_run_ops_dp", s, side, self._dp_stream.cuda_stream, seq, m, 1)
+            return
         if on_stage_done is None:
             L.call("msau_run_ops_overlap", s, side, arr, n, 1)
             return

@@ -7,6 +7,6 @@ for r in $(seq 1 "$rounds"); do
   for e in "$@"; do
     i=$((i+1))
     if [ "$e" = "-" ]; then e=""; fi
-    env $e python bench.py --no-secondary --no-cpu-baseline --no-roofline --steps 150 --warmup 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$i', '$e', d['ms_per_step'], d['value'])" | tee -a "$out/ab.log" || exit 1
+    env $e python bench.py --no-secondary --no-cpu-baseline --no-roofline --steps 150 --warmup 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$i', '$e', d['ms_per_step'], d['value'])" | tee -a "$out/ab.log" || exit 1
   done
 done
