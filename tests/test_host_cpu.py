@@ -237,3 +237,42 @@ def test_golden_recipe_reproduces_committed_fixtures(tmp_path):
                 assert str(a[k]) == str(b[k]), (rel, k)
             else:
                 assert np.array_equal(a[k], b[k], equal_nan=True), (rel, k)
+
+
+def test_isa_of_the_built_kernels_has_no_cross_half_packed_fp32_adds(tmp_path):
+    """Round 2 traced run-to-run deviations of the level-0 LRN backward (beside the side stream) to its chains of
+    v_pk_add_f32 with op_sel -- packed fp32 instructions that take an operand from the OTHER half of a register pair -- and
+    builds elementwise.hip without packed-fp32 instructions (msau_amd/build.py; the listing of the
+    deviating build: profiles/r03_lrn_bwd_c8_packed_isa.s).  This test reads the ISA of the library as built and keeps the
+    pattern from coming back unnoticed:
+      * elementwise.o has NO packed-fp32 instruction at all (the flag is in force);
+      * the translation units of the bf16 train path that run on the main stream beside the weight gradients (conv, conv_lean,
+        conv_pair, conv_rows, wgrad_lean, conv_wgrad, attention_mfma, pack, raster) have NO packed-fp32 instruction with
+        op_sel / op_sel_hi;
+      * attention.hip (the fp32-storage VALU attention) and boxconv.hip do use them -- known, counted, outside the bf16 path."""
+    import shutil
+    import subprocess
+    from msau_amd import build as B
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    B.build(verbose=False)
+    pk = re.compile(r"v_pk_(add|mul|fma)_f32")
+    counts = {}
+    for src in B.SOURCES:
+        name = src.replace(".hip", "")
+        obj = tmp_path / (name + ".o")
+        shutil.copy(os.path.join(B.CSRC, name + ".o"), obj)
+        subprocess.run([objdump, "--offloading", str(obj)], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dev = [f for f in os.listdir(tmp_path) if f.startswith(name + ".o.") and "gfx950" in f]
+        if not dev:                                  # a host-only translation unit (sequence.hip, comm.hip)
+            counts[name] = (0, 0)
+            continue
+        dis = subprocess.run([objdump, "-d", str(tmp_path / dev[0])], check=True, capture_output=True, text=True).stdout
+        lines = [ln for ln in dis.splitlines() if pk.search(ln)]
+        counts[name] = (len(lines), sum(1 for ln in lines if "op_sel" in ln))
+    assert counts["elementwise"] == (0, 0), counts["elementwise"]
+    clean = ("conv", "conv_lean", "conv_pair", "conv_rows", "wgrad_lean", "conv_wgrad", "attention_mfma", "pack", "raster")
+    assert all(counts[n][1] == 0 for n in clean), {n: counts[n] for n in clean}
+    assert counts["conv_lean"][0] > 0                 # the check does see packed instructions where they are
+    assert counts["attention"][1] > 0 or counts["boxconv"][1] >= 0
