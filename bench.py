@@ -105,17 +105,17 @@ def kernel_source_hash() -> str:
 def load_traffic(key):
     """HBM bytes per launch of `key` from the PMC file of this round -- only if it was measured on exactly these kernel
     sources (tools/make_traffic.py writes the hash); otherwise (None, reason)"""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
     try:
         tj = json.load(open(path))
     except Exception as e:                                   # noqa: BLE001
         return None, f"no traffic file ({e.__class__.__name__})"
     if tj.get("kernel_source_hash") != kernel_source_hash():
-        return None, (f"profiles/r02_traffic.json was measured on kernel sources {tj.get('kernel_source_hash')}, this tree is "
+        return None, (f"profiles/r03_traffic.json was measured on kernel sources {tj.get('kernel_source_hash')}, this tree is "
                       f"{kernel_source_hash()}: re-run tools/make_traffic.py")
     ent = tj.get("kernels", {}).get(key)
     if ent is None:
-        return None, f"profiles/r02_traffic.json has no entry for {key}"
+        return None, f"profiles/r03_traffic.json has no entry for {key}"
     return ent, None
 
 
@@ -136,11 +136,12 @@ def profile_pass(L, eng, plan, x, label, nprof):
     return rows
 
 
-def probe_in_place(eng, plan, x, label, keys, steps):
-    """durations of the MAIN-stream launches whose kernel key is in `keys`, measured inside the normal native sequence
-    (side-stream weight gradients running beside them): {key: (launches per step, avg us, algorithmic bytes per launch)}"""
+def probe_in_place(eng, plan, x, label, keys, steps, side=False):
+    """durations of the launches of one stream (main; side=True: the weight-gradient stream) whose kernel key is in `keys`,
+    measured inside the normal native sequence (the other stream's kernels running beside them):
+    {key: (launches per step, avg us, algorithmic bytes per launch)}"""
     import torch
-    order = plan.set_probe_keys(set(keys))
+    order = plan.set_probe_keys(set(keys), side=side)
     plan.read_probe()
     acc = {}
     for _ in range(max(steps, 1)):
@@ -386,8 +387,9 @@ def main():
                         gbs = meta[1] * nprof / (ms * 1e-3) / 1e9
                         tfs = meta[2] * nprof / (ms * 1e-3) / 1e12
                     f.write(f"{key}, {cnt}, {ms:.3f}, {1e3 * ms / cnt:.1f}, {ms / total_ms:.3f}, {gbs:.0f}, {tfs:.1f}\n")
-        # dominant kernel = largest share of the step among the conv / norm kernels of the op list
-        ms, key, cnt, meta = next(r for r in rows if r[3] and not r[1].startswith("msau_") and "wgrad" not in r[1])
+        # dominant kernel = the largest serialised share of the step among the launches of the op list, EITHER stream
+        # (weight gradients included; msau_* boundary / loss / optimiser passes are not layer kernels)
+        ms, key, cnt, meta = next(r for r in rows if r[3] and not r[1].startswith("msau_"))
         n_launch, alg_bytes, alg_flops = meta
         serial_us = 1e3 * ms / cnt
         # timed IN PLACE: the same native launch sequence as the timed region (weight gradients running beside it on the
@@ -396,6 +398,8 @@ def main():
         # memory-bound norm ops north_star names: LRN forward / backward and the max pool, per channel width.
         norm_keys = [k for k in plan.launch_meta if k.startswith(("lrn_", "pool_"))]
         probed = probe_in_place(eng, plan, x, label, [key] + norm_keys, min(args.steps, 30))
+        if key not in probed:                                # the dominant symbol runs on the side stream (a weight gradient)
+            probed.update(probe_in_place(eng, plan, x, label, [key], min(args.steps, 30), side=True))
         n_probe, insitu_us, bytes_probe = probed[key]
         import ctypes
         ov = ctypes.c_float(0.0)
@@ -411,6 +415,10 @@ def main():
                 norm_ops[k] = {"launches_per_step": c, "avg_launch_us": round(us, 2), "alg_MB_per_launch": round(nb / 1e6, 2),
                                "GB/s": round(nb / (us * 1e-6) / 1e9, 1), "frac": round(nb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                "avg_launch_us_serialised": round(serial.get(k, float("nan")), 2)}
+                tk, _ = load_traffic(k)
+                if tk:                                               # PMC bytes of the stand-alone pass (tools/make_traffic.py)
+                    norm_ops[k]["traffic"] = tk["hbm_bytes_per_launch"]
+                    norm_ops[k]["traffic_over_algorithmic"] = round(tk["hbm_bytes_per_launch"] / tk["alg_bytes_of_measured_launch"], 3)
         step_bytes = sum(m[1] for m in plan.launch_meta.values())
         roof = {"bound": "hbm", "kernel": key, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -190,6 +190,8 @@ int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc* d);
  * (pixel, 8-channel group) for the tile kernels (conv_pair.hip), 32 bytes of lane ballots per (row, 30-column strip) for the
  * row-streaming 8-channel bf16 kernel (conv_rows.hip).  Allocate with this, never from the layout comment above. */
 int64_t msau_conv_pair_bits_bytes(int dtype, const msau_conv_pair_desc* d);
+/* which instance takes the descriptor: 0 none, 1 a tile kernel (conv_pair.hip), 2 a row-streaming kernel (conv_rows.hip) */
+int msau_conv_pair_instance(int dtype, const msau_conv_pair_desc* d);
 /* The library reads its MSAU_* environment switches once.  msau_reload_env() makes the row-streaming kernel's switches
  * (MSAU_PAIR_ROWS, MSAU_CONV_ROWS, MSAU_ROWS_SH, MSAU_ROWS_WAVES, MSAU_ROWS_MIN_TASKS, MSAU_ROWS_MAXC) be read again on the next call: for tests and A/B
  * tools that change them inside one process. */

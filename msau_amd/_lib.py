@@ -123,6 +123,7 @@ _SIGNATURES = {
     "msau_conv_pair_applicable": (C.c_int, [C.c_int, C.POINTER(ConvPairDesc)]),
     "msau_conv_pair": (C.c_int, [vp, C.c_int, C.POINTER(ConvPairDesc)]),
     "msau_conv_pair_bits_bytes": (C.c_int64, [C.c_int, C.POINTER(ConvPairDesc)]),
+    "msau_conv_pair_instance": (C.c_int, [C.c_int, C.POINTER(ConvPairDesc)]),
     "msau_comm_available": (C.c_int, []),
     "msau_comm_unique_id": (C.c_int, [vp, C.c_int]),
     "msau_comm_init": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, vp, C.c_int]),

@@ -532,6 +532,13 @@ extern "C" int msau_conv_pair_applicable(int dtype, const msau_conv_pair_desc* d
     return 1;
 }
 
+// which instance msau_conv_pair launches for this descriptor: 0 none, 1 a tile kernel (conv_pair.hip), 2 a row-streaming kernel
+// (conv_rows.hip) -- for profiling / roofline labels, like msau_conv2d_launch_info
+extern "C" int msau_conv_pair_instance(int dtype, const msau_conv_pair_desc* d) {
+    if (!msau_conv_pair_applicable(dtype, d)) return 0;
+    return msau_rowpair_takes(dtype, d) ? 2 : 1;
+}
+
 // bytes of ONE ReLU-mask plane (bits_mid / bits_a) for this descriptor: the tile kernels keep a byte per (pixel, 8-channel
 // group), the row-streaming kernel 32 bytes of lane ballots per (row, 30-column strip)
 extern "C" int64_t msau_conv_pair_bits_bytes(int dtype, const msau_conv_pair_desc* d) {

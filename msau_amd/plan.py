@@ -577,6 +577,10 @@ class PairOp:
                         dsc.bits_mid, dsc.bits_a = _ptr(self.bits_mid), _ptr(self.bits_a)
                     self.fbytes += 2 * nbits
                     self.bbytes = 3 * n * esz + 2 * nbits
+        # label by the instance that takes the launches (the backward descriptor, once it has its planes, decides for both)
+        probe = self.bdesc if self.bdesc is not None else f
+        if L.load().msau_conv_pair_instance(P.dtype, C.byref(probe)) == 2:
+            self.key = f"rowpair_kernel<{T},C{x0.Cs}>"
         self.active = True
 
     def note(self):
@@ -1233,10 +1237,12 @@ class Plan:
             self.note_launch("msau_wgrad_reduce", self.reduce_bytes, 0.0)
             self.note_launch("msau_clip_adam_step", nparam * 4 * 8, 0.0)       # g twice, p, m, v read; p, m, v written
 
-    def set_probe_keys(self, keys) -> List[Tuple[str, float]]:
-        """Mark every MAIN-stream launch whose kernel key is in `keys` (None: unmark all) with MSAU_OP_PROBE in the forward
-        and backward sequences.  Returns [(key, algorithmic bytes)] of the marked launches in the order `read_probe`
-        reports their durations (sequence order; side-stream launches are not probed: they are released in batches)."""
+    def set_probe_keys(self, keys, side: bool = False) -> List[Tuple[str, float]]:
+        """Mark every launch of ONE stream (main, or with side=True the weight-gradient side stream) whose kernel key is in
+        `keys` (None: unmark all) with MSAU_OP_PROBE in the forward and backward sequences.  Returns [(key, algorithmic
+        bytes)] of the marked launches in the order `read_probe` reports their durations: sequence order, which is also the
+        enqueue order as long as only one stream is probed at a time (side launches are released in batches; a probed
+        weight gradient is launched on its own, not inside a grouped grid)."""
         order = []
         for seq in (self._fwd_seq, self._bwd_seq):
             if seq is None:
@@ -1244,7 +1250,7 @@ class Plan:
             arr, cnt, _ = seq
             for i in range(cnt):
                 meta = self.rec_meta.get(arr[i].args)
-                if keys is not None and meta is not None and meta[0] in keys and not (arr[i].kind & L.OP_SIDE):
+                if keys is not None and meta is not None and meta[0] in keys and bool(arr[i].kind & L.OP_SIDE) == side:
                     arr[i].kind |= L.OP_PROBE
                     order.append(meta)
                 else:

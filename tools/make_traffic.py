@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""HBM traffic per launch of the dominant kernels from PMC counters -> profiles/r02_traffic.json (read by bench.py).
+"""HBM traffic per launch of the dominant kernels from PMC counters -> profiles/r03_traffic.json (read by bench.py).
 
 Collected exactly as MI355X_MICROARCH.md prescribes: `rocprofv3 --kernel-trace --pmc <one counter>` in SEPARATE passes
 (never combined with another trace domain), FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of wide coalesced
@@ -39,6 +39,7 @@ def passes(tag, prog):
             if r["Counter_Name"] == ctr:
                 per.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
         res[ctr] = per
+        res.setdefault("_rows", {})[ctr] = [r for r in rows if r["Counter_Name"] == ctr]
     return res
 
 
@@ -51,34 +52,79 @@ def entry(res, name, launch, alg_bytes):
             "dispatches_averaged": len(f)}
 
 
+def avg_entry(res, pick, launch, alg_bytes):
+    """`pick`: kernel names (one launch kind may be several dispatches); their counters are summed per launch"""
+    fetch_kb = sum(sum(res["FETCH_SIZE"][n]) / len(res["FETCH_SIZE"][n]) for n in pick)
+    write_kb = sum(sum(res["WRITE_SIZE"][n]) / len(res["WRITE_SIZE"][n]) for n in pick)
+    return {"launch": launch, "mangled": " | ".join(pick), "FETCH_SIZE_KB": round(fetch_kb, 1), "WRITE_SIZE_KB": round(write_kb, 1),
+            "hbm_bytes_per_launch": int(round(2 * fetch_kb * 1024 + write_kb * 1024)), "alg_bytes_of_measured_launch": int(alg_bytes),
+            "dispatches_averaged": len(res["FETCH_SIZE"][pick[0]])}
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     sha = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or "unknown"
     n8 = B * H * W * 8 * 2                                       # one 8-channel bf16 tensor at level 0
     kernels = {}
-    # ---- the fused residual pair at level 0: forward launch and data-gradient launch
-    res = passes("pair", ["python3", os.path.join(ROOT, "tools", "pair_bench.py"), "3", "8"])
-    names = [n for n in res["FETCH_SIZE"] if "conv_pair_kernel" in n]
-    assert len(names) == 2, names
-    fwd = entry(res, names[0], "conv_pair forward (x0 -> r1, out, two mask bit planes), B=16 336x256 C=8", 3 * n8 + 2 * (n8 // 16))
-    bwd = entry(res, names[1], "conv_pair data gradient (g + two mask bit planes -> g_r1, g_x0), B=16 336x256 C=8", 3 * n8 + 2 * (n8 // 16))
-    both = {"launch": "mean of the forward and the data-gradient launch (12 each per step), B=16 336x256 C=8",
-            "mangled": names[0] + " | " + names[1],
+    tools = os.path.join(ROOT, "tools")
+    # ---- the residual pair at level 0 / 1 (row-streaming kernels): forward launch and data-gradient launch
+    for c, tag in ((8, "C8"), (16, "C16")):
+        res = passes(f"pair{c}", ["python3", os.path.join(tools, "pair_bench.py"), "3", str(c)])
+        fw = [n for n in res["FETCH_SIZE"] if f"rowpair_c{c}_kernel<false" in n or f"rowpair_c{c}_kernelILb0" in n]
+        bw = [n for n in res["FETCH_SIZE"] if f"rowpair_c{c}_kernel<true" in n or f"rowpair_c{c}_kernelILb1" in n]
+        assert len(fw) == 1 and len(bw) == 1, (fw, bw, list(res["FETCH_SIZE"]))
+        nt = n8 if c == 8 else n8 // 2                          # 16 channels at half the resolution: half the bytes
+        planes = 2 * B * (H if c == 8 else H // 2) * -(-(W if c == 8 else W // 2) // (30 if c == 8 else 14)) * 32
+        fwd = avg_entry(res, fw, f"residual pair forward (x0 -> r1, out, two ballot planes), B=16 C={c}", 3 * nt + planes)
+        bwd = avg_entry(res, bw, f"residual pair data gradient (g + two ballot planes -> g_r1, g_x0), B=16 C={c}", 3 * nt + planes)
+        kernels[f"rowpair_kernel<bf16,{tag}>"] = {
+            "launch": f"mean of the forward and the data-gradient launch (6 each per step), B=16 C={c}", "mangled": fwd["mangled"] + " | " + bwd["mangled"],
             "hbm_bytes_per_launch": (fwd["hbm_bytes_per_launch"] + bwd["hbm_bytes_per_launch"]) // 2,
             "alg_bytes_of_measured_launch": (fwd["alg_bytes_of_measured_launch"] + bwd["alg_bytes_of_measured_launch"]) // 2,
             "forward": fwd, "backward": bwd, "git_sha": sha}
-    kernels["conv_pair_kernel<bf16,C8>"] = both
-    # ---- the plain 8 -> 8 3x3 launch of conv_lean (the round-1 dominant symbol), forward
-    res = passes("lean", ["python3", os.path.join(ROOT, "tools", "kbench.py"), "--only", "L0 8->8", "--iters", "3"])
-    names = [n for n in res["FETCH_SIZE"] if "conv_lean_kernel" in n]
-    e = entry(res, names[0], "conv_lean plain forward 8 -> 8 3x3 (bias only), B=16 336x256", 2 * n8)
-    e["git_sha"] = sha
-    kernels["conv_lean_kernel<bf16,CIN8,CT1,K3>"] = e
+    # ---- 8 -> 8 3x3 at level 0: forward (row-streaming), data gradient (tile kernel), weight gradient
+    res = passes("l0", ["python3", os.path.join(tools, "kbench.py"), "--only", "L0 8->8", "--iters", "3"])
+    names = list(res["FETCH_SIZE"])
+    rc = [n for n in names if "rowconv8_kernel" in n]
+    wg = [n for n in names if "wgrad_lean_kernel" in n]
+    if rc:
+        e = avg_entry(res, rc[:1], "rowconv8 plain forward 8 -> 8 3x3 (bias only), B=16 336x256", 2 * n8)
+        e["git_sha"] = sha
+        kernels["rowconv_kernel<bf16,CIN8,CO8,K3>"] = e
+    if wg:
+        e = avg_entry(res, wg[:1], "weight gradient 8 -> 8 3x3 (x, g read once; slabs written), B=16 336x256", 2 * n8)
+        e["git_sha"] = sha
+        kernels["wgrad_lean_kernel<bf16,C8,CO8,K3>"] = e
+    # ---- the normalisation / pooling / boundary passes (tools/norm_bench.py: one launch of each per iteration, fixed order)
+    sys.path.insert(0, tools)
+    res = passes("norm", ["python3", os.path.join(tools, "norm_bench.py"), "3"])
+    fams = {"lrn_fwd": ("lrn_fast_kernel", False), "lrn_bwd": ("lrn_fast_kernel", True), "pool_fwd": ("pool_fwd_kernel", None),
+            "pool_bwd": ("pool_bwd_kernel", None), "msau_nchw_to_nhwc": ("nchw_to_nhwc", None)}
+    # per-dispatch rows in launch order: norm_bench launches (3 warm-up + 3 timed) x each op, op after op
+    import re
+    order = [("lrn_fwd<bf16,C8>", 2 * n8), ("lrn_bwd<bf16,C8>", 3 * n8), ("pool_fwd<bf16,C8>", n8 + n8 // 4 + n8 // 8), ("pool_bwd<bf16,C8>", n8 + n8 // 4 + n8 // 8),
+             ("lrn_fwd<bf16,C16>", n8), ("lrn_bwd<bf16,C16>", 3 * n8 // 2), ("pool_fwd<bf16,C16>", n8 // 2 + n8 // 8 + n8 // 16),
+             ("pool_bwd<bf16,C16>", n8 // 2 + n8 // 8 + n8 // 16), ("msau_nchw_to_nhwc", B * 64 * H * W * 6)]
+    seq = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        flat = [(int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"])) for r in res["_rows"][ctr]]
+        flat.sort()
+        flat = [f for f in flat if any(k in f[1] for k in ("lrn_fast_kernel", "pool_fwd_kernel", "pool_bwd_kernel", "nchw_to_nhwc"))]
+        assert len(flat) == 6 * len(order), (len(flat), len(order))
+        for i, (key, _) in enumerate(order):
+            vals = flat[6 * i + 3:6 * i + 6]                     # the three timed launches of op i
+            seq.setdefault(key, {})[ctr] = (sum(v[2] for v in vals) / len(vals), vals[0][1])
+    for key, alg in order:
+        f_kb, name = seq[key]["FETCH_SIZE"]
+        w_kb, _ = seq[key]["WRITE_SIZE"]
+        kernels[key] = {"launch": key + " stand-alone pass at its cfg-2 shape, B=16", "mangled": name, "FETCH_SIZE_KB": round(f_kb, 1),
+                        "WRITE_SIZE_KB": round(w_kb, 1), "hbm_bytes_per_launch": int(round(2 * f_kb * 1024 + w_kb * 1024)),
+                        "alg_bytes_of_measured_launch": int(alg), "dispatches_averaged": 3, "git_sha": sha}
     out = {"kernel_source_hash": bench.kernel_source_hash(), "git_sha": sha,
            "how": "tools/make_traffic.py: rocprofv3 --kernel-trace --pmc, one counter per pass; FETCH_SIZE x2 (gfx950), WRITE_SIZE as is; KB = 1024 B",
            "kernels": kernels}
     # profiles/ is the tracked copy; gpurun only brings gpurun_out/ back from the GPU box
-    for path in (os.path.join(ROOT, "profiles", "r02_traffic.json"), os.path.join(OUT, "r02_traffic.json")):
+    for path in (os.path.join(ROOT, "profiles", "r03_traffic.json"), os.path.join(OUT, "r03_traffic.json")):
         with open(path, "w") as f:
             json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
