@@ -53,9 +53,17 @@ def test_pool_in_the_conv_epilogue_is_bit_exact(monkeypatch, dtype, c, k, dual, 
     if not dual:
         p.pop("w0"); p.pop("b0")
     out = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("MSAU_FUSE_POOL", mode)
-        out[mode] = run_graph(build, p, x, gy, dtype)
+    # the pooled epilogue lives in the tile kernels: keep the un-pooled mode on them too (the row-streaming instance of the
+    # 8-channel coupling conv sums in another order and has its own test)
+    monkeypatch.setenv("MSAU_CONV_ROWS", "0")
+    L.load().msau_reload_env()
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MSAU_FUSE_POOL", mode)
+            out[mode] = run_graph(build, p, x, gy, dtype)
+    finally:
+        monkeypatch.undo()
+        L.load().msau_reload_env()
     assert took[0].fused_into is not None and took[1].fused_into is None
     for a, b in zip(out["1"], out["0"]):
         if isinstance(a, dict):
