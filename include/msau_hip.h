@@ -193,7 +193,7 @@ int64_t msau_conv_pair_bits_bytes(int dtype, const msau_conv_pair_desc* d);
 /* which instance takes the descriptor: 0 none, 1 a tile kernel (conv_pair.hip), 2 a row-streaming kernel (conv_rows.hip) */
 int msau_conv_pair_instance(int dtype, const msau_conv_pair_desc* d);
 /* The library reads its MSAU_* environment switches once.  msau_reload_env() makes the row-streaming kernel's switches
- * (MSAU_PAIR_ROWS, MSAU_CONV_ROWS, MSAU_ROWS_SH, MSAU_ROWS_WAVES, MSAU_ROWS_MIN_TASKS, MSAU_ROWS_MAXC) be read again on the next call: for tests and A/B
+ * (MSAU_PAIR_ROWS, MSAU_CONV_ROWS, MSAU_WGRAD_ROWS, MSAU_ROWS_SH, MSAU_ROWS_WAVES, MSAU_ROWS_MIN_TASKS, MSAU_ROWS_MAXC) be read again on the next call: for tests and A/B
  * tools that change them inside one process. */
 void msau_reload_env(void);
 
@@ -222,7 +222,8 @@ typedef struct {
     int32_t kext;               /* columns per row of a slab: nchunks*taps*cch + 8, rounded to 16   */
     int32_t max_slabs;          /* number of pixel tiles (upper bound for nslabs)                   */
     int64_t slab_bytes;         /* bytes of ONE slab                                                */
-    int32_t lean;               /* 1: a compile-time-specialised instance (wgrad_lean.hip) takes it */
+    int32_t lean;               /* 1: a compile-time-specialised instance (wgrad_lean.hip) takes it; 2: the row-streaming
+                                   instance (conv_rows.hip; needs d->nslabs set) */
     int32_t reserved;
 } msau_wgrad_geom;
 

@@ -758,11 +758,146 @@ __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
         [&]<int... K>(std::integer_sequence<int, K...>) { (step(IC<K>{}, tg), ...); }(std::make_integer_sequence<int, NXR>{});
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 8 -> 8 3x3 convs in the same form (msau_conv2d_wgrad descriptors; dispatched from conv_wgrad.hip).
+// The tile kernel re-reads tile halos (PMC, profiles/r03_traffic.json: x1.49 the algorithmic bytes); here a wave walks a
+// 30-column strip and every row of x and g is read exactly once.  Pixels are the MFMA's K: per 32 pixels of a row and per
+// kernel row ky ONE MFMA produces all three horizontal taps at once --
+//     D[(a, ci)][(b, co)] = sum_x  x[ci](y + ky - 1, x + a) * g[co](y, x + b)        a, b in {0, 1}
+// is the tap kx - 1 = a - b: (0,1) -> kx 0, (0,0) -> kx 1, (1,0) -> kx 2 ((1,1) repeats kx 1 and is dropped).  With the row
+// in LDS as [pixel][8 channels], the operand "8 consecutive pixels of channel c, shifted by a" is a 4 x 16 block whose 16
+// columns are the 32 contiguous bytes from pixel p: ds_read_b64_tr_b16 delivers it transposed, the shift is free.  g is zero
+// outside the strip's own 30 columns, so both shifted windows count every own pixel exactly once.  The x fragment of a row
+// serves ky = 2, 1, 0 of three consecutive output rows from registers.  The bias gradient is a fourth MFMA against ones.
+// Persistent workgroups (one per slab, the plan's nslabs): accumulators live across tasks, the four waves add up in LDS in
+// a fixed order and write the slab in the layout msau_wgrad_reduce expects ([co][tap * 8 + ci], ones column 72).
+struct RowWgradArgs {
+    msau_wgrad_desc d;
+    int nstrips, nseg, SH, ntasks;
+    int row_bytes, kext;
+    unsigned img_bytes;
+};
+
+typedef __attribute__((address_space(3))) bf16x4* lds_v4;
+constexpr int WG_ROW = 36 * 16;                                           // one staged row: 34 pixels used, 16-byte slots
+
+constexpr int WG_WAVES = 8;                                               // waves per workgroup = tasks per slab and round
+
+template <bool RELU_IN>
+__global__ __launch_bounds__(64 * WG_WAVES) void rowwgrad8_kernel(const RowWgradArgs a) {
+    __shared__ __align__(16) unsigned char smem[WG_WAVES * 2 * WG_ROW + 8 * 80 * 4];
+    const msau_wgrad_desc& d = a.d;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* xbuf = smem + wave * 2 * WG_ROW;
+    unsigned char* gbuf = xbuf + WG_ROW;
+    float* slab = reinterpret_cast<float*>(smem + WG_WAVES * 2 * WG_ROW);
+    const int H = d.Hout, W = d.Wout;
+    // zero the staging rows once: pixels of g outside the own columns stay zero for the whole kernel
+    for (int i = lane; i < 2 * WG_ROW / 16; i += 64) *reinterpret_cast<u32x4*>(xbuf + i * 16) = u32x4{0u, 0u, 0u, 0u};
+    __builtin_amdgcn_wave_barrier();
+    // transposed-read address of this lane: 16-lane group kg = lane >> 4 takes pixels 8 kg + 4 h + q, q = (lane & 15) >> 2,
+    // chunk p = lane & 3 of the 32 bytes that start at that pixel
+    const int tr_off = (8 * (lane >> 4) + ((lane & 15) >> 2)) * 16 + (lane & 3) * 8;
+    auto frag_of = [&](const unsigned char* buf) -> bf16x8 {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(buf + tr_off));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(buf + tr_off + 4 * 16));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    const u32x4 ones_bits = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    const bf16x8 ONES = __builtin_bit_cast(bf16x8, ones_bits);
+    f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accb = {0.f, 0.f, 0.f, 0.f};
+
+    const int gw = blockIdx.x * WG_WAVES + wave, nw = gridDim.x * WG_WAVES;
+    for (int task = gw; task < a.ntasks; task += nw) {                    // wave-uniform
+        const int t1 = task / a.nstrips, strip = task - t1 * a.nstrips;
+        const int b = t1 / a.nseg, seg = t1 - b * a.nseg;
+        const int x0 = strip * 30;
+        const int y0 = seg * a.SH, y1 = min(H, y0 + a.SH);
+        const long long img = (long long)b * a.img_bytes;
+        const __amdgpu_buffer_rsrc_t rx = rsrc_of(static_cast<const char*>(d.x1) + img, a.img_bytes);
+        const __amdgpu_buffer_rsrc_t rg = rsrc_of(static_cast<const char*>(d.g) + img, a.img_bytes);
+        // x: lanes 0..33 hold image columns x0 - 1 + lane; g: lanes 0..29 hold the own columns x0 + lane (staged at pixel 1 + lane)
+        const int cx = x0 - 1 + lane, cg = x0 + lane;
+        const unsigned xcol = lane < 34 && (unsigned)cx < (unsigned)W ? (unsigned)(cx * 16) : kOOB;
+        const unsigned gcol = lane < 30 && cg < W ? (unsigned)(cg * 16) : kOOB;
+        auto load_x = [&](int r) -> u32x4 {
+            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)r < (unsigned)H && r <= y1 ? (unsigned)(r * a.row_bytes) + xcol : kOOB, 0, 0);
+            if constexpr (RELU_IN) v = __builtin_bit_cast(u32x4, relu_bits(v));
+            return v;
+        };
+        auto load_g = [&](int r) -> u32x4 {
+            return __builtin_amdgcn_raw_buffer_load_b128(rg, r >= y0 && r < y1 ? (unsigned)(r * a.row_bytes) + gcol : kOOB, 0, 0);
+        };
+        auto stage_x = [&](u32x4 v) { if (lane < 34) *reinterpret_cast<u32x4*>(xbuf + lane * 16) = v; };
+        auto stage_g = [&](u32x4 v) { if (lane < 30) *reinterpret_cast<u32x4*>(gbuf + (1 + lane) * 16) = v; };
+        bf16x8 AX[3];
+        {   // fragments of x rows y0 - 1 and y0
+            const u32x4 r0 = load_x(y0 - 1), r1 = load_x(y0);
+            stage_x(r0);
+            __builtin_amdgcn_wave_barrier();
+            AX[0] = frag_of(xbuf);
+            __builtin_amdgcn_wave_barrier();
+            stage_x(r1);
+            __builtin_amdgcn_wave_barrier();
+            AX[1] = frag_of(xbuf);
+            __builtin_amdgcn_wave_barrier();
+        }
+        u32x4 PX[3], PG[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { PX[k] = load_x(y0 + 1 + k); PG[k] = load_g(y0 + k); }
+        auto step = [&](auto ic, const int tg) {
+            constexpr int I = decltype(ic)::value;
+            const int y = tg + I;
+            stage_x(PX[I]);                                               // x row y + 1
+            stage_g(PG[I]);                                               // g row y
+            PX[I] = load_x(y + 4);
+            PG[I] = load_g(y + 3);
+            __builtin_amdgcn_wave_barrier();
+            AX[(I + 2) % 3] = frag_of(xbuf);
+            const bf16x8 BG = frag_of(gbuf);
+            __builtin_amdgcn_wave_barrier();
+            acc[0] = mma8(AX[I % 3], BG, acc[0]);                         // ky 0: x row y - 1
+            acc[1] = mma8(AX[(I + 1) % 3], BG, acc[1]);
+            acc[2] = mma8(AX[(I + 2) % 3], BG, acc[2]);
+            accb = mma8(ONES, BG, accb);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int tg = y0; tg < y1; tg += 3) {
+            step(IC<0>{}, tg);
+            step(IC<1>{}, tg);
+            step(IC<2>{}, tg);
+        }
+    }
+    // ---- the waves' sums -> one slab, fixed order
+    for (int i = threadIdx.x; i < 8 * 80; i += 64 * WG_WAVES) slab[i] = 0.f;
+    __syncthreads();
+    const int n = lane & 15, kg = lane >> 4, bb = n >> 3, co = n & 7;
+#pragma unroll
+    for (int w = 0; w < WG_WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int row = 4 * kg + jj, aa = row >> 3, ci = row & 7;
+                if (!(aa == 1 && bb == 1)) {
+                    const int kx = aa - bb + 1;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) slab[co * 80 + (ky * 3 + kx) * 8 + ci] += acc[ky][jj];
+                }
+            }
+            if (kg == 0 && bb == 0) slab[co * 80 + 72] += accb[0];
+        }
+        __syncthreads();
+    }
+    float* out = d.slabs + (size_t)blockIdx.x * (8 * 80);
+    for (int i = threadIdx.x; i < 8 * 80; i += 64 * WG_WAVES) out[i] = slab[i];
+}
+
 constexpr int kFwd1 = MSAU_PAIR_RELU_IN | MSAU_PAIR_RELU_MID, kFwd2 = MSAU_CONV_ADD | MSAU_CONV_RELU_OUT;
 constexpr int kBwd1 = MSAU_PAIR_MASK_MID, kBwd2 = MSAU_CONV_MASK_A | MSAU_CONV_ADD;
 
 // environment switches of this file, read once; msau_reload_env() makes the next call read them again (tests, A/B tools)
-struct RowsEnv { int on, sh, waves, min_tasks, maxc, conv; };
+struct RowsEnv { int on, sh, waves, min_tasks, maxc, conv, wgrad; };
 RowsEnv g_env;
 bool g_env_ok = false;
 const RowsEnv& rows_env() {
@@ -772,6 +907,7 @@ const RowsEnv& rows_env() {
         g_env.sh = geti("MSAU_ROWS_SH", 0);                      // rows per segment (0: from MSAU_ROWS_WAVES)
         g_env.waves = geti("MSAU_ROWS_WAVES", 3072);             // tasks (= waves) per launch to aim for
         g_env.min_tasks = geti("MSAU_ROWS_MIN_TASKS", 16);       // below: the tile kernels (a wave per task needs a few tasks per XCD at least)
+        g_env.wgrad = geti("MSAU_WGRAD_ROWS", 1);                // the 8 -> 8 3x3 weight gradients on the row kernel
         g_env.conv = geti("MSAU_CONV_ROWS", 1);                  // single convolutions of the 8-channel level on the row kernels
         g_env.maxc = geti("MSAU_ROWS_MAXC", 16);                 // widest layer the row kernels take (8: the 16-channel pairs stay on the tile kernels)
         g_env_ok = true;
@@ -916,4 +1052,42 @@ int msau_rowconv_launch(hipStream_t s, int dtype, const msau_conv_desc* d, int k
         case 8: return launch_rowconv8<1, 4, 4, MSAU_CONV_ACCUM | MSAU_CONV_MASK_B>(s, a);
     }
     return msau_set_error(MSAU_ERR_ARG, "rowconv: no instance");
+}
+
+// ---- weight gradients (msau_conv2d_wgrad descriptors)
+int msau_rowwgrad_takes(int dtype, const msau_wgrad_desc* d, int cch, int nchunks, int kextc) {
+    const RowsEnv& e = rows_env();
+    if (!e.on || !e.wgrad || dtype != MSAU_BF16) return 0;
+    if (d->C1 != 8 || d->C2 != 0 || d->Cout != 8 || d->KH != 3 || d->KW != 3 || d->dil != 1 || d->stride != 1) return 0;
+    if (d->pad_t != 1 || d->pad_l != 1 || d->Hin != d->Hout || d->Win != d->Wout) return 0;
+    if (d->flags & ~MSAU_CONV_RELU_IN) return 0;
+    if (cch != 8 || nchunks != 1 || kextc != 80 || d->nslabs < 1) return 0;
+    if ((int64_t)d->Hout * d->Wout * 16 >= (1ll << 31)) return 0;
+    if ((int64_t)d->B * cdiv(d->Wout, 30) * cdiv(d->Hout, 8) < e.min_tasks) return 0;
+    return 1;
+}
+
+int msau_rowwgrad_launch(hipStream_t s, const msau_wgrad_desc* d) {
+    RowWgradArgs a;
+    a.d = *d;
+    a.nstrips = cdiv(d->Wout, 30);
+    const RowsEnv& e = rows_env();
+    // one round: at most one task per wave (nslabs workgroups x 8 waves), as many as that allows up to MSAU_ROWS_WAVES
+    int target = WG_WAVES * d->nslabs;
+    if (target > e.waves) target = e.waves;
+    int nseg = target / (d->B * a.nstrips);
+    if (nseg < 1) nseg = 1;
+    int sh = e.sh > 0 ? e.sh : cdiv(d->Hout, nseg);
+    if (sh < 9) sh = 9;
+    sh = roundup(sh, 3);
+    a.SH = sh < d->Hout ? sh : d->Hout;
+    a.nseg = cdiv(d->Hout, a.SH);
+    a.ntasks = d->B * a.nstrips * a.nseg;
+    a.row_bytes = d->Wout * 16;
+    a.img_bytes = (unsigned)d->Hout * (unsigned)a.row_bytes;
+    a.kext = 80;
+    if (d->flags & MSAU_CONV_RELU_IN) hipLaunchKernelGGL((rowwgrad8_kernel<true>), dim3(d->nslabs), dim3(64 * WG_WAVES), 0, s, a);
+    else hipLaunchKernelGGL((rowwgrad8_kernel<false>), dim3(d->nslabs), dim3(64 * WG_WAVES), 0, s, a);
+    MSAU_CHECK_LAUNCH("rowwgrad8_kernel");
+    return 0;
 }

@@ -300,6 +300,7 @@ extern "C" int msau_wgrad_geometry(int dtype, const msau_wgrad_desc* d, msau_wgr
     out->max_slabs = d->B * cdiv(d->Hout, 16) * cdiv(d->Wout, 16);
     out->slab_bytes = (int64_t)g.nchunks * d->Cout * g.kextc * 4;
     out->lean = msau_wgrad_lean_applicable(dtype, d, g.cch);
+    if (d->nslabs >= 1 && msau_rowwgrad_takes(dtype, d, g.cch, g.nchunks, g.kextc)) out->lean = 2;     // row-streaming instance
     out->reserved = 0;
     return 0;
 }
@@ -312,6 +313,8 @@ extern "C" int msau_conv2d_wgrad(void* stream, int dtype, const msau_wgrad_desc*
     if (rc) return rc;
     const int tiles_x = cdiv(d->Wout, 16), tiles_y = cdiv(d->Hout, 16), ntiles = d->B * tiles_x * tiles_y;
     MSAU_CHECK_ARG(d->nslabs >= 1 && d->nslabs <= ntiles, "wgrad: nslabs %d not in [1,%d]", d->nslabs, ntiles);
+    if (msau_rowwgrad_takes(dtype, d, g.cch, g.nchunks, g.kextc))              // conv_rows.hip: every row of x and g read once
+        return msau_rowwgrad_launch(static_cast<hipStream_t>(stream), d);
     if (d->Cout <= g.slice) {
         rc = msau_wgrad_lean_try(static_cast<hipStream_t>(stream), dtype, d, g.cch, g.nchunks, g.kextc);
         if (rc != 0) return rc < 0 ? rc : 0;
@@ -343,6 +346,7 @@ extern "C" int msau_conv2d_wgrad_groupable(int dtype, const msau_wgrad_desc* a, 
     if (!a || !b) return 0;
     WGeom g;
     if (wgrad_geom(dtype, a, &g)) return 0;
+    if (msau_rowwgrad_takes(dtype, a, g.cch, g.nchunks, g.kextc)) return 0;        // the row kernel runs one layer per launch
     if (a->Cout > g.slice || !msau_wgrad_lean_groupable(dtype, a, g.cch)) return 0;
     return a->B == b->B && a->Hin == b->Hin && a->Win == b->Win && a->Hout == b->Hout && a->Wout == b->Wout && a->C1 == b->C1 &&
            a->C2 == b->C2 && a->Cout == b->Cout && a->KH == b->KH && a->KW == b->KW && a->dil == b->dil && a->pad_t == b->pad_t &&

@@ -23,6 +23,9 @@ int msau_rowpair_launch(hipStream_t s, const msau_conv_pair_desc* d);
 // ... and of msau_conv2d for the single convolutions of the 8-channel level (dispatched from conv.hip)
 int msau_rowconv_takes(int dtype, const msau_conv_desc* d);
 int msau_rowconv_launch(hipStream_t s, int dtype, const msau_conv_desc* d, int kchunk, int rows);
+// ... and of msau_conv2d_wgrad for the 8 -> 8 3x3 weight gradients (dispatched from conv_wgrad.hip)
+int msau_rowwgrad_takes(int dtype, const msau_wgrad_desc* d, int cch, int nchunks, int kextc);
+int msau_rowwgrad_launch(hipStream_t s, const msau_wgrad_desc* d);
 
 #define MSAU_CHECK_ARG(cond, ...)                                   \
     do {                                                            \

@@ -411,7 +411,9 @@ class ConvOp(Op):
             ctn = 4 if ctn == 3 else (8 if ctn > 4 else ctn)
             nkw = -(-(wg.kext // 16) // 4)
             nkw = 1 if nkw <= 1 else 2 if nkw <= 2 else 3 if nkw <= 3 else 5 if nkw <= 5 else 10
-            if wg.lean:
+            if wg.lean == 2:
+                self.wkey = f"rowwgrad_kernel<{T},C{wg.cch},CO{w.Cout},K{w.KH}>"
+            elif wg.lean:
                 self.wkey = f"wgrad_lean_kernel<{T},C{wg.cch},CO{w.Cout},K{w.KH}>"
             else:
                 self.wkey = f"wgrad_kernel<{T},CT{ctn},NK{nkw}>"

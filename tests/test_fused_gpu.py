@@ -273,9 +273,11 @@ def _wdesc(x, g, slabs, cin, cout, k, nslabs):
 
 
 @pytest.mark.parametrize("cin,cout,k,hw", [(32, 32, 3, (42, 32)), (64, 64, 1, (21, 16)), (8, 8, 3, (64, 80))])
-def test_grouped_weight_gradients_write_the_same_slabs(cin, cout, k, hw):
+def test_grouped_weight_gradients_write_the_same_slabs(cin, cout, k, hw, monkeypatch):
     torch.manual_seed(14)
     lib = L.load()
+    monkeypatch.setenv("MSAU_WGRAD_ROWS", "0")           # grouping belongs to the tile kernels (the row kernel runs one layer per launch)
+    lib.msau_reload_env()
     s = torch.cuda.current_stream().cuda_stream
     B, (H, W), n = 4, hw, 3
     xs = [(torch.randn(B, H, W, cin, device="cuda") * 0.5).to(torch.bfloat16) for _ in range(n)]
@@ -295,6 +297,8 @@ def test_grouped_weight_gradients_write_the_same_slabs(cin, cout, k, hw):
     arr = (C.POINTER(L.WgradDesc) * n)(*[C.pointer(d) for d in d2])
     L.check(lib.msau_conv2d_wgrad_group(s, L.BF16, arr, n), "wgrad_group")
     torch.cuda.synchronize()
+    monkeypatch.undo()
+    lib.msau_reload_env()
     for a, b in zip(one, grp):
         assert not torch.isnan(a).any() and torch.equal(a, b)
     # a launch of another shape is refused, not mis-grouped
@@ -353,7 +357,10 @@ def test_chunked_first_conv_vs_autograd(dtype, cin, cout, hw, B):
 
 
 @pytest.mark.parametrize("cin,cout,k,hw", [(32, 32, 3, (42, 32)), (64, 64, 3, (21, 16)), (64, 64, 1, (21, 16)), (16, 32, 3, (84, 64)), (32, 64, 3, (33, 20)),
-                                           (8, 8, 3, (64, 80)), (16, 16, 3, (50, 37))])
+                                           (8, 8, 3, (64, 80)), (16, 16, 3, (50, 37)),
+                                           # the row-streaming instance (conv_rows.hip, bf16): strips ending inside / at the image edge,
+                                           # fewer rows than one segment, one column
+                                           (8, 8, 3, (57, 61)), (8, 8, 3, (90, 29)), (8, 8, 3, (17, 30)), (8, 8, 3, (200, 1))])
 @pytest.mark.parametrize("dtype", DT)
 def test_weight_gradient_slabs_vs_fp32_autograd_on_the_same_rounded_inputs(cin, cout, k, hw, dtype):
     """bf16 x bf16 products are exact in fp32, so the lean weight-gradient instances (pixel-split, two-wave-set, plain) must
@@ -375,6 +382,9 @@ def test_weight_gradient_slabs_vs_fp32_autograd_on_the_same_rounded_inputs(cin, 
     slab_elems = geom.slab_bytes // 4
     slabs = torch.full((nslabs * slab_elems,), float("nan"), device="cuda")
     d = _wdesc(x, g, slabs, cin, cout, k, nslabs)
+    if (cin, cout, k) == (8, 8, 3) and dtype == L.BF16 and B * -(-W // 30) * -(-H // 8) >= 16:
+        L.check(lib.msau_wgrad_geometry(dtype, C.byref(d), C.byref(geom)), "geometry")
+        assert geom.lean == 2                             # the row-streaming instance takes it
     L.check(lib.msau_conv2d_wgrad(s, dtype, C.byref(d)), "wgrad")
     torch.cuda.synchronize()
     tot = slabs.view(nslabs, cout, geom.kext).sum(0).cpu()
