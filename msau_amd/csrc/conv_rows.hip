@@ -832,8 +832,11 @@ __global__ __launch_bounds__(64 * WG_WAVES) void rowwgrad8_kernel(const RowWgrad
         auto stage_x = [&](u32x4 v) { if (lane < 34) *reinterpret_cast<u32x4*>(xbuf + lane * 16) = v; };
         auto stage_g = [&](u32x4 v) { if (lane < 30) *reinterpret_cast<u32x4*>(gbuf + (1 + lane) * 16) = v; };
         bf16x8 AX[3];
-        {   // fragments of x rows y0 - 1 and y0
+        u32x4 PX[3], PG[3];
+        {   // fragments of x rows y0 - 1 and y0; the first three rows of the loop are requested behind them, before the staging
             const u32x4 r0 = load_x(y0 - 1), r1 = load_x(y0);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { PX[k] = load_x(y0 + 1 + k); PG[k] = load_g(y0 + k); }
             stage_x(r0);
             __builtin_amdgcn_wave_barrier();
             AX[0] = frag_of(xbuf);
@@ -843,9 +846,6 @@ __global__ __launch_bounds__(64 * WG_WAVES) void rowwgrad8_kernel(const RowWgrad
             AX[1] = frag_of(xbuf);
             __builtin_amdgcn_wave_barrier();
         }
-        u32x4 PX[3], PG[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { PX[k] = load_x(y0 + 1 + k); PG[k] = load_g(y0 + k); }
         auto step = [&](auto ic, const int tg) {
             constexpr int I = decltype(ic)::value;
             const int y = tg + I;

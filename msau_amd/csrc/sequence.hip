@@ -153,6 +153,21 @@ extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_strea
     };
     hipStream_t cs = static_cast<hipStream_t>(comm_stream);
     bool any_comm = false;
+    // MSAU_SIDE_DEFER=1: hold side launches back while the main stream runs bandwidth-bound launches (the level-0 / level-1
+    // layers) and release them when it reaches the latency-bound ones (levels 2-3): two bandwidth-bound kernels side by side
+    // only slow each other down, a bandwidth-bound kernel beside a latency-bound chain is free.  `heavy` = pixels of the launch.
+    static const int defer = std::getenv("MSAU_SIDE_DEFER") ? atoi(std::getenv("MSAU_SIDE_DEFER")) : 0;
+    static const long long heavy_px = std::getenv("MSAU_SIDE_HEAVY_PX") ? atoll(std::getenv("MSAU_SIDE_HEAVY_PX")) : 200000;
+    auto pixels_of = [](const msau_op& o) -> long long {
+        switch (o.kind & 0xff) {
+            case MSAU_OP_CONV2D: { const msau_conv_desc* d = static_cast<const msau_conv_desc*>(o.args); return (long long)d->B * d->Hout * d->Wout; }
+            case MSAU_OP_CONV_PAIR: { const msau_conv_pair_desc* d = static_cast<const msau_conv_pair_desc*>(o.args); return (long long)d->B * d->H * d->W; }
+            case MSAU_OP_LRN_FWD: case MSAU_OP_LRN_BWD: return static_cast<const msau_lrn_args*>(o.args)->npix;
+            case MSAU_OP_POOL_FWD: case MSAU_OP_POOL_BWD: { const msau_pool_args* d = static_cast<const msau_pool_args*>(o.args); return (long long)d->B * d->H * d->W; }
+            default: return 0;
+        }
+    };
+    bool main_heavy = false;
     for (int i = 0; i < n; ++i) {
         msau_op o = ops[i];
         const bool side = o.kind & MSAU_OP_SIDE;
@@ -177,12 +192,14 @@ extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_strea
         }
         if (side) {
             pending.emplace_back(o, i);
-            if ((int)pending.size() >= fork_every || (o.kind & 0xff) == MSAU_OP_WGRAD_REDUCE) {
+            const bool hold = defer && main_heavy && (int)pending.size() < 96;
+            if (!hold && ((int)pending.size() >= fork_every || (o.kind & 0xff) == MSAU_OP_WGRAD_REDUCE)) {
                 int rc = flush();
                 if (rc) return rc;
             }
             continue;
         }
+        if (defer) main_heavy = pixels_of(o) >= heavy_px;
         if (join_first) {
             int rc = flush();
             if (rc) return rc;
