@@ -61,6 +61,14 @@ __device__ __forceinline__ float keep_if(float a, u64 mask) {
 __device__ __forceinline__ bf16x8 relu_bits(u32x4 v) { return relu8<bf16_t>(__builtin_bit_cast(bf16x8, v)); }
 template <int I> struct IC { static constexpr int value = I; };
 
+// MSAU_ROWS_SKEW=1 (compile time): run phase 2 one row behind phase 1 so that the two MFMA chains of an iteration are independent.
+// The compiler does interleave them (ISA), the kernel got SLOWER: forward 15.1 -> 17.9 us, backward 15.5 -> 17.0 us (80 / 101
+// registers instead of 76 / 88; three more iterations per task).  Off; kept as the measured alternative.
+#ifndef MSAU_ROWS_SKEW
+#define MSAU_ROWS_SKEW 0
+#endif
+constexpr int SKEW = MSAU_ROWS_SKEW;
+
 template <bool BWD, bool BITS>
 __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
     __shared__ __align__(16) unsigned char smem[4 * WAVE_LDS];
@@ -173,12 +181,13 @@ __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
     constexpr int kStoresPerRow = 2 + (!BWD && BITS ? 2 : 0);
 #pragma unroll
     for (int k = 0; k < 3 * kStoresPerRow; ++k) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rmid, kOOB + 8u * k, 0, 0);   // (distinct: equal ones are merged)
-    M[0] = M[2] = zero8<bf16_t>();
+    M[0] = M[1] = M[2] = zero8<bf16_t>();
+    u32x2 RR[2] = {{0u, 0u}, {0u, 0u}};                                   // SKEW: the residual operand of row t, fetched one iteration before its use
     u64 mm[2][4], ma[2][4];                                               // masks of iterations i (slot i & 1), two rows ahead
     if constexpr (BWD) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            cu64p pm = plane_row(pm0, y0 - 1 + k), pa = plane_row(pa0, y0 - 2 + k);
+            cu64p pm = plane_row(pm0, y0 - 1 + k), pa = plane_row(pa0, y0 - 2 - SKEW + k);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) { mm[k][jj] = pm[jj]; ma[k][jj] = pa[jj]; }
         }
@@ -191,6 +200,52 @@ __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
         X[(I + 5) % 6] = load_row(t + 5);
         first_use(X[(I + 2) % 6], RS[(I + 2) % 3]);
         const bool rowin = (unsigned)m < (unsigned)H;
+        // ================= phase 2: output row to = t - SKEW from intermediate rows to-1, to, to+1; columns x0 .. x0+29 ==========
+        // SKEW = 1: the row finished ONE iteration ago -- nothing here depends on this iteration's phase 1, so the compiler can run
+        // this epilogue in the shadow of phase 1's MFMAs and vice versa (un-skewed, 36-46 % of a wave's cycles were dependency stalls)
+        auto phase2 = [&]() {
+            const int to = t - SKEW;
+            f32x4 acc = bias2;
+            acc = mma8(A2[0], M[(I + 2 - SKEW + 3) % 3], acc);
+            acc = mma8(A2[1], M[(I + 3 - SKEW) % 3], acc);
+            acc = mma8(A2[2], M[(I + 1 - SKEW + 3) % 3], acc);
+#ifdef MSAU_ROWS_KEEPALIVE
+            asm volatile("" :: "v"(M[(I + 2) % 3]), "v"(M[I % 3]), "v"(M[(I + 1) % 3]));
+#endif
+            // residual (forward) / other-path gradient (backward): the raw input row t, from the neighbour lanes' registers
+            u32x2 rr;
+            if constexpr (SKEW) rr = RR[(I + 1) & 1];
+            else {
+                rr[0] = (unsigned)__builtin_amdgcn_ds_bpermute(res_src, (int)RS[I % 3][0]);
+                rr[1] = (unsigned)__builtin_amdgcn_ds_bpermute(res_src, (int)RS[I % 3][1]);
+            }
+            const bf16x4 r = __builtin_bit_cast(bf16x4, rr);
+            f32x4 v;
+            if constexpr (!BWD) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) v[jj] = fmaxf(acc[jj] + (float)r[jj], 0.f);   // ADD, RELU_OUT
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) v[jj] = keep_if(acc[jj], ma[P][jj]) + (float)r[jj];   // MASK_A, ADD
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) o[jj] = (bf16_t)v[jj];
+            const bool ownrow = to >= y0 && to < y1;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ry, ownrow ? (unsigned)(to * a.row_bytes) + out_col : kOOB, 0, 0);
+            if constexpr (!BWD && BITS) {
+                u64 bal[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) bal[jj] = __builtin_amdgcn_ballot_w64((float)r[jj] > 0.f);      // (x > 0): MASK_A of the backward
+                __builtin_amdgcn_raw_buffer_store_b32(lane_word(bal), rba, ownrow ? (unsigned)(to * plane_pitch) + bal_off : kOOB, 0, 0);
+            }
+        };
+        if constexpr (SKEW) {
+            phase2();
+            // the residual operand of row t for the next iteration
+            RR[I & 1][0] = (unsigned)__builtin_amdgcn_ds_bpermute(res_src, (int)RS[I % 3][0]);
+            RR[I & 1][1] = (unsigned)__builtin_amdgcn_ds_bpermute(res_src, (int)RS[I % 3][1]);
+        }
         // ================= phase 1: intermediate row m from input rows t, t+1, t+2; lattice columns 0..31 =================
         {
             f32x4 acc = bias1;
@@ -228,42 +283,9 @@ __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
         // overlap, so without this (it emits nothing) the read can be hoisted above the write -- it was, at 16 channels
         __builtin_amdgcn_wave_barrier();
         M[(I + 1) % 3] = *reinterpret_cast<const bf16x8*>(mrd + P * MP);    // the row just written, in fragment layout
-        // ================= phase 2: output row t from intermediate rows t-1, t, t+1; columns x0 .. x0+29 =================
-        {
-            f32x4 acc = bias2;
-            acc = mma8(A2[0], M[(I + 2) % 3], acc);
-            acc = mma8(A2[1], M[I % 3], acc);
-            acc = mma8(A2[2], M[(I + 1) % 3], acc);
-#ifdef MSAU_ROWS_KEEPALIVE
-            asm volatile("" :: "v"(M[(I + 2) % 3]), "v"(M[I % 3]), "v"(M[(I + 1) % 3]));
-#endif
-            // residual (forward) / other-path gradient (backward): the raw input row t, from the neighbour lanes' registers
-            u32x2 rr;
-            rr[0] = (unsigned)__builtin_amdgcn_ds_bpermute(res_src, (int)RS[I % 3][0]);
-            rr[1] = (unsigned)__builtin_amdgcn_ds_bpermute(res_src, (int)RS[I % 3][1]);
-            const bf16x4 r = __builtin_bit_cast(bf16x4, rr);
-            f32x4 v;
-            if constexpr (!BWD) {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) v[jj] = fmaxf(acc[jj] + (float)r[jj], 0.f);   // ADD, RELU_OUT
-            } else {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) v[jj] = keep_if(acc[jj], ma[P][jj]) + (float)r[jj];   // MASK_A, ADD
-            }
-            bf16x4 o;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) o[jj] = (bf16_t)v[jj];
-            const bool ownrow = t >= y0 && t < y1;
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ry, ownrow ? (unsigned)(t * a.row_bytes) + out_col : kOOB, 0, 0);
-            if constexpr (!BWD && BITS) {
-                u64 bal[4];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) bal[jj] = __builtin_amdgcn_ballot_w64((float)r[jj] > 0.f);      // (x > 0): MASK_A of the backward
-                __builtin_amdgcn_raw_buffer_store_b32(lane_word(bal), rba, ownrow ? (unsigned)(t * plane_pitch) + bal_off : kOOB, 0, 0);
-            }
-        }
+        if constexpr (!SKEW) phase2();
         if constexpr (BWD) {                                               // masks of iteration t + 2
-            cu64p pm = plane_row(pm0, m + 2), pa = plane_row(pa0, t + 2);
+            cu64p pm = plane_row(pm0, m + 2), pa = plane_row(pa0, t + 2 - SKEW);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) { mm[P][jj] = pm[jj]; ma[P][jj] = pa[jj]; }
         }
@@ -272,7 +294,7 @@ __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    for (int tg = y0 - 2; tg < y1; tg += UNR) {
+    for (int tg = y0 - 2; tg < y1 + SKEW; tg += UNR) {
         step(IC<0>{}, tg);
         step(IC<1>{}, tg);
         step(IC<2>{}, tg);
@@ -915,16 +937,15 @@ const RowsEnv& rows_env() {
     return g_env;
 }
 
-// segment height: a wave takes one task; aim for MSAU_ROWS_WAVES tasks in one round, at least 8 rows each.  Heights of the
-// form 6k - 2 make the row loop (6 rows per trip, two warm-up rows) come out even.
-int segment_rows(int B, int H, int nstrips) {
+// segment height: a wave takes one task; aim for MSAU_ROWS_WAVES tasks in one round, at least 8 rows each.
+int segment_rows(int B, int H, int nstrips, int warm) {
     const RowsEnv& e = rows_env();
     if (e.sh > 0) return e.sh < H ? e.sh : H;
     int nseg = e.waves / (B * nstrips);
     if (nseg < 1) nseg = 1;
     int sh = cdiv(H, nseg);
     if (sh < 10) sh = 10;
-    sh = cdiv(sh + 2, UNR) * UNR - 2;
+    sh = cdiv(sh + warm, UNR) * UNR - warm;              // `warm` iterations besides the rows: the trips of 6 come out even
     return sh < H ? sh : H;
 }
 
@@ -960,7 +981,7 @@ int msau_rowpair_launch(hipStream_t s, const msau_conv_pair_desc* d) {
     const bool c8 = d->C == 8;
     const bool bwd = d->flags1 == kBwd1, bits = d->bits_mid && d->bits_a, pool = !bwd && (d->flags2 & MSAU_CONV_POOL);
     a.nstrips = cdiv(d->W, c8 ? OW : OW16);
-    a.SH = segment_rows(d->B, d->H, a.nstrips);
+    a.SH = segment_rows(d->B, d->H, a.nstrips, c8 ? 2 + SKEW : 2);
     if (pool && (a.SH & 1) && a.SH < d->H) ++a.SH;                          // 2x2 windows do not straddle segments
     a.nseg = cdiv(d->H, a.SH);
     a.ntasks = d->B * a.nstrips * a.nseg;
