@@ -498,6 +498,9 @@ int msau_allreduce_bucket(void* stream, void* comm, float* buf, int64_t count);
 /* occupy the stream for ~microseconds (<= 200000) with a single sleeping wave: measurement aid only */
 int msau_spin(void* stream, int microseconds);
 int msau_fill_zero(void* stream, void* p, int64_t bytes);
+/* a non-blocking stream with queue priority -1 (device's highest), 0 (default) or +1 (device's lowest); the caller owns it */
+int msau_stream_create(int priority, void** stream_out);
+int msau_stream_destroy(void* stream);
 int msau_softmax_channels_nchw(void* stream, const float* logits, float* pred, int B, int C, int64_t hw);
 
 /* ------------------------------------------------------------------------------------------

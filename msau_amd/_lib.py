@@ -171,6 +171,8 @@ _SIGNATURES = {
     "msau_run_ops_overlap": (C.c_int, [vp, vp, C.POINTER(Op), C.c_int, C.c_int]),
     "msau_spin": (C.c_int, [vp, C.c_int]),
     "msau_fill_zero": (C.c_int, [vp, vp, i64]),
+    "msau_stream_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "msau_stream_destroy": (C.c_int, [vp]),
     "msau_softmax_channels_nchw": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, i64]),
     "msau_probe_read": (C.c_int, [vp, C.c_int, vp]),
     "msau_probe_overhead": (C.c_int, [vp, C.c_int, vp]),
@@ -279,8 +281,15 @@ def concurrent_stream(device=None, index: int = 0):
     probe = torch.zeros(1024, dtype=torch.float32, device=dev)
     torch.cuda.synchronize(dev)
     chosen, tried = None, []
+    prio = int(os.environ.get("MSAU_SIDE_PRIO", "0")) if index == 0 else 0
     for _ in range(8):
-        cand = torch.cuda.Stream(device=dev)
+        if prio:
+            # the weight-gradient stream at an explicit queue priority (+1 = lowest): torch only offers default / high
+            h = vp()
+            call("msau_stream_create", prio, C.byref(h))
+            cand = torch.cuda.ExternalStream(h.value, device=dev)
+        else:
+            cand = torch.cuda.Stream(device=dev)
         tried.append(cand)                                   # keep rejected candidates alive: their queue slots stay taken
         call("msau_spin", main.cuda_stream, 3000)
         call("msau_fill_zero", cand.cuda_stream, probe.data_ptr(), 4096)

@@ -349,6 +349,7 @@ extern "C" int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32
     if (g.nslices == 1 && !(d->flags & (MSAU_CONV_HEAD | MSAU_CONV_DOUT | MSAU_CONV_LRN | MSAU_CONV_POOL | MSAU_CONV_IDS)) &&
         msau_conv_chunked_capable(dtype, d, g.cch, g.nchunks, g.CT)) info[6] = 2;       // conv_chunked_kernel (conv_lean.hip)
     info[7] = msau_conv_lean_head_capable(dtype, d, g.nchunks, g.CT) | (msau_conv_lean_dout_capable(dtype, d, g.nchunks, g.CT) << 1) |
+              (((d->flags & MSAU_CONV_DOUT) && g.nslices == 1 && msau_rowconv_takes(dtype, d)) << 1) |
               (msau_conv_lean_lrn_capable(dtype, d, g.nchunks, g.CT) << 2) | (msau_conv_lean_pool_capable(dtype, d, g.nchunks, g.CT) << 3) |
               (msau_conv_lean_ids_capable(dtype, d, g.nchunks, g.CT) << 4);
     if (g.nslices == 1 && !(info[7] & 4)) {              // would a row-streaming instance take this launch with MSAU_CONV_LRN added?
@@ -398,7 +399,7 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
         const int okf = MSAU_CONV_DOUT | MSAU_CONV_ADD | MSAU_CONV_ACCUM | MSAU_CONV_MASK_B;
         MSAU_CHECK_ARG(d->y2 && !(d->flags & ~okf) && !(d->flags2 & ~(MSAU_CONV_ACCUM | MSAU_CONV_MASK_B)) &&
                        (!(d->flags2 & MSAU_CONV_MASK_B) || d->mask_b2), "conv2d: bad DOUT arguments");
-        if (!msau_conv_lean_dout_capable(dtype, d, g.nchunks, g.CT))
+        if (!msau_conv_lean_dout_capable(dtype, d, g.nchunks, g.CT) && !(g.nslices == 1 && msau_rowconv_takes(dtype, d)))
             return msau_set_error(MSAU_ERR_ARG, "conv2d: MSAU_CONV_DOUT is not implemented for this launch (see "
                                   "msau_conv2d_launch_info info[7]); issue one launch per output instead");
     }

@@ -508,7 +508,7 @@ constexpr int kBwd1 = MSAU_PAIR_MASK_MID, kBwd2 = MSAU_CONV_MASK_A | MSAU_CONV_A
 
 extern "C" int msau_conv_pair_applicable(int dtype, const msau_conv_pair_desc* d) {
     if (!d || (dtype != MSAU_F32 && dtype != MSAU_BF16)) return 0;
-    static const int maxc = std::getenv("MSAU_PAIR_MAXC") ? atoi(std::getenv("MSAU_PAIR_MAXC")) : 16;   // measured: C = 32 (84x64 images) gains nothing, 4.03 vs 4.00 ms/step
+    static const int maxc = std::getenv("MSAU_PAIR_MAXC") ? atoi(std::getenv("MSAU_PAIR_MAXC")) : 32;   // measured: C = 32 (84x64 images) gains nothing, 4.03 vs 4.00 ms/step
     // ... at batch 16; a launch of a few hundred pixels is launch-bound whatever it computes: there the 32-channel block fuses too
     const bool tiny = (int64_t)d->B * d->H * d->W <= 16384;
     if ((d->C != 8 && d->C != 16 && d->C != 32) || (d->C > maxc && !(tiny && d->C == 32))) return 0;

@@ -601,11 +601,17 @@ struct RowConvArgs {
     unsigned img_bytes;
 };
 
-template <int NS, int KH, int KW, int EPI>
+template <int NS, int KH, int KW, int EPI, int EPI2 = 0>
 __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
-    static_assert((KW == 3 && (NS == 1 || NS == 2)) || (KW == 1 && NS == 2 && KH == 1) || (KW == 4 && NS == 1), "instances: 3x3, 1x1 dual, 4x4");
+    constexpr bool DOUT = (EPI & MSAU_CONV_DOUT) != 0;                     // two outputs (stored weight rows 0..7 -> y, 8..15 -> y2)
+    constexpr bool K1D = KW == 1 && NS == 2;                               // 1x1 over concat(x1, x2)
+    static_assert((KW == 3 && (NS == 1 || NS == 2)) || (K1D && KH == 1) || (KW == 1 && NS == 1 && KH == 1 && DOUT) || (KW == 4 && NS == 1),
+                  "instances: 3x3, 1x1 dual, 1x1 two-output, 4x4");
+    static_assert(!DOUT || (!(EPI & ~(MSAU_CONV_DOUT | MSAU_CONV_ADD | MSAU_CONV_ACCUM | MSAU_CONV_MASK_B)) && !(EPI2 & ~(MSAU_CONV_ACCUM | MSAU_CONV_MASK_B)) &&
+                            NS == 1 && KW != 4), "two outputs: EPI = flags of y, EPI2 = flags2 of y2");
+    static_assert(DOUT || EPI2 == 0, "EPI2 belongs to the second output");
     constexpr int XL = KW == 4 ? 2 : 1;                                    // loads per lane, row and source
-    constexpr int NSL = KW == 1 ? 1 : NS;                                  // source "slots" per row (1x1: the lane picks its source)
+    constexpr int NSL = K1D ? 1 : NS;                                      // source "slots" per row (1x1 dual: the lane picks its source)
 #ifndef MSAU_ROWCONV_PF
 #define MSAU_ROWCONV_PF 3
 #endif
@@ -629,6 +635,7 @@ __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
 
     // ---- A fragments
     bf16x8 A[NSL][KH][XL];
+    bf16x8 A2[DOUT ? KH : 1];
     {
         const int co = lr & 7, pp = lr >> 3;
         const bf16_t* w = static_cast<const bf16_t*>(d.wpack) + co * a.wrow;
@@ -636,7 +643,7 @@ __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
         for (int s = 0; s < NSL; ++s)
 #pragma unroll
             for (int ky = 0; ky < KH; ++ky) {
-                if constexpr (KW == 1) {
+                if constexpr (K1D) {
                     const bool ok = (lg & 1) == pp;                        // this lane group's pixel is the row's pixel
                     A[s][ky][0] = ok ? load8<bf16_t>(w + (lg >> 1) * a.wchunk) : zero8<bf16_t>();
                 } else {
@@ -647,25 +654,29 @@ __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
                         const bool ok4 = lg == 0 && pp == 1;               // window column 4 = tap column 3 of the odd pixel
                         A[s][ky][1] = ok4 ? load8<bf16_t>(w + s * a.wchunk + (ky * KW + 3) * 8) : zero8<bf16_t>();
                     }
+                    if constexpr (DOUT) A2[ky] = ok ? load8<bf16_t>(w + 8 * a.wrow + (ky * KW + (ok ? kx : 0)) * 8) : zero8<bf16_t>();
                 }
             }
     }
-    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f}, bias2 = {0.f, 0.f, 0.f, 0.f};
     if (d.bias) bias = *reinterpret_cast<const f32x4*>(d.bias + c0);
+    if (DOUT && d.bias) bias2 = *reinterpret_cast<const f32x4*>(d.bias + 8 + c0);
+    constexpr bool ACC2 = (EPI2 & MSAU_CONV_ACCUM) != 0, MB2 = (EPI2 & MSAU_CONV_MASK_B) != 0;       // the second output's operands
 
     const long long img = (long long)b * a.img_bytes;
     const __amdgpu_buffer_rsrc_t rx1 = rsrc_of(static_cast<const char*>(d.x1) + img, a.img_bytes);
-    const __amdgpu_buffer_rsrc_t rx2 = rsrc_of(NS == 2 && KW != 1 ? static_cast<const char*>(d.x2) + img : nullptr, NS == 2 && KW != 1 ? a.img_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rx2 = rsrc_of(NS == 2 && !K1D ? static_cast<const char*>(d.x2) + img : nullptr, NS == 2 && !K1D ? a.img_bytes : 0u);
     const __amdgpu_buffer_rsrc_t ry = rsrc_of(static_cast<char*>(d.y) + img, a.img_bytes);
-    const __amdgpu_buffer_rsrc_t ry2 = rsrc_of(LRN ? static_cast<char*>(d.y2) + img : nullptr, LRN ? a.img_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t ry2 = rsrc_of(LRN || DOUT ? static_cast<char*>(d.y2) + img : nullptr, LRN || DOUT ? a.img_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rma = rsrc_of(HAS_MA ? static_cast<const char*>(d.mask_a) + img : nullptr, HAS_MA ? a.img_bytes : 0u);
     const __amdgpu_buffer_rsrc_t radd = rsrc_of(HAS_ADD ? static_cast<const char*>(d.add) + img : nullptr, HAS_ADD ? a.img_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rmb = rsrc_of(HAS_MB ? static_cast<const char*>(d.mask_b) + img : nullptr, HAS_MB ? a.img_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rmb2 = rsrc_of(MB2 ? static_cast<const char*>(d.mask_b2) + img : nullptr, MB2 ? a.img_bytes : 0u);
 
     // fragment loads of input row r
-    const int lxm = KW == 1 ? x0 + 2 * lr + (lg & 1) : x0 - d.pad_l + 2 * lr + lg;
+    const int lxm = K1D ? x0 + 2 * lr + (lg & 1) : x0 - d.pad_l + 2 * lr + lg;
     const int lxe = x0 - d.pad_l + 2 * lr + 4;
-    const unsigned lcol_m = (unsigned)lxm < (unsigned)W ? (unsigned)(lxm * 16) : kOOB;
+    const unsigned lcol_m = (unsigned)lxm < (unsigned)W && !(KW == 1 && !K1D && lg >= 2) ? (unsigned)(lxm * 16) : kOOB;   // (1x1 single source: groups 2,3 carry nothing)
     const unsigned lcol_e = (unsigned)lxe < (unsigned)W ? (unsigned)(lxe * 16) : kOOB;
     const int rlast = min(H - 1, y1 - 1 - d.pad_t + KH - 1);
     const bool b075 = d.lrn_beta == 0.75f;
@@ -673,12 +684,12 @@ __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
     // 1x1 over two sources: lanes of groups 0,1 read x1, of groups 2,3 x2 -- ONE load with a per-lane base address.  No halo,
     // so the only invalid lanes are pixels beyond the image width: they read (and never store) the pixel at the image edge.
     const char* src1x1 = nullptr;
-    if constexpr (KW == 1) src1x1 = static_cast<const char*>(lg < 2 ? d.x1 : d.x2) + img + (lxm < W ? lxm : W - 1) * 16;
+    if constexpr (K1D) src1x1 = static_cast<const char*>(lg < 2 ? d.x1 : d.x2) + img + (lxm < W ? lxm : W - 1) * 16;
     auto load_row = [&](int r, auto slot) {
         constexpr int S = decltype(slot)::value;
         const bool ok = r >= 0 && r <= rlast;
         const unsigned ro = (unsigned)(r * a.row_bytes);
-        if constexpr (KW == 1) {
+        if constexpr (K1D) {
             X[0][S][0] = *reinterpret_cast<const u32x4*>(src1x1 + (long long)(ok ? r : y0) * a.row_bytes);
         } else {
             X[0][S][0] = __builtin_amdgcn_raw_buffer_load_b128(rx1, ok ? ro + lcol_m : kOOB, 0, 0);
@@ -689,10 +700,12 @@ __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
     // epilogue operands of output row t (result layout), two rows ahead
     const bool out_ok = x0 + j < W;
     const unsigned out_col = out_ok ? (unsigned)((x0 + j) * 16 + c0 * 2) : kOOB;
-    u32x2 OPA[2], OPD[2], OPB[2], OPY[2];
+    u32x2 OPA[2], OPD[2], OPB[2], OPY[2], OPB2[2], OPY2[2];
     auto load_ops = [&](int t, auto slot) {
         constexpr int P = decltype(slot)::value;
         const unsigned o = (t >= y0 && t < y1) ? (unsigned)(t * a.row_bytes) + out_col : kOOB;
+        if constexpr (ACC2) OPY2[P] = __builtin_amdgcn_raw_buffer_load_b64(ry2, o, 0, 0);
+        if constexpr (MB2) OPB2[P] = __builtin_amdgcn_raw_buffer_load_b64(rmb2, o, 0, 0);
         if constexpr (HAS_MA) OPA[P] = __builtin_amdgcn_raw_buffer_load_b64(rma, o, 0, 0);
         if constexpr (HAS_ADD) OPD[P] = __builtin_amdgcn_raw_buffer_load_b64(radd, o, 0, 0);
         if constexpr (HAS_ACC) OPY[P] = __builtin_amdgcn_raw_buffer_load_b64(ry, o, 0, 0);
@@ -718,6 +731,30 @@ __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
             for (int s = 0; s < NSL; ++s)
 #pragma unroll
                 for (int e = 0; e < XL; ++e) acc = mma8(A[s][ky][e], __builtin_bit_cast(bf16x8, X[s][(I + ky) % NXR][e]), acc);
+        const unsigned oo = (t >= y0 && t < y1) ? (unsigned)(t * a.row_bytes) + out_col : kOOB;
+        if constexpr (DOUT) {
+            f32x4 acc_b = bias2;
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky) acc_b = mma8(A2[ky], __builtin_bit_cast(bf16x8, X[0][(I + ky) % NXR][0]), acc_b);
+            bf16x4 o1, o2;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                float v1 = acc[jj];                                        // same order as the tile kernel: ADD, ACCUM, MASK_B
+                if constexpr (HAS_ADD) v1 += (float)__builtin_bit_cast(bf16x4, OPD[P])[jj];
+                if constexpr (HAS_ACC) v1 += (float)__builtin_bit_cast(bf16x4, OPY[P])[jj];
+                if constexpr (HAS_MB) v1 = (float)__builtin_bit_cast(bf16x4, OPB[P])[jj] > 0.f ? v1 : 0.f;
+                float v2 = acc_b[jj];
+                if constexpr (ACC2) v2 += (float)__builtin_bit_cast(bf16x4, OPY2[P])[jj];
+                if constexpr (MB2) v2 = (float)__builtin_bit_cast(bf16x4, OPB2[P])[jj] > 0.f ? v2 : 0.f;
+                o1[jj] = (bf16_t)v1;
+                o2[jj] = (bf16_t)v2;
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o1), ry, oo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o2), ry2, oo, 0, 0);
+            load_ops(t + 2, IC<P>{});
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
         f32x4 v = acc;
         if constexpr (HAS_MA) {
             const bf16x4 mk = __builtin_bit_cast(bf16x4, OPA[P]);
@@ -746,7 +783,6 @@ __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
         bf16x4 o;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) o[jj] = (bf16_t)v[jj];
-        const unsigned oo = (t >= y0 && t < y1) ? (unsigned)(t * a.row_bytes) + out_col : kOOB;
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ry, oo, 0, 0);
         if constexpr (LRN) {
             // y2 = y * (k + alpha/n * sum over [c - 4, c + 3] of y^2)^-beta from the rounded y (layers.py:145,161-162); lane l holds
@@ -919,7 +955,7 @@ constexpr int kFwd1 = MSAU_PAIR_RELU_IN | MSAU_PAIR_RELU_MID, kFwd2 = MSAU_CONV_
 constexpr int kBwd1 = MSAU_PAIR_MASK_MID, kBwd2 = MSAU_CONV_MASK_A | MSAU_CONV_ADD;
 
 // environment switches of this file, read once; msau_reload_env() makes the next call read them again (tests, A/B tools)
-struct RowsEnv { int on, sh, waves, min_tasks, maxc, conv, wgrad; };
+struct RowsEnv { int on, sh, waves, min_tasks, maxc, conv, wgrad, dout; };
 RowsEnv g_env;
 bool g_env_ok = false;
 const RowsEnv& rows_env() {
@@ -931,6 +967,7 @@ const RowsEnv& rows_env() {
         g_env.min_tasks = geti("MSAU_ROWS_MIN_TASKS", 16);       // below: the tile kernels (a wave per task needs a few tasks per XCD at least)
         g_env.wgrad = geti("MSAU_WGRAD_ROWS", 1);                // the 8 -> 8 3x3 weight gradients on the row kernel
         g_env.conv = geti("MSAU_CONV_ROWS", 1);                  // single convolutions of the 8-channel level on the row kernels
+        g_env.dout = geti("MSAU_DOUT_ROWS", 1);                  // the two-output data gradients (8 -> 8 + 8, 3x3 and 1x1) on the row kernels
         g_env.maxc = geti("MSAU_ROWS_MAXC", 16);                 // widest layer the row kernels take (8: the 16-channel pairs stay on the tile kernels)
         g_env_ok = true;
     }
@@ -1007,9 +1044,9 @@ int msau_rowpair_launch(hipStream_t s, const msau_conv_pair_desc* d) {
 
 // ---- single convolutions (msau_conv2d descriptors)
 namespace {
-template <int NS, int KH, int KW, int EPI>
+template <int NS, int KH, int KW, int EPI, int EPI2 = 0>
 int launch_rowconv8(hipStream_t s, const RowConvArgs& a) {
-    hipLaunchKernelGGL((rowconv8_kernel<NS, KH, KW, EPI>), dim3(8 * (a.tasks_per_xcd / 4)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((rowconv8_kernel<NS, KH, KW, EPI, EPI2>), dim3(8 * (a.tasks_per_xcd / 4)), dim3(256), 0, s, a);
     MSAU_CHECK_LAUNCH("rowconv8_kernel");
     return 0;
 }
@@ -1017,11 +1054,20 @@ int launch_rowconv8(hipStream_t s, const RowConvArgs& a) {
 int rowconv_case(int dtype, const msau_conv_desc* d) {
     const RowsEnv& e = rows_env();
     if (!e.on || !e.conv || dtype != MSAU_BF16) return 0;
-    if (d->Cout != 8 || d->C1 != 8 || (d->C2 != 0 && d->C2 != 8) || d->stride != 1 || d->ups != 1 || d->dil != 1) return 0;
+    const bool dout = d->flags & MSAU_CONV_DOUT;
+    if (d->Cout != (dout ? 16 : 8) || d->C1 != 8 || (d->C2 != 0 && d->C2 != 8) || d->stride != 1 || d->ups != 1 || d->dil != 1) return 0;
     if (d->Hin != d->Hout || d->Win != d->Wout || d->KH != d->KW) return 0;
     if ((int64_t)d->Hout * d->Wout * 16 >= (1ll << 31)) return 0;
     if ((int64_t)d->B * cdiv(d->Wout, 32) * cdiv(d->Hout, 8) < e.min_tasks) return 0;
     const int f = d->flags, k = d->KH, dual = d->C2 != 0;
+    if (dout) {                                                            // the data gradient of a conv over concat(x1, x2): g -> (dx1, dx2)
+        if (!e.dout || dual || !d->y2) return 0;
+        // the flag sets the reference's nets produce (anything else: the tile kernel's run-time epilogue)
+        const int f1 = f & ~MSAU_CONV_DOUT, f2 = d->flags2;
+        if (k == 3 && d->pad_t == 1 && d->pad_l == 1 && f2 == 0) return f1 == 0 ? 9 : f1 == MSAU_CONV_ACCUM ? 10 : 0;
+        if (k == 1 && d->pad_t == 0 && d->pad_l == 0 && f1 == 0 && f2 == MSAU_CONV_MASK_B && d->mask_b2) return 11;
+        return 0;
+    }
     if (k == 3 && !dual && d->pad_t == 1 && d->pad_l == 1) {
         if (f == MSAU_CONV_LRN) return d->y2 && d->lrn_k > 0.f ? 1 : 0;
         if (f == 0) return 2;
@@ -1071,6 +1117,9 @@ int msau_rowconv_launch(hipStream_t s, int dtype, const msau_conv_desc* d, int k
         case 6: return launch_rowconv8<1, 4, 4, 0>(s, a);
         case 7: return launch_rowconv8<1, 4, 4, MSAU_CONV_MASK_B>(s, a);
         case 8: return launch_rowconv8<1, 4, 4, MSAU_CONV_ACCUM | MSAU_CONV_MASK_B>(s, a);
+        case 9: return launch_rowconv8<1, 3, 3, MSAU_CONV_DOUT>(s, a);
+        case 10: return launch_rowconv8<1, 3, 3, MSAU_CONV_DOUT | MSAU_CONV_ACCUM>(s, a);
+        case 11: return launch_rowconv8<1, 1, 1, MSAU_CONV_DOUT, MSAU_CONV_MASK_B>(s, a);
     }
     return msau_set_error(MSAU_ERR_ARG, "rowconv: no instance");
 }

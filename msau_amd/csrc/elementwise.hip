@@ -990,6 +990,28 @@ extern "C" int msau_spin(void* stream, int microseconds) {
     return 0;
 }
 
+// A stream with an explicit queue priority: -1 = the device's highest, 0 = default, +1 = the device's lowest.  The
+// weight-gradient side stream is created with +1 so that, when both queues have workgroups ready, the dispatcher serves
+// the data-gradient chain (the critical path) first and the side launches fill what is left.
+extern "C" int msau_stream_create(int priority, void** stream_out) {
+    MSAU_CHECK_ARG(stream_out && priority >= -1 && priority <= 1, "stream_create: priority is -1, 0 or +1");
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "stream_create: %s", hipGetErrorString(e));
+    hipStream_t s = nullptr;
+    e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority < 0 ? greatest : priority > 0 ? least : 0);
+    if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "stream_create: %s", hipGetErrorString(e));
+    *stream_out = s;
+    return 0;
+}
+
+extern "C" int msau_stream_destroy(void* stream) {
+    MSAU_CHECK_ARG(stream, "stream_destroy: null");
+    hipError_t e = hipStreamDestroy(static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "stream_destroy: %s", hipGetErrorString(e));
+    return 0;
+}
+
 extern "C" int msau_fill_zero(void* stream, void* p, int64_t bytes) {
     MSAU_CHECK_ARG(p && bytes >= 0, "fill_zero: bad args");
     hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, static_cast<hipStream_t>(stream));

@@ -107,12 +107,34 @@ extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_strea
     static const int fork_every = std::getenv("MSAU_FORK_EVERY") ? atoi(std::getenv("MSAU_FORK_EVERY")) : 8;
     std::vector<std::pair<msau_op, int>> pending;
     bool any_side = false;
+    // A second side queue (MSAU_SIDE2, owned by the library): weight gradients are mutually independent and most of their
+    // grids (64..384 workgroups) do not fill 256 CUs, so two of them side by side finish sooner than one after the other.
+    // Launches of a released batch alternate between the two queues; whatever consumes them (slab reduction, comm fork,
+    // join, the end of this call) first orders the second queue into the first, so callers still see ONE side stream.
+    static const int side2_on = std::getenv("MSAU_SIDE2") ? atoi(std::getenv("MSAU_SIDE2")) : 0;
+    static thread_local hipStream_t side2 = nullptr;
+    if (side2_on && !side2 && hipStreamCreateWithFlags(&side2, hipStreamNonBlocking) != hipSuccess)
+        return msau_set_error(MSAU_ERR_HIP, "run_ops_overlap: second side stream");
+    hipStream_t s2 = side2_on ? side2 : nullptr;
+    bool s2_open = false;                                      // work on s2 that ss has not been ordered behind yet
+    unsigned turn = 0;
+    auto close_s2 = [&]() -> int {
+        if (!s2_open) return 0;
+        hipEvent_t ev;
+        int rc = next_event(&ev);
+        if (rc) return rc;
+        if (hipEventRecord(ev, s2) != hipSuccess || hipStreamWaitEvent(ss, ev, 0) != hipSuccess)
+            return msau_set_error(MSAU_ERR_HIP, "run_ops_overlap: side join failed");
+        s2_open = false;
+        return 0;
+    };
     auto flush = [&]() -> int {
         if (pending.empty()) return 0;
         hipEvent_t ev;
         int rc = next_event(&ev);
         if (rc) return rc;
-        if (hipEventRecord(ev, ms) != hipSuccess || hipStreamWaitEvent(ss, ev, 0) != hipSuccess)
+        if (hipEventRecord(ev, ms) != hipSuccess || hipStreamWaitEvent(ss, ev, 0) != hipSuccess ||
+            (s2 && hipStreamWaitEvent(s2, ev, 0) != hipSuccess))
             return msau_set_error(MSAU_ERR_HIP, "run_ops_overlap: fork failed");
         // weight gradients of one shape released together share a grid (msau_conv2d_wgrad_group)
         static const bool group_off = std::getenv("MSAU_WGRAD_GROUP") && std::getenv("MSAU_WGRAD_GROUP")[0] == '0';
@@ -130,13 +152,22 @@ extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_strea
                     ds[n++] = static_cast<const msau_wgrad_desc*>(p.args);
                     done[j] = 1;
                 }
+                void* q = side_stream;
+                if (s2 && (turn++ & 1)) { q = s2; s2_open = true; }
                 if (n > 1) {
-                    rc = msau_conv2d_wgrad_group(side_stream, o.dtype, ds, n);
+                    rc = msau_conv2d_wgrad_group(q, o.dtype, ds, n);
                     if (rc) return rc;
                     continue;
                 }
+                rc = run_one(q, o, pending[i].second);
+                if (rc) return rc;
+                continue;
             }
-            rc = run_one(side_stream, o, pending[i].second);
+            // the slab reduction consumes both queues: on the first, behind the second; channel sums alternate like the rest
+            void* q = side_stream;
+            if ((o.kind & 0xff) == MSAU_OP_WGRAD_REDUCE) { rc = close_s2(); if (rc) return rc; }
+            else if (s2 && (turn++ & 1)) { q = s2; s2_open = true; }
+            rc = run_one(q, o, pending[i].second);
             if (rc) return rc;
         }
         pending.clear();
@@ -145,7 +176,9 @@ extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_strea
     };
     auto join_side = [&]() -> int {
         hipEvent_t ev;
-        int rc = next_event(&ev);
+        int rc = close_s2();
+        if (rc) return rc;
+        rc = next_event(&ev);
         if (rc) return rc;
         if (hipEventRecord(ev, ss) != hipSuccess || hipStreamWaitEvent(ms, ev, 0) != hipSuccess)
             return msau_set_error(MSAU_ERR_HIP, "run_ops_overlap: join failed");
@@ -179,6 +212,8 @@ extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_strea
             // that completed it) and on the main stream, on a stream of its own; the sweep goes on
             if (!cs) return msau_set_error(MSAU_ERR_ARG, "run_ops_dp: op %d needs the comm stream", i);
             int rc = flush();
+            if (rc) return rc;
+            rc = close_s2();
             if (rc) return rc;
             hipEvent_t ev;
             rc = next_event(&ev);
@@ -216,6 +251,8 @@ extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_strea
     }
     {
         int rc = flush();
+        if (rc) return rc;
+        rc = close_s2();
         if (rc) return rc;
     }
     if (any_comm && join) {

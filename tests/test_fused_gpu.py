@@ -504,3 +504,72 @@ def test_row_streaming_single_convs_match_the_tile_kernels_and_torch(k, dual, fl
         assert err(out["1"][1], lrn, True) < 1e-2
         if "0" in out:
             assert err(out["1"][1], out["0"][1], True) < 5e-3
+
+
+@pytest.mark.parametrize("k,flags,flags2", [(3, 0, 0), (3, L.CONV_ACCUM, 0), (1, 0, L.CONV_MASK_B),
+                                            (3, L.CONV_ADD | L.CONV_ACCUM | L.CONV_MASK_B, L.CONV_ACCUM | L.CONV_MASK_B)])
+@pytest.mark.parametrize("hw,B", [((40, 64), 2), ((37, 45), 3), ((9, 130), 2), ((130, 140), 4)])
+def test_row_streaming_two_output_data_gradients_match_the_tile_kernels_and_torch(k, flags, flags2, hw, B):
+    """rowconv8_kernel<.., MSAU_CONV_DOUT, flags2>: the data gradient of an 8-channel conv over concat(x1, x2) -- g [8] -> (dx1 [8],
+    dx2 [8]) -- for the flag sets the reference's nets produce (3x3: plain / y accumulates; 1x1: y2 masked); the last case has
+    no row instance and must stay on the tile kernel.  Through msau_conv2d, against the tile kernel on the same packed weights
+    (where the image is large enough for it) and against torch on the rounded operands"""
+    rows_have = (k, flags, flags2) in ((3, 0, 0), (3, L.CONV_ACCUM, 0), (1, 0, L.CONV_MASK_B))
+    torch.manual_seed(7)
+    H, W = hw
+    lib = L.load()
+    s = torch.cuda.current_stream().cuda_stream
+    bf = lambda t: t.to(torch.bfloat16)
+    nhwc = lambda t: bf(t).permute(0, 2, 3, 1).contiguous().cuda()
+    g = torch.randn(B, 8, H, W)
+    w = 0.2 * torch.randn(16, 8, k, k)
+    add, y1old, y2old, mb1, mb2 = (torch.randn(B, 8, H, W) for _ in range(5))
+    d = L.ConvDesc()
+    d.B, d.Hin, d.Win, d.Hout, d.Wout = B, H, W, H, W
+    d.C1, d.C2, d.Cout, d.KH, d.KW, d.dil, d.stride, d.ups = 8, 0, 16, k, k, 1, 1, 1
+    d.pad_t = d.pad_l = k // 2
+    d.flags, d.flags2 = flags | L.CONV_DOUT, flags2
+    G, Wp, AD, MB1, MB2 = nhwc(g), _pack_image(w, 8, 0), nhwc(add), nhwc(mb1), nhwc(mb2)
+    d.x1, d.wpack, d.bias = G.data_ptr(), Wp.data_ptr(), None
+    d.add = AD.data_ptr() if flags & L.CONV_ADD else None
+    d.mask_b = MB1.data_ptr() if flags & L.CONV_MASK_B else None
+    d.mask_b2 = MB2.data_ptr() if flags2 & L.CONV_MASK_B else None
+    out = {}
+    try:
+        for mode in ("1", "0"):
+            os.environ["MSAU_DOUT_ROWS"] = mode
+            os.environ["MSAU_ROWS_MIN_TASKS"] = "1"
+            lib.msau_reload_env()
+            Y1, Y2 = nhwc(y1old), nhwc(y2old)
+            d.y, d.y2 = Y1.data_ptr(), Y2.data_ptr()
+            info = (L.i32 * 8)()
+            L.check(lib.msau_conv2d_launch_info(L.BF16, C.byref(d), info))
+            assert (info[6] == 3) == (mode == "1" and rows_have), (mode, list(info))
+            if not info[7] & 2:
+                continue                          # small image and no row instance: the caller issues one launch per output
+            L.check(lib.msau_conv2d(s, L.BF16, C.byref(d)))
+            torch.cuda.synchronize()
+            out[mode] = (Y1.float().cpu(), Y2.float().cpu())
+    finally:
+        os.environ.pop("MSAU_DOUT_ROWS", None)
+        os.environ.pop("MSAU_ROWS_MIN_TASKS", None)
+        lib.msau_reload_env()
+    F = torch.nn.functional
+    both = F.conv2d(bf(g).float(), bf(w).float(), None, padding=k // 2)
+    r1, r2 = both[:, :8], both[:, 8:]
+    if flags & L.CONV_ADD:
+        r1 = r1 + bf(add).float()
+    if flags & L.CONV_ACCUM:
+        r1 = r1 + bf(y1old).float()
+    if flags & L.CONV_MASK_B:
+        r1 = r1 * (bf(mb1).float() > 0)
+    if flags2 & L.CONV_ACCUM:
+        r2 = r2 + bf(y2old).float()
+    if flags2 & L.CONV_MASK_B:
+        r2 = r2 * (bf(mb2).float() > 0)
+    for mode in out:
+        assert err(out[mode][0], r1.permute(0, 2, 3, 1), True) < 1e-2, mode
+        assert err(out[mode][1], r2.permute(0, 2, 3, 1), True) < 1e-2, mode
+    assert rows_have <= ("1" in out)
+    if len(out) == 2:
+        assert err(out["1"][0], out["0"][0], True) < 5e-3 and err(out["1"][1], out["0"][1], True) < 5e-3

@@ -332,8 +332,12 @@ def test_unet_loss_and_trainer_api(tmp_path):
 
 
 def test_two_output_data_gradient_is_bit_identical_to_two_launches(monkeypatch):
-    """concat convs (decoder merge, stage coupling): one MSAU_CONV_DOUT launch for both sources == one launch each"""
+    """concat convs (decoder merge, stage coupling): one MSAU_CONV_DOUT launch for both sources == one launch each (within
+    the tile kernels: the row-streaming two-output instances group the taps differently -- tests/test_fused_gpu.py covers them)"""
     from msau_amd.plan import ConvOp
+    from msau_amd import _lib as L
+    monkeypatch.setenv("MSAU_DOUT_ROWS", "0")
+    L.load().msau_reload_env()
     g, cfg, sd, x, label = load_net_case("net_cfg2_336x256x64")
     outs = []
     for fuse in ("1", "0"):
@@ -346,6 +350,8 @@ def test_two_output_data_gradient_is_bit_identical_to_two_launches(monkeypatch):
         nf = sum(1 for op in plan.ops if isinstance(op, ConvOp) and op.dd_off is not None)
         assert (nf > 10) if fuse == "1" else (nf == 0)
         outs.append((eng.flat_grad.clone(), m.flat_parameters.clone()))
+    monkeypatch.delenv("MSAU_DOUT_ROWS")
+    L.load().msau_reload_env()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
