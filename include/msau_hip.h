@@ -159,6 +159,12 @@ int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info8);
  * data-gradient image).  msau_conv_pair_applicable: 1 if an instance exists for the shape (C, enough tiles, LDS).
  * ------------------------------------------------------------------------------------------ */
 enum { MSAU_PAIR_RELU_IN = 1, MSAU_PAIR_RELU_MID = 2, MSAU_PAIR_MASK_MID = 4,
+       MSAU_PAIR_LRN_BWD = 16,  /* backward flag set only: x0 (whose gradient this launch produces) is the output of
+                                   LocalResponseNorm(size = C) applied to lrn_a (layers.py:145,161-162), and nothing else
+                                   contributes to its gradient: the launch runs the LRN backward on the storage-rounded result in
+                                   its epilogue and writes lrn_da (gradient w.r.t. lrn_a) INSTEAD of y -- the msau_lrn_bwd launch,
+                                   its read of dy and the write of dy disappear.  Row-streaming 8-channel instance only
+                                   (msau_conv_pair_applicable says so); lrn_alpha_over_n / lrn_beta / lrn_k as in msau_conv_desc */
        MSAU_PAIR_TILES = 8 };   /* take the tile kernels (conv_pair.hip) even where the row-streaming kernel has an instance: the
                                    forward and the backward launch of one block must agree on the layout of the mask planes, so a
                                    caller whose forward carries a flag only the tile kernels implement (MSAU_CONV_POOL) sets this on
@@ -182,6 +188,10 @@ typedef struct {
     uint8_t* bits_mid;          /* both NULL, or ReLU masks as bit planes [B][H][W][C/8] (bit c%8 of byte c/8 = element > 0): */
     uint8_t* bits_a;            /* the forward flag set WRITES (mid > 0) and (x > 0); the backward flag set READS them     */
                                 /* instead of the tensors mask_mid / mask_a (which may then be NULL)                       */
+    const void* lrn_a;          /* MSAU_PAIR_LRN_BWD: the LRN's input [B][H][W][C] ...                                     */
+    void* lrn_da;               /* ... and the gradient w.r.t. it (written; y is not)                                      */
+    float lrn_alpha_over_n, lrn_beta, lrn_k;
+    int32_t reserved0;
 } msau_conv_pair_desc;
 int msau_conv_pair_applicable(int dtype, const msau_conv_pair_desc* d);
 int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc* d);

@@ -29,10 +29,12 @@ class ConvDesc(C.Structure):
 
 class ConvPairDesc(C.Structure):
     _fields_ = [(n, i32) for n in ("B", "H", "W", "C", "flags1", "flags2")] + \
-               [(n, vp) for n in ("x", "w1", "b1", "mask_mid", "mid", "w2", "b2", "add", "mask_a", "mask_b", "y", "pool_y", "pool_idx", "bits_mid", "bits_a")]
+               [(n, vp) for n in ("x", "w1", "b1", "mask_mid", "mid", "w2", "b2", "add", "mask_a", "mask_b", "y", "pool_y", "pool_idx", "bits_mid", "bits_a",
+                                  "lrn_a", "lrn_da")] + \
+               [("lrn_alpha_over_n", f32), ("lrn_beta", f32), ("lrn_k", f32), ("reserved0", i32)]
 
 
-PAIR_RELU_IN, PAIR_RELU_MID, PAIR_MASK_MID, PAIR_TILES = 1, 2, 4, 8
+PAIR_RELU_IN, PAIR_RELU_MID, PAIR_MASK_MID, PAIR_TILES, PAIR_LRN_BWD = 1, 2, 4, 8, 16
 
 
 class BoxArgs(C.Structure):

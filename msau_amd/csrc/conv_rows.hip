@@ -69,8 +69,13 @@ template <int I> struct IC { static constexpr int value = I; };
 #endif
 constexpr int SKEW = MSAU_ROWS_SKEW;
 
-template <bool BWD, bool BITS>
+// LRNB (MSAU_PAIR_LRN_BWD, backward flag set): the block's input is the output of LocalResponseNorm(size = 8) (layers.py:145,
+// 161-162), whose backward used to be the next launch: read dy, read a, write da.  Here the finished row of dy is still in
+// the result layout -- the 8 channels of a pixel in lanes l and l ^ 16 -- so the epilogue loads a (8 bytes per lane, two rows
+// ahead), runs the same arithmetic as lrn_fast_kernel<G = 2> on the storage-rounded dy and stores da; y is not written.
+template <bool BWD, bool BITS, bool LRNB = false>
 __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
+    static_assert(!LRNB || (BWD && !SKEW), "the LRN backward rides on the data-gradient launch");
     __shared__ __align__(16) unsigned char smem[4 * WAVE_LDS];
     const msau_conv_pair_desc& d = a.d;
     const int lane = threadIdx.x & 63;
@@ -117,6 +122,9 @@ __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
     const __amdgpu_buffer_rsrc_t ry = rsrc_of(static_cast<char*>(d.y) + img, a.img_bytes);
     const __amdgpu_buffer_rsrc_t rbm = rsrc_of(BITS ? d.bits_mid + (long long)b * a.plane_img : nullptr, BITS ? a.plane_img : 0u);
     const __amdgpu_buffer_rsrc_t rba = rsrc_of(BITS ? d.bits_a + (long long)b * a.plane_img : nullptr, BITS ? a.plane_img : 0u);
+    const __amdgpu_buffer_rsrc_t rla = rsrc_of(LRNB ? static_cast<const char*>(d.lrn_a) + img : nullptr, LRNB ? a.img_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rlda = rsrc_of(LRNB ? static_cast<char*>(d.lrn_da) + img : nullptr, LRNB ? a.img_bytes : 0u);
+    const bool b075 = d.lrn_beta == 0.75f;
 
     // input row r in fragment layout: this lane's pixel is x0 - 2 + q; outside the image the offset is out of range -> 0
     const int lx = x0 - 2 + q;
@@ -184,6 +192,7 @@ __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
     M[0] = M[1] = M[2] = zero8<bf16_t>();
     u32x2 RR[2] = {{0u, 0u}, {0u, 0u}};                                   // SKEW: the residual operand of row t, fetched one iteration before its use
     u64 mm[2][4], ma[2][4];                                               // masks of iterations i (slot i & 1), two rows ahead
+    u32x2 AL[3] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};                         // LRNB: a(t, x0 + j, c0..c0+3) of output row t in AL[t' % 3], two rows ahead
     if constexpr (BWD) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -198,6 +207,10 @@ __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
         constexpr int I = decltype(ic)::value, P = I & 1;
         const int t = tg + I, m = t + 1;                                  // output row, intermediate row of this iteration
         X[(I + 5) % 6] = load_row(t + 5);
+        if constexpr (LRNB) {
+            const int ta = t + 2;
+            AL[(I + 2) % 3] = __builtin_amdgcn_raw_buffer_load_b64(rla, (ta >= y0 && ta < y1) ? (unsigned)(ta * a.row_bytes) + out_col : kOOB, 0, 0);
+        }
         first_use(X[(I + 2) % 6], RS[(I + 2) % 3]);
         const bool rowin = (unsigned)m < (unsigned)H;
         // ================= phase 2: output row to = t - SKEW from intermediate rows to-1, to, to+1; columns x0 .. x0+29 ==========
@@ -232,6 +245,42 @@ __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) o[jj] = (bf16_t)v[jj];
             const bool ownrow = to >= y0 && to < y1;
+            if constexpr (LRNB) {
+                // da = dy d^-beta - 2 beta alpha/n a * sum over the adjoint window [c - 3, c + 4] of dy a d^(-beta-1), d = k + alpha/n *
+                // sum over [c - 4, c + 3] of a^2; window sums = differences of prefix sums, the other half from lane ^ 16
+                const bf16x4 av = __builtin_bit_cast(bf16x4, AL[I % 3]);
+                const int h = lg & 1;
+                auto swz = [](float f) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, f), 0x401F)); };
+                float xa[4], gg[4], Pf[4], run = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) { xa[jj] = (float)av[jj]; gg[jj] = (float)o[jj]; run += xa[jj] * xa[jj]; Pf[jj] = run; }
+                const float other = swz(run);
+                const float E = h ? other : 0.f, tot = run + other;
+                float dnb[4], Q[4], runq = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float Xe = E + (jj ? Pf[jj - 1] : 0.f);        // exclusive prefix at channel 4h + jj
+                    const float Xo = swz(Xe);
+                    const float win = h ? tot - Xo : Xo;
+                    const float dd = d.lrn_k + d.lrn_alpha_over_n * win;
+                    float invd;
+                    if (b075) { const float r = __builtin_amdgcn_rsqf(dd); dnb[jj] = r * __builtin_amdgcn_sqrtf(r); invd = r * r; }
+                    else { dnb[jj] = __expf(-d.lrn_beta * __logf(dd)); invd = __builtin_amdgcn_rcpf(dd); }
+                    runq += gg[jj] * xa[jj] * dnb[jj] * invd;
+                    Q[jj] = runq;
+                }
+                const float otherq = swz(runq);
+                const float Eq = h ? otherq : 0.f, totq = runq + otherq;
+                const float c2 = 2.f * d.lrn_beta * d.lrn_alpha_over_n;
+                bf16x4 da;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float Io = swz(Eq + Q[jj]);                     // the other half's inclusive prefix at the same jj
+                    const float adj = h ? totq - Io : Io;
+                    da[jj] = (bf16_t)(gg[jj] * dnb[jj] - c2 * xa[jj] * adj);
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, da), rlda, ownrow ? (unsigned)(to * a.row_bytes) + out_col : kOOB, 0, 0);
+            } else
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ry, ownrow ? (unsigned)(to * a.row_bytes) + out_col : kOOB, 0, 0);
             if constexpr (!BWD && BITS) {
                 u64 bal[4];
@@ -994,8 +1043,10 @@ int msau_rowpair_takes(int dtype, const msau_conv_pair_desc* d) {
     const RowsEnv& e = rows_env();
     if (!e.on || dtype != MSAU_BF16 || (d->C != 8 && d->C != 16) || d->C > e.maxc || (d->flags1 & MSAU_PAIR_TILES)) return 0;
     const int pool_ok = d->C == 16 ? MSAU_CONV_POOL : 0;
-    const bool fwd = d->flags1 == kFwd1 && (d->flags2 & ~pool_ok) == kFwd2, bwd = d->flags1 == kBwd1 && d->flags2 == kBwd2;
+    const bool lrnb = d->flags1 & MSAU_PAIR_LRN_BWD;
+    const bool fwd = d->flags1 == kFwd1 && (d->flags2 & ~pool_ok) == kFwd2, bwd = (d->flags1 & ~MSAU_PAIR_LRN_BWD) == kBwd1 && d->flags2 == kBwd2;
     if (!fwd && !bwd) return 0;
+    if (lrnb && !(bwd && d->C == 8 && d->lrn_a && d->lrn_da && d->lrn_k > 0.f)) return 0;
     if (fwd && (d->flags2 & MSAU_CONV_POOL) && !d->pool_y) return 0;
     if (bwd && !(d->bits_mid && d->bits_a)) return 0;
     if (d->add != d->x) return 0;
@@ -1016,7 +1067,7 @@ int msau_rowpair_launch(hipStream_t s, const msau_conv_pair_desc* d) {
     RowArgs a;
     a.d = *d;
     const bool c8 = d->C == 8;
-    const bool bwd = d->flags1 == kBwd1, bits = d->bits_mid && d->bits_a, pool = !bwd && (d->flags2 & MSAU_CONV_POOL);
+    const bool bwd = (d->flags1 & ~MSAU_PAIR_LRN_BWD) == kBwd1, bits = d->bits_mid && d->bits_a, pool = !bwd && (d->flags2 & MSAU_CONV_POOL);
     a.nstrips = cdiv(d->W, c8 ? OW : OW16);
     a.SH = segment_rows(d->B, d->H, a.nstrips, c8 ? 2 + SKEW : 2);
     if (pool && (a.SH & 1) && a.SH < d->H) ++a.SH;                          // 2x2 windows do not straddle segments
@@ -1028,7 +1079,8 @@ int msau_rowpair_launch(hipStream_t s, const msau_conv_pair_desc* d) {
     a.plane_img = (unsigned)d->H * (unsigned)a.nstrips * 32u;
     const dim3 grid(8 * (a.tasks_per_xcd / 4)), block(256);
     if (c8) {
-        if (bwd) hipLaunchKernelGGL((rowpair_c8_kernel<true, true>), grid, block, 0, s, a);
+        if (bwd && (d->flags1 & MSAU_PAIR_LRN_BWD)) hipLaunchKernelGGL((rowpair_c8_kernel<true, true, true>), grid, block, 0, s, a);
+        else if (bwd) hipLaunchKernelGGL((rowpair_c8_kernel<true, true>), grid, block, 0, s, a);
         else if (bits) hipLaunchKernelGGL((rowpair_c8_kernel<false, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((rowpair_c8_kernel<false, false>), grid, block, 0, s, a);
     } else {

@@ -579,6 +579,20 @@ class PairOp:
                         dsc.bits_mid, dsc.bits_a = _ptr(self.bits_mid), _ptr(self.bits_a)
                     self.fbytes += 2 * nbits
                     self.bbytes = 3 * n * esz + 2 * nbits
+                # the block's input is an LRN output nothing else reads: its backward rides on this launch (conv_rows.hip)
+                lrn = getattr(x0, "lrn_producer", None)
+                if self.bdesc is not None and lrn is not None and x0.n_contrib == 1 and not (d1.flags & L.CONV_ACCUM) \
+                        and lrn.a.grad is not None and lrn.a.n_contrib == 1 and not lrn.a.relu_out and lrn.a.C == lrn.a.Cs == x0.Cs \
+                        and os.environ.get("MSAU_FUSE_LRN_BWD", "1") != "0":
+                    b.flags1 |= L.PAIR_LRN_BWD
+                    b.lrn_a, b.lrn_da = _ptr(lrn.a.data), _ptr(lrn.a.grad)
+                    b.lrn_alpha_over_n, b.lrn_beta, b.lrn_k = 1e-4 / lrn.a.C, 0.75, 1.0
+                    if L.load().msau_conv_pair_instance(P.dtype, C.byref(b)) == 2:
+                        lrn.bwd_fused_into = self
+                        self.bbytes += n * esz              # a read, da written instead of dx
+                    else:
+                        b.flags1 &= ~L.PAIR_LRN_BWD
+                        b.lrn_a = b.lrn_da = None
         # label by the instance that takes the launches (the backward descriptor, once it has its planes, decides for both)
         probe = self.bdesc if self.bdesc is not None else f
         if L.load().msau_conv_pair_instance(P.dtype, C.byref(probe)) == 2:
@@ -705,6 +719,8 @@ class LrnOp(Op):
         self.slot = a.register() if a.needs_grad else None
         self.stage = plan._cur_stage
         self.fused_into = None             # the ConvOp whose epilogue writes y (MSAU_CONV_LRN), when its instance can
+        self.bwd_fused_into = None         # the PairOp whose data-gradient launch also runs this backward (MSAU_PAIR_LRN_BWD)
+        y.lrn_producer = self
         prod = plan.ops[-1] if plan.ops else None
         if isinstance(prod, ConvOp) and prod.out is a and os.environ.get("MSAU_FUSE_LRN", "1") != "0":
             prod.lrn = self
@@ -726,7 +742,7 @@ class LrnOp(Op):
         self.fbytes, self.bbytes = 2 * n, 3 * n
         if self.fused_into is None:
             P.note_launch(self.fkey, self.fbytes, 0.0)
-        if P.training and self.y.grad is not None and a.grad is not None:
+        if P.training and self.y.grad is not None and a.grad is not None and self.bwd_fused_into is None:
             P.note_launch(self.bkey, self.bbytes, 0.0)
 
     def fwd_recs(self):
@@ -739,7 +755,7 @@ class LrnOp(Op):
 
     def bwd_recs(self):
         a, y = self.a, self.y
-        if y.grad is None or a.grad is None:
+        if y.grad is None or a.grad is None or self.bwd_fused_into is not None:
             return []
         self._ba = L.LrnArgs(_ptr(a.data), _ptr(y.grad), _ptr(a.grad), a.npix, a.C, a.Cs, a.C, 1e-4, 0.75, 1.0)
         self.plan.rec_meta[C.addressof(self._ba)] = (self.bkey, self.bbytes)
@@ -757,7 +773,7 @@ class LrnOp(Op):
 
     def bwd(self, s):
         a, y = self.a, self.y
-        if y.grad is None or a.grad is None:
+        if y.grad is None or a.grad is None or self.bwd_fused_into is not None:
             return
         assert a.n_contrib == 1 and not a.relu_out
         L.call("msau_lrn_bwd", s, self.plan.dtype, _ptr(a.data), _ptr(y.grad), _ptr(a.grad), a.npix, a.C, a.Cs, a.C,

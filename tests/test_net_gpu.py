@@ -438,3 +438,34 @@ def test_fused_residual_pair_is_bit_identical_to_two_launches(monkeypatch, dtype
     else:
         assert abs(l1 - l0) < 1e-3 * abs(l0) and err(q1.float().cpu(), q0.float().cpu(), True) < 5e-2
         assert err(g1.cpu(), g0.cpu(), True) < 3e-1 and float((p1 - p0).abs().max()) < 2.5e-4      # Adam's first step is lr * sign(g)
+
+
+@pytest.mark.parametrize("B,channels,H,W", [(4, 64, 112, 96), (3, 13, 75, 91)])
+def test_lrn_backward_in_the_pair_epilogue_matches_the_standalone_pass(monkeypatch, B, channels, H, W):
+    """MSAU_PAIR_LRN_BWD: the level-0 residual block's data-gradient launch (rowpair_c8_kernel, conv_rows.hip) also runs the
+    backward of the LocalResponseNorm in front of the block (layers.py:145,161-162) -- same arithmetic on the same rounded dy
+    as msau_lrn_bwd, prefix sums in another order -- so da, every parameter gradient and the updated parameters agree with
+    the two-launch path to bf16 rounding, and one launch per stage is gone."""
+    from oracle import msau_oracle as O
+    from msau_amd.plan import LrnOp
+    x, label = O.synthetic_batch(B, channels, H, W, 5, seed=11)
+    x, label = x.cuda(), label.cuda()
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("MSAU_FUSE_LRN_BWD", fuse)
+        kw = dict(scale_space_num=4, res_depth=2, featRoot=8, final_act="softmax", num_blocks=3, dtype="bf16", seed=3)
+        m = MSAUWrapper(channels, 5, kw).cuda()
+        eng = TrainEngine(m)
+        eng.step(x, label)
+        torch.cuda.synchronize()
+        plan = m._plan_for(x, True)
+        lrns = [op for op in plan.ops if isinstance(op, LrnOp)]
+        nf = sum(1 for op in lrns if op.bwd_fused_into is not None)
+        assert nf == (3 if fuse == "1" else 0), nf                      # one 8-channel level per stage
+        da = [op.a.grad.float().cpu() for op in lrns if op.a.Cs == 8]
+        outs.append((da, eng.flat_grad.float().cpu(), m.flat_parameters.float().cpu(), sum(n for n, _, _ in plan.launch_meta.values())))
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert float(b.abs().max()) > 0 and err(a, b, True) < 1e-2
+    assert err(outs[0][1], outs[1][1], True) < 2e-2
+    assert err(outs[0][2], outs[1][2], True) < 1e-3
+    assert outs[0][3] == outs[1][3] - 3
