@@ -165,6 +165,11 @@ enum { MSAU_PAIR_RELU_IN = 1, MSAU_PAIR_RELU_MID = 2, MSAU_PAIR_MASK_MID = 4,
                                    its epilogue and writes lrn_da (gradient w.r.t. lrn_a) INSTEAD of y -- the msau_lrn_bwd launch,
                                    its read of dy and the write of dy disappear.  Row-streaming 8-channel instance only
                                    (msau_conv_pair_applicable says so); lrn_alpha_over_n / lrn_beta / lrn_k as in msau_conv_desc */
+       MSAU_PAIR_WGRAD1 = 32,   /* backward flag set only: the weight gradient of the block's FIRST conv in the same launch -- its g
+                                   operand is the intermediate gradient this launch produces, so that tensor is neither written
+                                   (`mid` is left untouched) nor re-read; wg1_x = the block's forward input x0 (ReLU applied on load),
+                                   wg1_slabs = msau_conv_pair_wgrad_slabs() slabs of [8][80] fp32 in the layout msau_wgrad_reduce expects
+                                   (kext 80, ones column 72).  Row-streaming 8-channel instance only. */
        MSAU_PAIR_TILES = 8 };   /* take the tile kernels (conv_pair.hip) even where the row-streaming kernel has an instance: the
                                    forward and the backward launch of one block must agree on the layout of the mask planes, so a
                                    caller whose forward carries a flag only the tile kernels implement (MSAU_CONV_POOL) sets this on
@@ -192,6 +197,8 @@ typedef struct {
     void* lrn_da;               /* ... and the gradient w.r.t. it (written; y is not)                                      */
     float lrn_alpha_over_n, lrn_beta, lrn_k;
     int32_t reserved0;
+    const void* wg1_x;          /* MSAU_PAIR_WGRAD1: x0, [B][H][W][C]                                                     */
+    float* wg1_slabs;           /* [msau_conv_pair_wgrad_slabs()][C][80] partial sums, one slab per workgroup             */
 } msau_conv_pair_desc;
 int msau_conv_pair_applicable(int dtype, const msau_conv_pair_desc* d);
 int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc* d);
@@ -200,6 +207,8 @@ int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc* d);
  * (pixel, 8-channel group) for the tile kernels (conv_pair.hip), 32 bytes of lane ballots per (row, 30-column strip) for the
  * row-streaming 8-channel bf16 kernel (conv_rows.hip).  Allocate with this, never from the layout comment above. */
 int64_t msau_conv_pair_bits_bytes(int dtype, const msau_conv_pair_desc* d);
+/* number of slabs an MSAU_PAIR_WGRAD1 launch of this descriptor writes (= its workgroups); 0 if no instance takes the flag */
+int msau_conv_pair_wgrad_slabs(int dtype, const msau_conv_pair_desc* d);
 /* which instance takes the descriptor: 0 none, 1 a tile kernel (conv_pair.hip), 2 a row-streaming kernel (conv_rows.hip) */
 int msau_conv_pair_instance(int dtype, const msau_conv_pair_desc* d);
 /* The library reads its MSAU_* environment switches once.  msau_reload_env() makes the row-streaming kernel's switches

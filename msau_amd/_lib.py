@@ -31,10 +31,10 @@ class ConvPairDesc(C.Structure):
     _fields_ = [(n, i32) for n in ("B", "H", "W", "C", "flags1", "flags2")] + \
                [(n, vp) for n in ("x", "w1", "b1", "mask_mid", "mid", "w2", "b2", "add", "mask_a", "mask_b", "y", "pool_y", "pool_idx", "bits_mid", "bits_a",
                                   "lrn_a", "lrn_da")] + \
-               [("lrn_alpha_over_n", f32), ("lrn_beta", f32), ("lrn_k", f32), ("reserved0", i32)]
+               [("lrn_alpha_over_n", f32), ("lrn_beta", f32), ("lrn_k", f32), ("reserved0", i32), ("wg1_x", vp), ("wg1_slabs", vp)]
 
 
-PAIR_RELU_IN, PAIR_RELU_MID, PAIR_MASK_MID, PAIR_TILES, PAIR_LRN_BWD = 1, 2, 4, 8, 16
+PAIR_RELU_IN, PAIR_RELU_MID, PAIR_MASK_MID, PAIR_TILES, PAIR_LRN_BWD, PAIR_WGRAD1 = 1, 2, 4, 8, 16, 32
 
 
 class BoxArgs(C.Structure):
@@ -126,6 +126,7 @@ _SIGNATURES = {
     "msau_conv_pair": (C.c_int, [vp, C.c_int, C.POINTER(ConvPairDesc)]),
     "msau_conv_pair_bits_bytes": (C.c_int64, [C.c_int, C.POINTER(ConvPairDesc)]),
     "msau_conv_pair_instance": (C.c_int, [C.c_int, C.POINTER(ConvPairDesc)]),
+    "msau_conv_pair_wgrad_slabs": (C.c_int, [C.c_int, C.POINTER(ConvPairDesc)]),
     "msau_comm_available": (C.c_int, []),
     "msau_comm_unique_id": (C.c_int, [vp, C.c_int]),
     "msau_comm_init": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, vp, C.c_int]),

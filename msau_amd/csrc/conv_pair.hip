@@ -514,13 +514,13 @@ extern "C" int msau_conv_pair_applicable(int dtype, const msau_conv_pair_desc* d
     if ((d->C != 8 && d->C != 16 && d->C != 32) || (d->C > maxc && !(tiny && d->C == 32))) return 0;
     if (dtype == MSAU_F32 && d->C == 32) return 0;                 // two fp32 tiles + two weight sets exceed the LDS
     if (d->B <= 0 || d->H <= 0 || d->W <= 0) return 0;
-    const int f1 = d->flags1 & ~(MSAU_PAIR_TILES | MSAU_PAIR_LRN_BWD);
+    const int f1 = d->flags1 & ~(MSAU_PAIR_TILES | MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1);
     const bool fwd = f1 == kFwd1 && (d->flags2 & ~MSAU_CONV_POOL) == kFwd2, bwd = f1 == kBwd1 && d->flags2 == kBwd2;
     if (fwd && (d->flags2 & MSAU_CONV_POOL) && !d->pool_y) return 0;
     if (!fwd && !bwd) return 0;
     if (d->add != d->x) return 0;                                  // the ADD operand is read back from the input tile
     if (msau_rowpair_takes(dtype, d)) return 1;                    // 8 channels, bf16: the row-streaming kernel (conv_rows.hip)
-    if (d->flags1 & MSAU_PAIR_LRN_BWD) return 0;                   // the LRN backward epilogue exists in the row-streaming instance only
+    if (d->flags1 & (MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1)) return 0;  // riders of the row-streaming instance only
     const int esz = dtype == MSAU_F32 ? 4 : 2;
     if ((int64_t)d->H * d->W * d->C * esz >= (1ll << 31)) return 0;             // 32-bit lane offsets inside an image
     const int tw = pair_tw(dtype, d);
@@ -540,6 +540,11 @@ extern "C" int msau_conv_pair_instance(int dtype, const msau_conv_pair_desc* d) 
     return msau_rowpair_takes(dtype, d) ? 2 : 1;
 }
 
+extern "C" int msau_conv_pair_wgrad_slabs(int dtype, const msau_conv_pair_desc* d) {
+    if (!d || !(d->flags1 & MSAU_PAIR_WGRAD1) || !msau_conv_pair_applicable(dtype, d) || !msau_rowpair_takes(dtype, d)) return 0;
+    return msau_rowpair_workgroups(d);
+}
+
 // bytes of ONE ReLU-mask plane (bits_mid / bits_a) for this descriptor: the tile kernels keep a byte per (pixel, 8-channel
 // group), the row-streaming kernel 32 bytes of lane ballots per (row, 30-column strip)
 extern "C" int64_t msau_conv_pair_bits_bytes(int dtype, const msau_conv_pair_desc* d) {
@@ -555,7 +560,7 @@ extern "C" int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc
     MSAU_CHECK_ARG(d && d->x && d->w1 && d->w2 && d->mid && (d->y || (d->flags1 & MSAU_PAIR_LRN_BWD)), "conv_pair: null pointer");
     MSAU_CHECK_ARG(msau_conv_pair_applicable(dtype, d), "conv_pair: unsupported shape or flags (C %d, %dx%d, B %d, flags 0x%x / 0x%x; "
                    "MSAU_CONV_ADD must name the input tensor)", d->C, d->H, d->W, d->B, d->flags1, d->flags2);
-    const bool bwd = (d->flags1 & ~(MSAU_PAIR_TILES | MSAU_PAIR_LRN_BWD)) == kBwd1;
+    const bool bwd = (d->flags1 & ~(MSAU_PAIR_TILES | MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1)) == kBwd1;
     MSAU_CHECK_ARG(!bwd || (d->mask_mid && d->mask_a) || (d->bits_mid && d->bits_a), "conv_pair: backward without mask_mid / mask_a (tensors or bit planes)");
     MSAU_CHECK_ARG(!d->bits_mid == !d->bits_a, "conv_pair: bits_mid and bits_a come together");
     hipStream_t s = static_cast<hipStream_t>(stream);

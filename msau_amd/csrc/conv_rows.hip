@@ -40,6 +40,8 @@ constexpr int OW = 30, XW = 34;                   // output / input columns of a
 constexpr int MP = XW * 16;                       // an intermediate row in LDS: 34 pixels x 8 bf16
 constexpr int WAVE_LDS = 2 * MP;                  // two alternating slots per wave
 constexpr int UNR = 6;                            // rows per loop body: 3 rows in use + 3 in flight, all statically named
+typedef __attribute__((address_space(3))) bf16x4* lds_v4;
+constexpr int WG_ROW = 36 * 16;                   // a row staged for a weight gradient: 34 pixels used, 16-byte slots
 
 struct RowArgs {
     msau_conv_pair_desc d;
@@ -73,16 +75,30 @@ constexpr int SKEW = MSAU_ROWS_SKEW;
 // 161-162), whose backward used to be the next launch: read dy, read a, write da.  Here the finished row of dy is still in
 // the result layout -- the 8 channels of a pixel in lanes l and l ^ 16 -- so the epilogue loads a (8 bytes per lane, two rows
 // ahead), runs the same arithmetic as lrn_fast_kernel<G = 2> on the storage-rounded dy and stores da; y is not written.
-template <bool BWD, bool BITS, bool LRNB = false>
+//
+// WG1 (MSAU_PAIR_WGRAD1, backward flag set): the weight gradient of the block's FIRST conv in the same launch.  Its g operand
+// is the intermediate row this walk has just produced -- already in LDS as [pixel][8 channels], the layout rowwgrad8_kernel
+// stages by hand -- so the stand-alone launch's read of g (22 MB at the bench size) and this launch's write of it (nothing
+// else reads the gradient of the block's inner tensor) both disappear; what is added is one 16-byte load per lane and row
+// of the block's input x0 (the weight gradient's other operand), its transposed fragment, and four MFMAs:
+//     D[(a, ci)][(b, co)] += sum over 32 pixels  relu(x0)[ci](m + ky - 1, x + a) * g_mid[co](m, x + b)     (tap kx - 1 = a - b)
+// exactly as in rowwgrad8_kernel.  A wave owns the lattice columns 1..30 of its own rows m; the other lattice columns
+// (neighbour strips' pixels) are cleared in the fragment.  The four waves of a workgroup add up in LDS in a fixed order and
+// the workgroup writes ONE slab (layout of msau_wgrad_reduce: [co][tap * 8 + ci], ones column 72).
+template <bool BWD, bool BITS, bool LRNB = false, bool WG1 = false>
 __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
     static_assert(!LRNB || (BWD && !SKEW), "the LRN backward rides on the data-gradient launch");
-    __shared__ __align__(16) unsigned char smem[4 * WAVE_LDS];
+    static_assert(!WG1 || (BWD && !SKEW), "the weight gradient rides on the data-gradient launch");
+    __shared__ __align__(16) unsigned char smem[4 * WAVE_LDS + (WG1 ? 4 * WG_ROW + 8 * 80 * 4 : 0)];
     const msau_conv_pair_desc& d = a.d;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tloc = (blockIdx.x >> 3) * 4 + wave;
     const int task = (blockIdx.x & 7) * a.tasks_per_xcd + tloc;
-    if (tloc >= a.tasks_per_xcd || task >= a.ntasks) return;              // wave-uniform; there is no barrier below
+    const bool live = tloc < a.tasks_per_xcd && task < a.ntasks;          // wave-uniform
+    if constexpr (!WG1) { if (!live) return; }                            // (no barrier below; WG1: idle waves wait at the slab reduction)
+    f32x4 wacc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, waccb = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
     const int t1 = task / a.nstrips, strip = task - t1 * a.nstrips;
     const int b = t1 / a.nseg, seg = t1 - b * a.nseg;
     const int H = d.H, W = d.W;
@@ -125,6 +141,48 @@ __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
     const __amdgpu_buffer_rsrc_t rla = rsrc_of(LRNB ? static_cast<const char*>(d.lrn_a) + img : nullptr, LRNB ? a.img_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rlda = rsrc_of(LRNB ? static_cast<char*>(d.lrn_da) + img : nullptr, LRNB ? a.img_bytes : 0u);
     const bool b075 = d.lrn_beta == 0.75f;
+    // ---- WG1: x0 rows (columns x0 - 1 + lane, lanes 0..33) -> LDS -> transposed fragments; the g fragment comes from the M slots
+    const __amdgpu_buffer_rsrc_t rwx = rsrc_of(WG1 ? static_cast<const char*>(d.wg1_x) + img : nullptr, WG1 ? a.img_bytes : 0u);
+    unsigned char* wxbuf = smem + 4 * WAVE_LDS + wave * WG_ROW;
+    const int wtr_off = (8 * (lane >> 4) + ((lane & 15) >> 2)) * 16 + (lane & 3) * 8;
+    auto wfrag = [&](const unsigned char* buf) -> bf16x8 {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(buf + wtr_off));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(buf + wtr_off + 4 * 16));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    const int wcx = x0 - 1 + lane;
+    const unsigned wxcol = lane < 34 && (unsigned)wcx < (unsigned)W ? (unsigned)(wcx * 16) : kOOB;
+    auto load_wx = [&](int r) -> u32x4 {
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rwx, (unsigned)r < (unsigned)H && r <= y1 ? (unsigned)(r * a.row_bytes) + wxcol : kOOB, 0, 0);
+        return __builtin_bit_cast(u32x4, relu_bits(v));                   // MSAU_PAIR_RELU_IN of the forward: the first conv saw max(x0, 0)
+    };
+    auto stage_wx = [&](u32x4 v) { if (lane < 34) *reinterpret_cast<u32x4*>(wxbuf + lane * 16) = v; };
+    // element jj of the g fragment is lattice pixel 8 (lane >> 4) + jj + b, b = (lane & 15) >> 3: keep the own ones, 1..30
+    u32x4 wgmask;
+    {
+        unsigned mk[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int p0 = 8 * lg + 2 * w + ((lane & 15) >> 3), p1 = p0 + 1;
+            mk[w] = (p0 >= 1 && p0 <= OW ? 0x0000FFFFu : 0u) | (p1 >= 1 && p1 <= OW ? 0xFFFF0000u : 0u);
+        }
+        wgmask = u32x4{mk[0], mk[1], mk[2], mk[3]};
+    }
+    const u32x4 ones_bits = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    const bf16x8 WONES = __builtin_bit_cast(bf16x8, ones_bits);
+    bf16x8 WAX[3] = {zero8<bf16_t>(), zero8<bf16_t>(), zero8<bf16_t>()};
+    u32x4 WPX[3] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    if constexpr (WG1) {
+        // the first intermediate row of the walk is m = y0 - 1 (not own: its g fragment is cleared), the first own one y0: it
+        // needs x0 rows y0 - 1 (fragment now), y0 and y0 + 1 (staged by iterations 0 and 1); rows y0 .. y0 + 2 are requested here
+        const u32x4 r1 = load_wx(y0 - 1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) WPX[k] = load_wx(y0 + k);
+        stage_wx(r1);
+        __builtin_amdgcn_wave_barrier();
+        WAX[1] = wfrag(wxbuf);
+        __builtin_amdgcn_wave_barrier();
+    }
 
     // input row r in fragment layout: this lane's pixel is x0 - 2 + q; outside the image the offset is out of range -> 0
     const int lx = x0 - 2 + q;
@@ -186,7 +244,7 @@ __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
     // stores the hardware drops: with them the loop is entered in the state its back edge leaves behind (rows t+2..t+4 in
     // flight, each followed by a row's stores), and the compiler's merged wait before the first rows is the steady-state
     // vmcnt(9), not vmcnt(1) -- which would wait for ALL rows in flight once per trip
-    constexpr int kStoresPerRow = 2 + (!BWD && BITS ? 2 : 0);
+    constexpr int kStoresPerRow = (WG1 ? 1 : 2) + (!BWD && BITS ? 2 : 0);
 #pragma unroll
     for (int k = 0; k < 3 * kStoresPerRow; ++k) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rmid, kOOB + 8u * k, 0, 0);   // (distinct: equal ones are merged)
     M[0] = M[1] = M[2] = zero8<bf16_t>();
@@ -319,6 +377,7 @@ __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
             for (int jj = 0; jj < 4; ++jj) o[jj] = (bf16_t)v[jj];
             *reinterpret_cast<bf16x4*>(mwr + P * MP) = o;
             const bool ownrow = m >= y0 && m < y1;
+            if constexpr (!WG1)      // (WG1: the only other reader of this tensor was the weight-gradient launch)
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rmid, ownrow ? (unsigned)(m * a.row_bytes) + mid_col : kOOB, 0, 0);
             if constexpr (!BWD && BITS) {
                 // (mid > 0) as the four lane masks of this row: what the backward's phase 1 applies to the same lanes
@@ -332,6 +391,23 @@ __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
         // overlap, so without this (it emits nothing) the read can be hoisted above the write -- it was, at 16 channels
         __builtin_amdgcn_wave_barrier();
         M[(I + 1) % 3] = *reinterpret_cast<const bf16x8*>(mrd + P * MP);    // the row just written, in fragment layout
+        if constexpr (WG1) {
+            // x0 row m + 1 = t + 2 -> fragment; rows m - 1, m are WAX[I % 3], WAX[(I + 1) % 3] from the iterations before
+            stage_wx(WPX[I % 3]);
+            WPX[I % 3] = load_wx(t + 5);
+            __builtin_amdgcn_wave_barrier();
+            WAX[(I + 2) % 3] = wfrag(wxbuf);
+            u32x4 gb = __builtin_bit_cast(u32x4, wfrag(mr + P * MP));
+            __builtin_amdgcn_wave_barrier();
+            const bool ownm = m >= y0 && m < y1;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) gb[w] = ownm ? gb[w] & wgmask[w] : 0u;
+            const bf16x8 BG = __builtin_bit_cast(bf16x8, gb);
+            wacc[0] = mma8(WAX[I % 3], BG, wacc[0]);                        // ky 0: x0 row m - 1
+            wacc[1] = mma8(WAX[(I + 1) % 3], BG, wacc[1]);
+            wacc[2] = mma8(WAX[(I + 2) % 3], BG, wacc[2]);
+            waccb = mma8(WONES, BG, waccb);
+        }
         if constexpr (!SKEW) phase2();
         if constexpr (BWD) {                                               // masks of iteration t + 2
             cu64p pm = plane_row(pm0, m + 2), pa = plane_row(pa0, t + 2 - SKEW);
@@ -350,6 +426,32 @@ __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
         step(IC<3>{}, tg);
         step(IC<4>{}, tg);
         step(IC<5>{}, tg);
+    }
+    }   // live
+    if constexpr (WG1) {
+        // ---- the four waves' sums -> one slab, fixed order (as rowwgrad8_kernel)
+        float* slab = reinterpret_cast<float*>(smem + 4 * WAVE_LDS + 4 * WG_ROW);
+        for (int i = threadIdx.x; i < 8 * 80; i += 256) slab[i] = 0.f;
+        __syncthreads();
+        const int n = lane & 15, kg = lane >> 4, bb = n >> 3, co = n & 7;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int row = 4 * kg + jj, aa = row >> 3, ci = row & 7;
+                    if (!(aa == 1 && bb == 1)) {
+                        const int kx = aa - bb + 1;
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky) slab[co * 80 + (ky * 3 + kx) * 8 + ci] += wacc[ky][jj];
+                    }
+                }
+                if (kg == 0 && bb == 0) slab[co * 80 + 72] += waccb[0];
+            }
+            __syncthreads();
+        }
+        float* out = a.d.wg1_slabs + (size_t)blockIdx.x * (8 * 80);
+        for (int i = threadIdx.x; i < 8 * 80; i += 256) out[i] = slab[i];
     }
 }
 
@@ -885,8 +987,6 @@ struct RowWgradArgs {
     unsigned img_bytes;
 };
 
-typedef __attribute__((address_space(3))) bf16x4* lds_v4;
-constexpr int WG_ROW = 36 * 16;                                           // one staged row: 34 pixels used, 16-byte slots
 
 constexpr int WG_WAVES = 8;                                               // waves per workgroup = tasks per slab and round
 
@@ -1004,7 +1104,7 @@ constexpr int kFwd1 = MSAU_PAIR_RELU_IN | MSAU_PAIR_RELU_MID, kFwd2 = MSAU_CONV_
 constexpr int kBwd1 = MSAU_PAIR_MASK_MID, kBwd2 = MSAU_CONV_MASK_A | MSAU_CONV_ADD;
 
 // environment switches of this file, read once; msau_reload_env() makes the next call read them again (tests, A/B tools)
-struct RowsEnv { int on, sh, waves, min_tasks, maxc, conv, wgrad, dout; };
+struct RowsEnv { int on, sh, waves, min_tasks, maxc, conv, wgrad, dout, pairwg; };
 RowsEnv g_env;
 bool g_env_ok = false;
 const RowsEnv& rows_env() {
@@ -1016,6 +1116,7 @@ const RowsEnv& rows_env() {
         g_env.min_tasks = geti("MSAU_ROWS_MIN_TASKS", 16);       // below: the tile kernels (a wave per task needs a few tasks per XCD at least)
         g_env.wgrad = geti("MSAU_WGRAD_ROWS", 1);                // the 8 -> 8 3x3 weight gradients on the row kernel
         g_env.conv = geti("MSAU_CONV_ROWS", 1);                  // single convolutions of the 8-channel level on the row kernels
+        g_env.pairwg = geti("MSAU_PAIR_WGRAD", 1);               // the first conv's weight gradient inside the pair's data-gradient launch
         g_env.dout = geti("MSAU_DOUT_ROWS", 1);                  // the two-output data gradients (8 -> 8 + 8, 3x3 and 1x1) on the row kernels
         g_env.maxc = geti("MSAU_ROWS_MAXC", 16);                 // widest layer the row kernels take (8: the 16-channel pairs stay on the tile kernels)
         g_env_ok = true;
@@ -1043,10 +1144,12 @@ int msau_rowpair_takes(int dtype, const msau_conv_pair_desc* d) {
     const RowsEnv& e = rows_env();
     if (!e.on || dtype != MSAU_BF16 || (d->C != 8 && d->C != 16) || d->C > e.maxc || (d->flags1 & MSAU_PAIR_TILES)) return 0;
     const int pool_ok = d->C == 16 ? MSAU_CONV_POOL : 0;
-    const bool lrnb = d->flags1 & MSAU_PAIR_LRN_BWD;
-    const bool fwd = d->flags1 == kFwd1 && (d->flags2 & ~pool_ok) == kFwd2, bwd = (d->flags1 & ~MSAU_PAIR_LRN_BWD) == kBwd1 && d->flags2 == kBwd2;
+    const bool lrnb = d->flags1 & MSAU_PAIR_LRN_BWD, wg1 = d->flags1 & MSAU_PAIR_WGRAD1;
+    const bool fwd = d->flags1 == kFwd1 && (d->flags2 & ~pool_ok) == kFwd2,
+               bwd = (d->flags1 & ~(MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1)) == kBwd1 && d->flags2 == kBwd2;
     if (!fwd && !bwd) return 0;
     if (lrnb && !(bwd && d->C == 8 && d->lrn_a && d->lrn_da && d->lrn_k > 0.f)) return 0;
+    if (wg1 && !(bwd && d->C == 8 && d->wg1_x && d->wg1_slabs && e.pairwg)) return 0;
     if (fwd && (d->flags2 & MSAU_CONV_POOL) && !d->pool_y) return 0;
     if (bwd && !(d->bits_mid && d->bits_a)) return 0;
     if (d->add != d->x) return 0;
@@ -1063,11 +1166,20 @@ int64_t msau_rowpair_plane_bytes(const msau_conv_pair_desc* d) {
     return (int64_t)d->B * d->H * cdiv(d->W, d->C == 8 ? OW : OW16) * 32;
 }
 
+// workgroups (= slabs of an MSAU_PAIR_WGRAD1 launch) of the descriptor's launch
+int msau_rowpair_workgroups(const msau_conv_pair_desc* d) {
+    const bool c8 = d->C == 8;
+    const int nstrips = cdiv(d->W, c8 ? OW : OW16);
+    const int SH = segment_rows(d->B, d->H, nstrips, c8 ? 2 + SKEW : 2);
+    const int ntasks = d->B * nstrips * cdiv(d->H, SH);
+    return 8 * (roundup(cdiv(ntasks, 8), 4) / 4);
+}
+
 int msau_rowpair_launch(hipStream_t s, const msau_conv_pair_desc* d) {
     RowArgs a;
     a.d = *d;
     const bool c8 = d->C == 8;
-    const bool bwd = (d->flags1 & ~MSAU_PAIR_LRN_BWD) == kBwd1, bits = d->bits_mid && d->bits_a, pool = !bwd && (d->flags2 & MSAU_CONV_POOL);
+    const bool bwd = (d->flags1 & ~(MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1)) == kBwd1, bits = d->bits_mid && d->bits_a, pool = !bwd && (d->flags2 & MSAU_CONV_POOL);
     a.nstrips = cdiv(d->W, c8 ? OW : OW16);
     a.SH = segment_rows(d->B, d->H, a.nstrips, c8 ? 2 + SKEW : 2);
     if (pool && (a.SH & 1) && a.SH < d->H) ++a.SH;                          // 2x2 windows do not straddle segments
@@ -1079,7 +1191,10 @@ int msau_rowpair_launch(hipStream_t s, const msau_conv_pair_desc* d) {
     a.plane_img = (unsigned)d->H * (unsigned)a.nstrips * 32u;
     const dim3 grid(8 * (a.tasks_per_xcd / 4)), block(256);
     if (c8) {
-        if (bwd && (d->flags1 & MSAU_PAIR_LRN_BWD)) hipLaunchKernelGGL((rowpair_c8_kernel<true, true, true>), grid, block, 0, s, a);
+        const bool lrnb = d->flags1 & MSAU_PAIR_LRN_BWD, wg1 = d->flags1 & MSAU_PAIR_WGRAD1;
+        if (bwd && lrnb && wg1) hipLaunchKernelGGL((rowpair_c8_kernel<true, true, true, true>), grid, block, 0, s, a);
+        else if (bwd && wg1) hipLaunchKernelGGL((rowpair_c8_kernel<true, true, false, true>), grid, block, 0, s, a);
+        else if (bwd && lrnb) hipLaunchKernelGGL((rowpair_c8_kernel<true, true, true>), grid, block, 0, s, a);
         else if (bwd) hipLaunchKernelGGL((rowpair_c8_kernel<true, true>), grid, block, 0, s, a);
         else if (bits) hipLaunchKernelGGL((rowpair_c8_kernel<false, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((rowpair_c8_kernel<false, false>), grid, block, 0, s, a);

@@ -176,6 +176,8 @@ class ConvOp(Op):
         P.add_pack_entry(be, out.Cs)
         # ---- data-gradient images
         self.d_off = [None, None]
+        self.wg_fused = False        # the weight gradient rides on the residual pair's data-gradient launch (MSAU_PAIR_WGRAD1)
+        self.uentry = None
         self.dd_off = None           # one launch for both sources of a concat conv (MSAU_CONV_DOUT) when an instance has it
         if P.training and conv and x2 is not None and None not in self.slots and x1.C == x1.Cs == x2.C == x2.Cs \
                 and x1.Cs + x2.Cs <= 128 and os.environ.get("MSAU_FUSE_DGRAD", "1") != "0":
@@ -358,6 +360,7 @@ class ConvOp(Op):
             u.b_src_off, u.b_slab_stride, u.b_elem_stride, u.b_nslabs = self.csum_off, out.Cs, 1, self.csum_blocks
             u.b_count = out.C
         P.add_unpack_entry(u, slab_elems, self.reduce_group())
+        self.uentry = u
 
     def late_bind(self):
         P = self.plan
@@ -419,7 +422,8 @@ class ConvOp(Op):
                 self.wkey = f"wgrad_kernel<{T},CT{ctn},NK{nkw}>"
             self.wbytes = (w.B * w.Hin * w.Win * (w.C1 + w.C2) * wg.nchunks // wg.nchunks + w.B * w.Hout * w.Wout * w.Cout) * esz \
                 + w.nslabs * wg.slab_bytes
-            P.note_launch(self.wkey, self.wbytes, self.flops)
+            if not self.wg_fused:
+                P.note_launch(self.wkey, self.wbytes, self.flops)
             if self.kind != "conv":                      # bias gradient of the transposed conv: one pass over its output gradient
                 P.note_launch("msau_channel_sum", self.out.npix * self.out.Cs * esz, 0.0)
 
@@ -447,13 +451,14 @@ class ConvOp(Op):
         if self.x1 is self.plan.x_in:
             side = 0        # the net's first conv has no data gradient: nothing is left on the main stream to run beside,
                             # and the side stream is still busy with the two weight gradients enqueued before this one
-        recs = [(L.OP_WGRAD | side, self.wdesc)]
+        recs = [] if self.wg_fused else [(L.OP_WGRAD | side, self.wdesc)]
         if self.kind != "conv":
             P = self.plan
             self._csum = L.CsumArgs(_ptr(self.out.grad), self.out.npix, self.out.Cs, P.slab_ptr(self.csum_off), self.csum_blocks)
             recs.append((L.OP_CHANNEL_SUM | side, self._csum))
         rm = self.plan.rec_meta
-        rm[C.addressof(self.wdesc)] = (self.wkey, self.wbytes)
+        if not self.wg_fused:
+            rm[C.addressof(self.wdesc)] = (self.wkey, self.wbytes)
         if self.pair is not None and self.pair.active and self.pair.bdesc is not None:
             if self is self.pair.c2:                    # both data gradients in one launch, behind the second conv's wgrad
                 rm[C.addressof(self.pair.bdesc)] = (self.pair.key, self.pair.bbytes)
@@ -467,7 +472,7 @@ class ConvOp(Op):
 
     def bwd_wgrad(self, s):
         """weight / bias gradient: reads out.grad and the saved inputs, writes only this op's slabs"""
-        if self.wdesc is None:
+        if self.wdesc is None or self.wg_fused:
             return
         P = self.plan
         L.call("msau_conv2d_wgrad", s, P.dtype, C.byref(self.wdesc), key=self.wkey)
@@ -593,11 +598,31 @@ class PairOp:
                     else:
                         b.flags1 &= ~L.PAIR_LRN_BWD
                         b.lrn_a = b.lrn_da = None
+                # the first conv's weight gradient rides on this launch too: its g operand is the row the walk has just produced
+                u = c1.uentry
+                if self.bdesc is not None and u is not None and c1.wdesc is not None and c1.relu_in and r1.n_contrib == 1 \
+                        and u.kext == 80 and u.slab_elems == 640 and os.environ.get("MSAU_PAIR_WGRAD", "1") != "0":
+                    b.flags1 |= L.PAIR_WGRAD1
+                    b.wg1_x, b.wg1_slabs = _ptr(x0.data), 1                 # (placeholder: the slab arena does not exist yet)
+                    ns = int(L.load().msau_conv_pair_wgrad_slabs(P.dtype, C.byref(b)))
+                    if ns > 0:
+                        self.wg_slab_off = P.alloc_slab(ns * 640)
+                        u.slab_off, u.nslabs = self.wg_slab_off, ns
+                        u.b_src_off, u.b_nslabs = self.wg_slab_off + 72, ns
+                        c1.wg_fused = True
+                        self.bbytes += ns * 640 * 4                      # x0 read instead of the intermediate gradient written; the slabs
+                    else:
+                        b.flags1 &= ~L.PAIR_WGRAD1
+                        b.wg1_x = b.wg1_slabs = None
         # label by the instance that takes the launches (the backward descriptor, once it has its planes, decides for both)
         probe = self.bdesc if self.bdesc is not None else f
         if L.load().msau_conv_pair_instance(P.dtype, C.byref(probe)) == 2:
             self.key = f"rowpair_kernel<{T},C{x0.Cs}>"
         self.active = True
+
+    def late_bind(self):
+        if self.bdesc is not None and self.c1.wg_fused:
+            self.bdesc.wg1_slabs = self.plan.slab_ptr(self.wg_slab_off)
 
     def note(self):
         """replace the two convs' launch accounting by the fused launches' (bench.py roofline)"""
@@ -1141,12 +1166,14 @@ class Plan:
         for op in self.ops:
             if isinstance(op, ConvOp):
                 op.bind()
+        for pr in self.pairs:
+            pr.bind()                    # (before the slab arena exists: a pair that takes over a weight gradient sizes its slabs)
         self.slab_arena = torch.zeros(max(self._slab_elems, 64), dtype=torch.float32, device=self.device)
         for op in self.ops:
             if isinstance(op, ConvOp):
                 op.late_bind()
         for pr in self.pairs:
-            pr.bind()
+            pr.late_bind()
             pr.note()
         for op in self.ops:
             if not isinstance(op, ConvOp):

@@ -469,3 +469,41 @@ def test_lrn_backward_in_the_pair_epilogue_matches_the_standalone_pass(monkeypat
     assert err(outs[0][1], outs[1][1], True) < 2e-2
     assert err(outs[0][2], outs[1][2], True) < 1e-3
     assert outs[0][3] == outs[1][3] - 3
+
+
+@pytest.mark.parametrize("B,channels,H,W", [(4, 64, 112, 96), (3, 13, 75, 91), (2, 8, 45, 150)])
+def test_first_conv_weight_gradient_in_the_pair_launch_matches_the_standalone_launch(monkeypatch, B, channels, H, W):
+    """MSAU_PAIR_WGRAD1: the level-0 residual block's data-gradient launch also accumulates the weight (and bias) gradient of
+    the block's first conv from the intermediate rows it has in LDS; the stand-alone weight-gradient launch and the
+    intermediate gradient tensor's round trip through memory are gone.  Same bf16 operands, fp32 sums in another order."""
+    from oracle import msau_oracle as O
+    from msau_amd import _lib as L
+    x, label = O.synthetic_batch(B, channels, H, W, 5, seed=12)
+    x, label = x.cuda(), label.cuda()
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("MSAU_PAIR_WGRAD", fuse)
+        L.load().msau_reload_env()
+        kw = dict(scale_space_num=4, res_depth=2, featRoot=8, final_act="softmax", num_blocks=3, dtype="bf16", seed=3)
+        m = MSAUWrapper(channels, 5, kw).cuda()
+        eng = TrainEngine(m)
+        eng.step(x, label)
+        torch.cuda.synchronize()
+        plan = m._plan_for(x, True)
+        nf = sum(1 for pr in plan.pairs if pr.active and pr.c1.wg_fused)
+        assert nf == (6 if fuse == "1" else 0), nf                      # encoder and decoder block of the 8-channel level, 3 stages
+        outs.append((eng.flat_grad.float().cpu(), m.flat_parameters.float().cpu(), sum(n for n, _, _ in plan.launch_meta.values()),
+                     {pr.c1.wname: (plan.poff[pr.c1.wname], plan.poff[pr.c1.bname]) for pr in plan.pairs if pr.active and pr.c1.x1.Cs == 8},
+                     dict(plan.pshape)))
+    monkeypatch.delenv("MSAU_PAIR_WGRAD")
+    L.load().msau_reload_env()
+    g1, g0 = outs[0][0], outs[1][0]
+    for wname, (woff, boff) in outs[0][3].items():
+        n = int(np.prod(outs[0][4][wname]))
+        a, b = g1[woff:woff + n], g0[woff:woff + n]
+        assert float(b.abs().max()) > 0 and err(a, b, True) < 2e-3, wname
+        a, b = g1[boff:boff + 8], g0[boff:boff + 8]
+        assert float(b.abs().max()) > 0 and err(a, b, True) < 2e-3, wname
+    assert err(g1, g0, True) < 2e-3
+    assert err(outs[0][1], outs[1][1], True) < 1e-3
+    assert outs[0][2] == outs[1][2] - 6
