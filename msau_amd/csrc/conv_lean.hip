@@ -799,7 +799,7 @@ int msau_conv_lean_dout_capable(int dtype, const msau_conv_desc* d, int nchunks,
 
 // ---- fused epilogues: the instances that exist (the featRoot-8 / featRoot-16 shapes of the reference's configurations);
 // everything else runs the stand-alone LRN / pool launch.  One table for the capability queries and the dispatch.
-//   LRN : level-entry convs  8 -> 8 (3x3), 8 -> 16 (dilation 2), 16 -> 16, 16 -> 32 (dilation 4 / 2)
+//   LRN : level-entry convs  8 -> 8 (3x3), 8 -> 16 (dilation 2), 16 -> 16, 16 -> 32 (dilation 4 / 2), 64 -> 8 (the net's first conv)
 //   POOL: coupling 1x1 convs over concat (8+8 -> 8, 16+16 -> 16, 32+32 -> 32) and the split 32 -> 32 3x3 (stage 0, level 2)
 static bool lean_wide_tile(const msau_conv_desc* d, int tiles_y) {          // the 16 x 32 tile of lean_ct
     return d->Wout >= 64 && (int64_t)d->B * tiles_y * cdiv(d->Wout, 32) >= 512;
@@ -813,6 +813,12 @@ static int lean_epi_case(int dtype, const msau_conv_desc* d, int CT, int epi) {
         if (c8 == 2 && CT == 2 && d->dil == 4 && d->Cout == 32) return 4;
         if (c8 == 2 && CT == 1 && d->dil == 1 && d->Cout == 16) return 5;
         if (c8 == 2 && CT == 2 && d->dil == 2 && d->Cout == 32) return 6;
+        // the net's first conv (64 one-hot channels -> featRoot 8): measured 9 us SLOWER per step than the conv + the 8.4 us stand-alone
+        // LRN launch (the epilogue instance loses more than the launch costs): off unless MSAU_LRN_FIRST=1
+        if (c8 == 8 && CT == 1 && d->dil == 1 && d->Cout == 8) {                    // (one query per step: read the switch every time)
+            const char* v = std::getenv("MSAU_LRN_FIRST");
+            if (v && v[0] == '1') return 7;
+        }
     }
     if (epi == EPI_POOL && d->dil == 1) {
         if (dual && k == 1 && !split) {
@@ -833,6 +839,7 @@ int lean_epi(hipStream_t s, const LeanArgs& a, int which) {
         case 4: return launch_lean<T, 2, 2, 3, false, 4, 1, false, false, 1, 1, EPI_LRN>(s, a);
         case 5: return launch_lean<T, 2, 1, 3, false, 1, 1, false, false, 1, 1, EPI_LRN>(s, a);
         case 6: return launch_lean<T, 2, 2, 3, false, 2, 1, false, false, 1, 1, EPI_LRN>(s, a);
+        case 7: return launch_lean<T, 8, 1, 3, false, 1, 1, false, false, 1, 1, EPI_LRN>(s, a);
         case 10: return launch_lean<T, 2, 1, 1, true, 1, 1, false, false, 1, 1, EPI_POOL>(s, a);
         case 11: return launch_lean<T, 4, 1, 1, true, 1, 1, false, false, 1, 1, EPI_POOL>(s, a);
         case 12: return launch_lean<T, 8, 2, 1, true, 1, 1, false, false, 1, 1, EPI_POOL>(s, a);
