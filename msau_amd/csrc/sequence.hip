@@ -104,7 +104,7 @@ extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_strea
     // MI355X / ROCm 7.2 against 2 us for a whole tiny kernel (tools/launch_floor.py).  Side ops only need inputs that
     // stay valid for the rest of the sweep, so they are held back and released in batches behind ONE fork: when
     // `fork_every` of them are pending, before a slab reduction (it consumes them), before a join, and at the end.
-    static const int fork_every = std::getenv("MSAU_FORK_EVERY") ? atoi(std::getenv("MSAU_FORK_EVERY")) : 8;
+    static const int fork_every = std::getenv("MSAU_FORK_EVERY") ? atoi(std::getenv("MSAU_FORK_EVERY")) : 6;   // (round 3, after the fused launches: 1: +8 %, 2: +2 %, 3-4: 0, 5-6: -0.7 %, 8: 0, 12: +1 %, 24: +4 %)
     std::vector<std::pair<msau_op, int>> pending;
     bool any_side = false;
     // A second side queue (MSAU_SIDE2, owned by the library): weight gradients are mutually independent and most of their

@@ -130,7 +130,10 @@ class ConvOp(Op):
         """slab-reduction group: the stage, except for the level-0 encoder convs of stage 0.  They close the backward
         sweep, and whatever is reduced behind them is exposed; with a group of their own the bulk of stage 0 (the
         level-1..3 layers own most of the slab bytes) is reduced earlier, while the level-0 launches still run."""
-        return -1 if (self.stage == 0 and self.name.startswith("s0.d0.")) else self.stage
+        # (round 3: MSAU_TAIL_LEVELS = 2..4 moves the stage's own reduction, 60 us of slab reads, up to where the level-1..3 encoder
+        #  launches begin: measured 0.0 % -- the side queue is busy throughout the backward sweep, so its END does not move)
+        n = int(os.environ.get("MSAU_TAIL_LEVELS", "1"))
+        return -1 if (self.stage == 0 and any(self.name.startswith(f"s0.d{l}.") for l in range(n))) else self.stage
 
     def reads(self):
         return [t for t in (self.x1, self.x2, self.fwd_add) if t is not None]

@@ -120,5 +120,16 @@ for (H, W, Cc) in ((336, 256, 8), (168, 128, 16)):
     res["fwd pair"] = timed(lambda: L.check(lib.msau_conv_pair(s, L.BF16, C.byref(pf))))
     res["bwd 2 launches"] = timed(lambda: two(d2, d1))
     res["bwd pair"] = timed(lambda: L.check(lib.msau_conv_pair(s, L.BF16, C.byref(pb))))
+    if Cc == 8:
+        # riders of the 8-channel data-gradient launch: LRN backward in the epilogue, the first conv's weight gradient
+        la, lda = t(), t()
+        for tag, fl in (("bwd pair +lrn", L.PAIR_LRN_BWD), ("bwd pair +wg1", L.PAIR_WGRAD1), ("bwd pair +lrn+wg1", L.PAIR_LRN_BWD | L.PAIR_WGRAD1)):
+            q = pair_desc(False)
+            q.flags1 |= fl
+            q.lrn_a, q.lrn_da, q.lrn_alpha_over_n, q.lrn_beta, q.lrn_k = la.data_ptr(), lda.data_ptr(), 1e-4 / 8, 0.75, 1.0
+            slabs = torch.zeros(4096 * 640, device=dev)
+            q.wg1_x, q.wg1_slabs = x.data_ptr(), slabs.data_ptr()
+            if lib.msau_conv_pair_applicable(L.BF16, C.byref(q)):
+                res[tag] = timed(lambda: L.check(lib.msau_conv_pair(s, L.BF16, C.byref(q))))
     mb = n * 2 / 1e6
     print(f"C={Cc} {H}x{W}: tensor {mb:.1f} MB | " + " | ".join(f"{k} {v:.1f} us" for k, v in res.items()))
