@@ -227,7 +227,7 @@ def secondary_measurements(args, L, MSAUWrapper, TrainEngine, dev, n_class):
             occ = x.sum(1) > 0
             ids = torch.where(occ, x.argmax(1), torch.full_like(x.argmax(1), -1)).to(torch.int32).contiguous()
         step = (lambda: eng.step_ids(ids, label)) if feed == "ids" else (lambda: eng.step(x, label))
-        if feed == "device-painted":
+        if feed in ("device-painted", "device-painted, prefetched"):
             # the BERT chargrid as its loader builds it (data_generator_funsd_bert.py:64-93): one feature vector per text line
             # painted over the line's box.  Box lists and the feature table live on the device; every step paints the grid
             # into the plan's own NHWC buffer (msau_raster_dense) and the label mask (msau_raster_labels) -- no fp32 NCHW tensor,
@@ -247,6 +247,14 @@ def secondary_measurements(args, L, MSAUWrapper, TrainEngine, dev, n_class):
             lbt = torch.from_numpy(np.asarray(lb, np.int32)).to(dev)
             feats = torch.randn((len(fb), channels), device=dev)
             step = lambda: eng.step_boxes(fbt, lbt, batch, H, W, feats=feats)
+            if feed == "device-painted, prefetched":
+                # the loader's pipeline: the NEXT batch is painted (into the second input buffer, on the side stream) while this
+                # one trains; every timed step still contains one paint and one optimisation step
+                eng.prefetch_boxes(fbt, lbt, batch, H, W, feats=feats)
+
+                def step():
+                    eng.prefetch_boxes(fbt, lbt, batch, H, W, feats=feats)
+                    return eng.step_prefetched()
         for _ in range(5):
             step()
         torch.cuda.synchronize()
@@ -276,6 +284,11 @@ def secondary_measurements(args, L, MSAUWrapper, TrainEngine, dev, n_class):
     if hasattr(TrainEngine, "step_boxes"):
         run("cfg4 fed from box lists: the embedding grid is painted on the device into the plan's NHWC input every step (no fp32 NCHW tensor, no boundary conversion; SURVEY 8f N1)",
             768, 2, "bf16", args.batch, feed="device-painted")
+    if hasattr(TrainEngine, "prefetch_boxes") and os.environ.get("MSAU_BENCH_PREFETCH") == "1":
+        # measured 2026-10-04: 4829 against 4863 tiles/s un-prefetched -- the painter's 2.1 GB store beside the first conv's 2.1 GB
+        # read only shares the same HBM; bytes, not latency, are what cfg 4 pays for.  Kept as an opt-in line.
+        run("cfg4 fed from box lists, next batch painted while this one trains (TrainEngine.prefetch_boxes / step_prefetched: two input buffers, the painter on the side stream during the forward sweep)",
+            768, 2, "bf16", args.batch, feed="device-painted, prefetched")
     run("cfg2 in fp32 storage (the parity mode of the same kernels)", args.channels, args.stages, "fp32", args.batch)
     run("cfg5: model_box variant 512x384x64, 3-stage (BASELINE configs[4]; BoxConv2d is third-party: self-consistent only)", 64, 3,
         "bf16", args.batch, box=True, hw=(512, 384))

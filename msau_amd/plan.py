@@ -1444,6 +1444,32 @@ class Plan:
                    self.head_argmax.data_ptr(), lg.npix, lg.C, lg.Cs)
         return self.head_probs, self.head_argmax
 
+    def input_buffer(self, k: int) -> torch.Tensor:
+        """Input buffer k (0 = the plan's own, 1 = a second one allocated on first use): a producer on another stream paints
+        the NEXT batch into the buffer this step does not read (TrainEngine.prefetch_boxes)."""
+        if not hasattr(self, "_x_bufs"):
+            self._x_bufs = [self.x_in.data, None]
+        if self._x_bufs[k] is None:
+            self._x_bufs[k] = torch.zeros_like(self.x_in.data)
+        return self._x_bufs[k]
+
+    def use_input(self, k: int):
+        """Point the launches that read the net's input (the first conv and its weight gradient) at input buffer k.  The
+        descriptors are launched by value, so flipping them between sweeps is safe."""
+        buf = self.input_buffer(k)
+        if buf is self.x_in.data:
+            return
+        self._feed_ids(None)
+        old = self.x_in.data.data_ptr()
+        for op in self.ops:
+            if isinstance(op, ConvOp):
+                for d in (op.fdesc, op.wdesc):
+                    if d is not None:
+                        for f in ("x1", "x2"):
+                            if getattr(d, f) == old:
+                                setattr(d, f, buf.data_ptr())
+        self.x_in.data = buf
+
     @property
     def input_nhwc(self) -> torch.Tensor:
         """The net's input buffer: [B][H][W][Cs] in the storage dtype, channels beyond `channels` zero.  A producer on the

@@ -417,3 +417,48 @@ def test_train_step_is_bit_reproducible_beside_the_side_stream():
             ref = cur
         else:
             assert cur[0] == ref[0] and torch.equal(cur[1], ref[1]), f"step {it} differs from step 0"
+
+
+@pytest.mark.parametrize("dense", [True, False])
+def test_prefetched_box_batches_train_exactly_like_step_boxes(dense):
+    """TrainEngine.prefetch_boxes / step_prefetched: the next batch is painted into the plan's SECOND input buffer on the side
+    stream while the current step runs.  A sequence of DIFFERENT batches (so a stale or swapped buffer would show) must give
+    the losses, gradients and parameters of the same batches through step_boxes, bit for bit."""
+    torch.manual_seed(3)
+    B, H, W, C, ncls = 3, 40, 56, 24, 5
+    rng = np.random.default_rng(12)
+
+    def batch():
+        boxes, labs = [], []
+        for b in range(B):
+            for i in range(12):
+                y0, x0 = int(rng.integers(0, H - 4)), int(rng.integers(0, W - 6))
+                y1, x1 = y0 + int(rng.integers(1, 6)), x0 + int(rng.integers(2, 12))
+                boxes.append((b, y0, y1, x0, x1, len(boxes) if dense else int(rng.integers(0, C))))
+                labs.append((b, y0, y1, x0, x1, int(rng.integers(1, ncls))))
+        boxes, labs = np.asarray(boxes, np.int32), np.asarray(labs, np.int32)
+        feats = rng.standard_normal((len(boxes), C)).astype(np.float32) if dense else None
+        return boxes, labs, feats
+    batches = [batch() for _ in range(5)]
+    kw = dict(scale_space_num=3, res_depth=2, featRoot=8, final_act="softmax", num_blocks=2, dtype="bf16", seed=4, deterministic=True)
+    res = {}
+    for mode in ("prefetch", "plain"):
+        m = MSAUWrapper(C, ncls, kw).cuda()
+        eng = TrainEngine(m)
+        losses = []
+        if mode == "plain":
+            for bx, lb, ft in batches:
+                losses.append(float(eng.step_boxes(bx, lb, B, H, W, feats=ft)))
+        else:
+            eng.prefetch_boxes(batches[0][0], batches[0][1], B, H, W, feats=batches[0][2])
+            for i in range(len(batches)):
+                if i + 1 < len(batches):
+                    bx, lb, ft = batches[i + 1]
+                    eng.prefetch_boxes(bx, lb, B, H, W, feats=ft)
+                losses.append(float(eng.step_prefetched()))
+            plan = m._plan_for_shape(B, H, W, torch.device("cuda", 0), True)
+            assert plan.input_buffer(0).data_ptr() != plan.input_buffer(1).data_ptr()
+        torch.cuda.synchronize()
+        res[mode] = (losses, eng.flat_grad.clone(), m.flat_parameters.clone())
+    assert res["prefetch"][0] == res["plain"][0], (res["prefetch"][0], res["plain"][0])
+    assert torch.equal(res["prefetch"][1], res["plain"][1]) and torch.equal(res["prefetch"][2], res["plain"][2])
