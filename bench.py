@@ -227,7 +227,8 @@ def secondary_measurements(args, L, MSAUWrapper, TrainEngine, dev, n_class):
             occ = x.sum(1) > 0
             ids = torch.where(occ, x.argmax(1), torch.full_like(x.argmax(1), -1)).to(torch.int32).contiguous()
         step = (lambda: eng.step_ids(ids, label)) if feed == "ids" else (lambda: eng.step(x, label))
-        if feed in ("device-painted", "device-painted, prefetched"):
+        if feed in ("device-painted", "device-painted, prefetched", "box-lists"):
+            os.environ["MSAU_OWNER_CONV"] = "1" if feed == "box-lists" else "0"     # (read when the plan first meets a box-list step)
             # the BERT chargrid as its loader builds it (data_generator_funsd_bert.py:64-93): one feature vector per text line
             # painted over the line's box.  Box lists and the feature table live on the device; every step paints the grid
             # into the plan's own NHWC buffer (msau_raster_dense) and the label mask (msau_raster_labels) -- no fp32 NCHW tensor,
@@ -277,6 +278,7 @@ def secondary_measurements(args, L, MSAUWrapper, TrainEngine, dev, n_class):
                                       "alg_MB_per_launch": round(meta[1] / meta[0] / 1e6, 2), "GB/s": round(gbs, 1),
                                       "frac": round(gbs / HBM_PEAK_GBS, 4), "share_of_step": round(ms / sum(r[0] for r in rows), 3)}
         out.append(ent)
+        os.environ.pop("MSAU_OWNER_CONV", None)
         del eng, model, x, label
         torch.cuda.empty_cache()
 
@@ -284,6 +286,9 @@ def secondary_measurements(args, L, MSAUWrapper, TrainEngine, dev, n_class):
     if hasattr(TrainEngine, "step_boxes"):
         run("cfg4 fed from box lists: the embedding grid is painted on the device into the plan's NHWC input every step (no fp32 NCHW tensor, no boundary conversion; SURVEY 8f N1)",
             768, 2, "bf16", args.batch, feed="device-painted")
+    if hasattr(TrainEngine, "step_boxes"):
+        run("cfg4 fed from box lists, the grid NEVER painted: the first conv gathers per-tap partial products per feature row, its weight gradient sums the output gradient per box (MSAU_CONV_OWNER, csrc/ownerconv.hip; SURVEY 8f N1)",
+            768, 2, "bf16", args.batch, feed="box-lists")
     if hasattr(TrainEngine, "prefetch_boxes") and os.environ.get("MSAU_BENCH_PREFETCH") == "1":
         # measured 2026-10-04: 4829 against 4863 tiles/s un-prefetched -- the painter's 2.1 GB store beside the first conv's 2.1 GB
         # read only shares the same HBM; bytes, not latency, are what cfg 4 pays for.  Kept as an opt-in line.

@@ -86,6 +86,14 @@ enum {
                                    (id == c), ids outside [0, C1) are empty pixels -- the one-hot chargrid is synthesised in
                                    LDS, never painted nor read, and the result equals the dense launch bit for bit.  C1 = 64,
                                    3x3, <= 16 output channels; info[7] & 16.  msau_conv2d_wgrad takes the same flag. */
+    MSAU_CONV_OWNER    = 2048,  /* the net's first conv fed with BOX LISTS instead of a painted tensor (csrc/ownerconv.hip): x1 is a
+                                   HOST pointer to an msau_owner_ctx -- per pixel the index of the owning box (msau_raster_owner), the
+                                   box list, the feature table.  The piecewise-constant embedding chargrid (data_generator_funsd_bert.py:
+                                   64-93,240; 1536 bytes per pixel at 768 channels) is never painted: the forward gathers per-tap partial
+                                   products from a [feature row][tap][co] table, the weight gradient sums the output gradient per box
+                                   and tap.  3x3, stride 1, C1 -> 8; other flags: RELU_OUT only; also on msau_wgrad_desc.flags (x1 =
+                                   the same context; the first msau_owner_slabs(d) slabs are written -- the slab reduction must be told).
+                                   msau_conv2d_launch_info: info[7] & 32 when the launch can take it. */
     MSAU_CONV_HEAD     = 64     /* inference head (kv_model.py:305-313): besides y, write softmax over the Cout real
                                    channels of the (storage-rounded) result to head_probs (fp32 [B][Hout][Wout][Cout],
                                    dense) and the index of its first maximum to head_argmax (uint8 [B][Hout][Wout]).
@@ -143,7 +151,7 @@ int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d);
  * info[6] = 1 if a compile-time-specialised "lean" instance (conv_lean.hip) takes the launch, 2 if the chunked-K instance does,
  *           3 if a row-streaming instance (conv_rows.hip) does,
  * info[7] = bit 0: that instance implements MSAU_CONV_HEAD for this descriptor, bit 1: MSAU_CONV_DOUT,
- *           bit 2: MSAU_CONV_LRN, bit 3: MSAU_CONV_POOL, bit 4: MSAU_CONV_IDS */
+ *           bit 2: MSAU_CONV_LRN, bit 3: MSAU_CONV_POOL, bit 4: MSAU_CONV_IDS, bit 5: MSAU_CONV_OWNER */
 int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info8);
 
 /* ------------------------------------------------------------------------------------------
@@ -512,6 +520,21 @@ int msau_comm_unique_id(void* id128_out, int bytes);
 int msau_comm_init(void** comm_out, int world, int rank, const void* id128, int bytes);
 int msau_comm_destroy(void* comm);
 int msau_allreduce_bucket(void* stream, void* comm, float* buf, int64_t count);
+
+/* context of an MSAU_CONV_OWNER launch (host struct; every pointer inside is a DEVICE pointer) */
+typedef struct {
+    const int32_t* owner;       /* [B][H][W]: index of the box that owns the pixel, -1 = none (msau_raster_owner)              */
+    const int32_t* boxes;       /* [n_boxes][6] = sample, y0, y1, x0, x1, value (= row of feats)                               */
+    const float* feats;         /* [n_vec][C] fp32 feature table                                                              */
+    const float* w;             /* the conv's fp32 master weight, OIHW [8][C][3][3] (rounded to the storage type on the fly)   */
+    float* wt;                  /* workspace, max(C, 32) * 72 floats (the weight re-ordered and rounded for the table product)  */
+    float* table;               /* workspace, n_vec * 72 floats  (forward)                                                    */
+    float* sums;                /* workspace, n_boxes * 72 floats (weight gradient)                                           */
+    float* csum;                /* workspace, csum_blocks * 8 floats (bias gradient partials, msau_channel_sum)               */
+    int32_t n_boxes, n_vec, C, csum_blocks;
+} msau_owner_ctx;
+
+int msau_owner_slabs(const msau_wgrad_desc* d);   /* slabs an MSAU_CONV_OWNER weight gradient of this descriptor writes (<= d->nslabs) */
 
 /* misc */
 /* occupy the stream for ~microseconds (<= 200000) with a single sleeping wave: measurement aid only */

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MSAU_HIP_LIB", os.path.join(HERE, "libmsau_hip.so"))
 F32, BF16 = 0, 1
 
 CONV_RELU_IN, CONV_RELU_OUT, CONV_ADD, CONV_ACCUM, CONV_MASK_A, CONV_MASK_B, CONV_HEAD, CONV_DOUT = 1, 2, 4, 8, 16, 32, 64, 128
-CONV_LRN, CONV_POOL, CONV_IDS = 256, 512, 1024
+CONV_LRN, CONV_POOL, CONV_IDS, CONV_OWNER = 256, 512, 1024, 2048
 
 i32, i64, vp, f32 = C.c_int32, C.c_int64, C.c_void_p, C.c_float
 
@@ -105,6 +105,11 @@ class AllreduceArgs(C.Structure):
     _fields_ = [("comm", vp), ("buf", vp), ("count", i64)]
 
 
+class OwnerCtx(C.Structure):
+    _fields_ = [(n, vp) for n in ("owner", "boxes", "feats", "w", "wt", "table", "sums", "csum")] + \
+               [(n, i32) for n in ("n_boxes", "n_vec", "C", "csum_blocks")]
+
+
 OP_SIDE = 0x100
 OP_PROBE = 0x200
 OP_COMM = 0x400
@@ -127,6 +132,7 @@ _SIGNATURES = {
     "msau_conv_pair_bits_bytes": (C.c_int64, [C.c_int, C.POINTER(ConvPairDesc)]),
     "msau_conv_pair_instance": (C.c_int, [C.c_int, C.POINTER(ConvPairDesc)]),
     "msau_conv_pair_wgrad_slabs": (C.c_int, [C.c_int, C.POINTER(ConvPairDesc)]),
+    "msau_owner_slabs": (C.c_int, [C.POINTER(WgradDesc)]),
     "msau_comm_available": (C.c_int, []),
     "msau_comm_unique_id": (C.c_int, [vp, C.c_int]),
     "msau_comm_init": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, vp, C.c_int]),
@@ -187,7 +193,7 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 # ctypes mirrors in the order of msau_sizeof(which): load() refuses a library whose structs have another size
 ABI_STRUCTS = (ConvDesc, WgradDesc, PackEntry, UnpackEntry, Op, LrnArgs, PoolArgs, AttnArgs, CsumArgs, ReduceArgs,
-               ConvPackGeom, WgradGeom, ConvPairDesc, BoxArgs, AllreduceArgs)
+               ConvPackGeom, WgradGeom, ConvPairDesc, BoxArgs, AllreduceArgs, OwnerCtx)
 
 
 class MsauHipError(RuntimeError):

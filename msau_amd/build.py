@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmsau_hip.so")
-SOURCES = ["pack.hip", "conv.hip", "conv_lean.hip", "conv_pair.hip", "conv_rows.hip", "conv_wgrad.hip", "wgrad_lean.hip", "elementwise.hip", "attention.hip", "attention_mfma.hip", "raster.hip", "boxconv.hip", "sequence.hip", "comm.hip"]
+SOURCES = ["pack.hip", "conv.hip", "conv_lean.hip", "conv_pair.hip", "conv_rows.hip", "conv_wgrad.hip", "wgrad_lean.hip", "elementwise.hip", "attention.hip", "attention_mfma.hip", "raster.hip", "boxconv.hip", "sequence.hip", "comm.hip", "ownerconv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"] + os.environ.get("MSAU_EXTRA_HIPCC_FLAGS", "").split() + [
          "-ffp-contract=fast"]
 
@@ -23,7 +23,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 EXTRA_FLAGS = {"elementwise.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
                # MFMA results straight into VGPRs (gfx950 has one unified file): without it the row kernel's accumulators live in
                # AGPRs and every epilogue starts with four v_accvgpr_read
+               # ... and, since round 3 put the LRN backward into the residual pair's epilogue (MSAU_PAIR_LRN_BWD: the same adjoint-window
+               # chains as lrn_fast_kernel, beside the same side-stream kernels), WITHOUT packed-fp32 instructions like elementwise.hip:
+               # the compiler had produced 31 op_sel'd v_pk_*_f32 in exactly those two instances (tests/test_host_cpu.py reads the ISA)
                "conv_rows.hip": ["-std=c++20"] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.environ.get("MSAU_ROWS_VGPR_FORM", "1") != "0" else [])
+                                + (["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] if os.environ.get("MSAU_ROWS_PACKED_FP32", "0") != "1" else [])
                                 + (["-DMSAU_ROWCONV_PF=" + os.environ["MSAU_ROWCONV_PF"]] if os.environ.get("MSAU_ROWCONV_PF") else [])}
 
 

@@ -352,6 +352,11 @@ extern "C" int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32
               (((d->flags & MSAU_CONV_DOUT) && g.nslices == 1 && msau_rowconv_takes(dtype, d)) << 1) |
               (msau_conv_lean_lrn_capable(dtype, d, g.nchunks, g.CT) << 2) | (msau_conv_lean_pool_capable(dtype, d, g.nchunks, g.CT) << 3) |
               (msau_conv_lean_ids_capable(dtype, d, g.nchunks, g.CT) << 4);
+    {
+        msau_conv_desc p = *d;
+        p.flags |= MSAU_CONV_OWNER;
+        if (msau_ownerconv_takes(dtype, &p)) info[7] |= 32;
+    }
     if (g.nslices == 1 && !(info[7] & 4)) {              // would a row-streaming instance take this launch with MSAU_CONV_LRN added?
         msau_conv_desc p = *d;
         p.flags |= MSAU_CONV_LRN;
@@ -385,6 +390,10 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
     MSAU_CHECK_ARG(!(d->flags & MSAU_CONV_ADD) || d->add, "conv2d: ADD without pointer");
     MSAU_CHECK_ARG(!(d->flags & MSAU_CONV_MASK_A) || d->mask_a, "conv2d: MASK_A without pointer");
     MSAU_CHECK_ARG(!(d->flags & MSAU_CONV_MASK_B) || d->mask_b, "conv2d: MASK_B without pointer");
+    if (d->flags & MSAU_CONV_OWNER) {                                          // ownerconv.hip: box lists instead of a painted input tensor
+        MSAU_CHECK_ARG(msau_ownerconv_takes(dtype, d), "conv2d: MSAU_CONV_OWNER is the 3x3 stride-1 C -> 8 conv, no other flag but RELU_OUT");
+        return msau_ownerconv_fwd(static_cast<hipStream_t>(stream), dtype, d);
+    }
     ConvGeom g; TileGeom t; int PT; int64_t nb;
     int rc = conv_plan(dtype, d, &g, &t, &PT, &nb);
     if (rc) return rc;

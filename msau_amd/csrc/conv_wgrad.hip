@@ -311,6 +311,8 @@ extern "C" int msau_conv2d_wgrad(void* stream, int dtype, const msau_wgrad_desc*
     WGeom g;
     int rc = wgrad_geom(dtype, d, &g);
     if (rc) return rc;
+    if (d->flags & MSAU_CONV_OWNER)                                            // ownerconv.hip: per-box sums of g instead of a painted input tensor
+        return msau_ownerconv_wgrad(static_cast<hipStream_t>(stream), dtype, d, g.cch, g.nchunks, g.kextc);
     const int tiles_x = cdiv(d->Wout, 16), tiles_y = cdiv(d->Hout, 16), ntiles = d->B * tiles_x * tiles_y;
     MSAU_CHECK_ARG(d->nslabs >= 1 && d->nslabs <= ntiles, "wgrad: nslabs %d not in [1,%d]", d->nslabs, ntiles);
     if (msau_rowwgrad_takes(dtype, d, g.cch, g.nchunks, g.kextc))              // conv_rows.hip: every row of x and g read once
@@ -342,6 +344,8 @@ extern "C" int msau_conv2d_wgrad(void* stream, int dtype, const msau_wgrad_desc*
 }
 
 // ---- grouped launch: up to 4 weight gradients of one shape in one grid (include/msau_hip.h)
+extern "C" int msau_owner_slabs(const msau_wgrad_desc* d) { return d ? msau_ownerconv_slabs(d) : 0; }
+
 extern "C" int msau_conv2d_wgrad_groupable(int dtype, const msau_wgrad_desc* a, const msau_wgrad_desc* b) {
     if (!a || !b) return 0;
     WGeom g;

@@ -19,6 +19,11 @@ int msau_set_error(int code, const char* fmt, ...);
 // conv_rows.hip: the row-streaming form of msau_conv_pair for the 8-channel bf16 layers (dispatched from conv_pair.hip)
 int msau_rowpair_takes(int dtype, const msau_conv_pair_desc* d);
 int64_t msau_rowpair_plane_bytes(const msau_conv_pair_desc* d);
+// ownerconv.hip: the first conv fed with box lists (MSAU_CONV_OWNER)
+int msau_ownerconv_takes(int dtype, const msau_conv_desc* d);
+int msau_ownerconv_fwd(hipStream_t s, int dtype, const msau_conv_desc* d);
+int msau_ownerconv_wgrad(hipStream_t s, int dtype, const msau_wgrad_desc* d, int cch, int nchunks, int kext);
+int msau_ownerconv_slabs(const msau_wgrad_desc* d);
 int msau_rowpair_workgroups(const msau_conv_pair_desc* d);
 int msau_rowpair_launch(hipStream_t s, const msau_conv_pair_desc* d);
 // ... and of msau_conv2d for the single convolutions of the 8-channel level (dispatched from conv.hip)

@@ -14,7 +14,7 @@ int msau_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* msau_last_error(void) { return g_err; }
-extern "C" int msau_version(void) { return 4; }
+extern "C" int msau_version(void) { return 5; }
 
 // sizeof() of every struct that crosses the ABI by pointer, so that a binding can check its mirror (tests/test_host_cpu.py)
 extern "C" int msau_sizeof(int which) {
@@ -34,6 +34,7 @@ extern "C" int msau_sizeof(int which) {
         case 12: return (int)sizeof(msau_conv_pair_desc);
         case 13: return (int)sizeof(msau_box_args);
         case 14: return (int)sizeof(msau_allreduce_args);
+        case 15: return (int)sizeof(msau_owner_ctx);
         default: return -1;
     }
 }

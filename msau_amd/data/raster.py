@@ -75,6 +75,28 @@ def rasterize(char_boxes, label_boxes, B: int, H: int, W: int, C: int,
     return grid, labels
 
 
+def owner_maps(feat_boxes, label_boxes, B: int, H: int, W: int, device="cuda"):
+    """-> (owner int32 [B,H,W]: index of the feature box that owns each pixel, -1 = none; the feature boxes as a device
+    tensor [n,6] (or None) and n; labels int64 [B,H,W]).  What the dense painters start from -- and all that the net's first
+    conv needs when it is fed with box lists (MSAU_CONV_OWNER, csrc/ownerconv.hip): the grid itself is never painted."""
+    dev = torch.device(device)
+    if dev.index is None and dev.type == "cuda":
+        dev = torch.device("cuda", torch.cuda.current_device())
+    s = torch.cuda.current_stream(dev).cuda_stream
+    owner = torch.empty((B, H, W), dtype=torch.int32, device=dev)
+    lown = torch.empty((B, H, W), dtype=torch.int32, device=dev)
+    labels = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    fb, nf = _dev_boxes(feat_boxes, dev)
+    lb, nl = _dev_boxes(label_boxes, dev)
+    L.call("msau_raster_owner", s, fb.data_ptr() if nf else None, nf, owner.data_ptr(), B, H, W)
+    L.call("msau_raster_owner", s, lb.data_ptr() if nl else None, nl, lown.data_ptr(), B, H, W)
+    L.call("msau_raster_labels", s, lb.data_ptr() if nl else None, lown.data_ptr(), labels.data_ptr(), B, H, W)
+    for t in (fb, lb, lown):
+        if t is not None:
+            t.record_stream(torch.cuda.current_stream(dev))
+    return owner, fb, nf, labels
+
+
 def document_line_boxes(doc: dict, sample: int = 0, feat_base: int = 0):
     """-> (feature boxes [n,6] with value = feat_base + line index, label boxes [n,6], H, W) for the dense (BERT) painter
     `funsd.get_box_mask_box_label`: both the feature vectors and the labels cover the text-LINE boxes"""

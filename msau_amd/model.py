@@ -17,6 +17,8 @@ import os
 import weakref
 
 import math
+
+import numpy as np
 from collections import OrderedDict
 from typing import Dict, Optional, Tuple
 
@@ -532,8 +534,8 @@ class TrainEngine:
         weakref.finalize(self, L.load().msau_comm_destroy, self._comm)
 
     # -- pieces (each is a fixed launch sequence on the current stream) --
-    def _fwd_bwd(self, plan: Plan, x, labels, ids=None, nhwc_ready=False):
-        plan.forward(self.model._flat, x, export=False, ids=ids, nhwc_ready=nhwc_ready)
+    def _fwd_bwd(self, plan: Plan, x, labels, ids=None, nhwc_ready=False, owner=None):
+        plan.forward(self.model._flat, x, export=False, ids=ids, nhwc_ready=nhwc_ready, owner=owner)
         loss = plan.loss_grads(labels)
         # MSAU_DP_BUCKETS=1: ONE all-reduce of the whole flat gradient after the backward instead of a bucket per stage
         # issued while the earlier stages' backward still runs (fewer launches and joins, no overlap)
@@ -662,6 +664,17 @@ class TrainEngine:
         = row of feats) and the label mask are painted on the device, the grid straight into the plan's input buffer.
         Only the lists (KBs) and the feature table cross PCIe.  Arguments may be numpy arrays or device tensors."""
         from .data import raster
+        plan = self.model._plan_for_shape(B, H, W, self.model._flat.device, True)
+        if feats is not None and not self.use_graph and plan._feed_owner(None):
+            # the embedding grid is piecewise constant: the first conv and its weight gradient work from the per-pixel box index
+            # and the feature table (MSAU_CONV_OWNER, csrc/ownerconv.hip) -- the 1536-bytes-per-pixel tensor is never painted
+            dev = self.model._flat.device
+            ft = feats if isinstance(feats, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(feats, dtype=np.float32)).to(dev)
+            owner, fb, nf, labels = raster.owner_maps(grid_boxes, label_boxes, B, H, W, dev)
+            loss = self._fwd_bwd(plan, None, labels, owner=(owner, fb, nf, ft))
+            self._allreduce()
+            self._optim()
+            return loss
         buf = self.input_nhwc(B, H, W)
         if feats is None:
             _, labels = raster.rasterize(grid_boxes, label_boxes, B, H, W, self.model.channels, self.model.dtype_name, buf.device, out=buf)

@@ -1417,6 +1417,69 @@ class Plan:
             self._ids_keep = None
         return True
 
+    def _feed_owner(self, src, flat_params: Optional[torch.Tensor] = None) -> bool:
+        """Switch the net's first conv (and its weight gradient) between the painted input tensor and BOX LISTS
+        (MSAU_CONV_OWNER, csrc/ownerconv.hip): `src` = (owner int32 [B,H,W], boxes int32 [n,6] device tensor or None, n, feats
+        fp32 [n_vec, C] device tensor) or None.  Returns False when no instance takes the conv (paint the tensor instead)."""
+        if not hasattr(self, "_owner_conv"):
+            c = next((op for op in self.ops if isinstance(op, ConvOp) and op.x1 is self.x_in and op.x2 is None), None)
+            ok = c is not None and os.environ.get("MSAU_OWNER_CONV", "1") != "0" and not (c.pair is not None and c.pair.active) \
+                and not (c.fdesc.flags & ~L.CONV_RELU_OUT)
+            if ok:
+                info = (L.i32 * 8)()
+                L.call("msau_conv2d_launch_info", self.dtype, C.byref(c.fdesc), info)
+                ok = bool(info[7] & 32)
+            if ok and self.training and c.wdesc is not None:
+                ok = c.wdesc.flags == 0 and c.uentry is not None and c.kind == "conv"
+            self._owner_conv = c if ok else None
+            self._owner_keep = None
+            self._owner_slabs = None
+        c = self._owner_conv
+        if c is None:
+            return False
+        if src is None:
+            if self._owner_keep is not None:
+                c.fdesc.flags &= ~L.CONV_OWNER
+                c.fdesc.x1 = _ptr(self.x_in.data)
+                if c.wdesc is not None:
+                    c.wdesc.flags &= ~L.CONV_OWNER
+                    c.wdesc.x1 = _ptr(self.x_in.data)
+                    self._set_unpack_slabs(c, c.wdesc.nslabs)
+                self._owner_keep = None
+            return True
+        owner, boxes, n_boxes, feats = src
+        assert owner.dtype == torch.int32 and owner.is_contiguous() and tuple(owner.shape) == (self.B, self.H, self.W)
+        assert feats.dtype == torch.float32 and feats.is_contiguous() and feats.dim() == 2 and int(feats.shape[1]) == self.x_in.C, feats.shape
+        self._feed_ids(None)
+        n_vec = int(feats.shape[0])
+        ctx = L.OwnerCtx()
+        blocks = max(1, min(256, c.out.npix // 1024))
+        wt = torch.empty((max(self.x_in.C, 32) * 72,), dtype=torch.float32, device=self.device)
+        table = torch.empty((max(n_vec, 1) * 72,), dtype=torch.float32, device=self.device)
+        sums = torch.empty((max(n_boxes, 1) * 72,), dtype=torch.float32, device=self.device)
+        csum = torch.empty((blocks * 8,), dtype=torch.float32, device=self.device)
+        ctx.owner, ctx.boxes, ctx.feats = owner.data_ptr(), (boxes.data_ptr() if n_boxes else None), feats.data_ptr()
+        ctx.w = flat_params.data_ptr() + 4 * self.poff[c.wname]
+        ctx.wt, ctx.table, ctx.sums, ctx.csum = wt.data_ptr(), table.data_ptr(), sums.data_ptr(), csum.data_ptr()
+        ctx.n_boxes, ctx.n_vec, ctx.C, ctx.csum_blocks = n_boxes, n_vec, self.x_in.C, blocks
+        c.fdesc.flags |= L.CONV_OWNER
+        c.fdesc.x1 = C.addressof(ctx)
+        if c.wdesc is not None:
+            c.wdesc.flags |= L.CONV_OWNER
+            c.wdesc.x1 = C.addressof(ctx)
+            self._set_unpack_slabs(c, int(L.load().msau_owner_slabs(C.byref(c.wdesc))))     # the slabs the box-list weight gradient writes
+        self._owner_keep = (ctx, owner, boxes, feats, wt, table, sums, csum, flat_params)  # read again by the backward
+        return True
+
+    def _set_unpack_slabs(self, c: "ConvOp", n: int):
+        """patch the slab count of a conv's entry in the device-side reduction table"""
+        if self._owner_slabs == n or self.unpack_table is None:
+            return
+        idx = next(i for i, e in enumerate(self._unpack_entries) if e is c.uentry)
+        off = idx * C.sizeof(L.UnpackEntry) + L.UnpackEntry.nslabs.offset
+        self.unpack_table[off:off + 4].copy_(torch.tensor([n], dtype=torch.int32).view(torch.uint8))
+        self._owner_slabs = n
+
     def load_ids(self, ids: torch.Tensor):
         """Paint the one-hot input from a character-id mask int32 [B,H,W] (to_categorical, generic_util.py:97-98):
         H*W*4 bytes cross PCIe instead of the dense H*W*C float grid."""
@@ -1477,12 +1540,21 @@ class Plan:
         return self.x_in.data
 
     def forward(self, flat_params: torch.Tensor, x_nchw: Optional[torch.Tensor], export: bool = True,
-                ids: Optional[torch.Tensor] = None, nhwc_ready: bool = False):
+                ids: Optional[torch.Tensor] = None, nhwc_ready: bool = False, owner=None):
         """`ids` (int32 [B,H,W] character ids, -1 = empty) instead of `x_nchw`: the one-hot grid is painted on the device.
         `nhwc_ready`: the input buffer (`input_nhwc`) already holds the grid -- no boundary conversion at all."""
         s = self._stream()
         self.pack(flat_params)
-        if nhwc_ready:
+        if owner is not None:
+            # box lists instead of a painted input (`owner` as Plan._feed_owner takes it); the caller checked that an instance exists
+            assert x_nchw is None and ids is None and not nhwc_ready
+            ok = self._feed_owner(owner, flat_params)
+            assert ok, "no MSAU_CONV_OWNER instance for this plan's first conv"
+        elif getattr(self, "_owner_keep", None) is not None:
+            self._feed_owner(None)
+        if owner is not None:
+            pass
+        elif nhwc_ready:
             assert x_nchw is None and ids is None
             self._feed_ids(None)
         elif ids is not None:

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from msau_amd.model import MSAUWrapper, TrainEngine
-from tests.golden_util import GOLDEN, load_net_case, rel_err, rel_l2, summarize
+from tests.golden_util import GOLDEN, err, load_net_case, rel_err, rel_l2, summarize
 
 pytestmark = pytest.mark.gpu
 
@@ -319,12 +319,13 @@ def test_device_dense_rasteriser_matches_cpu_painter(dtype, tmp_path):
 
 
 @pytest.mark.parametrize("dtype,dense", [("fp32", True), ("bf16", True), ("bf16", False)])
-def test_training_from_box_lists_equals_the_step_on_the_painted_tensor(dtype, dense):
+def test_training_from_box_lists_equals_the_step_on_the_painted_tensor(dtype, dense, monkeypatch):
     """TrainEngine.step_boxes / step_nhwc (N1; data_generator_funsd_bert.py:64-93,240): the box lists are painted on the device
     straight into the plan's NHWC input buffer -- no fp32 NCHW tensor, no boundary conversion -- against TrainEngine.step on
     the same grid handed over as the reference does (float [B,C,H,W]): every bit of loss, gradient and updated parameters.
     dense: 24-d feature vectors per line box (the BERT painter); else one-hot character ids."""
     from msau_amd.data.raster import rasterize, rasterize_dense
+    monkeypatch.setenv("MSAU_OWNER_CONV", "0")             # the PAINTED path (the box-list-fed first conv has its own test below)
     torch.manual_seed(3)
     B, H, W, C, ncls = 3, 40, 56, 24, 5
     rng = np.random.default_rng(11)
@@ -420,10 +421,11 @@ def test_train_step_is_bit_reproducible_beside_the_side_stream():
 
 
 @pytest.mark.parametrize("dense", [True, False])
-def test_prefetched_box_batches_train_exactly_like_step_boxes(dense):
+def test_prefetched_box_batches_train_exactly_like_step_boxes(dense, monkeypatch):
     """TrainEngine.prefetch_boxes / step_prefetched: the next batch is painted into the plan's SECOND input buffer on the side
     stream while the current step runs.  A sequence of DIFFERENT batches (so a stale or swapped buffer would show) must give
     the losses, gradients and parameters of the same batches through step_boxes, bit for bit."""
+    monkeypatch.setenv("MSAU_OWNER_CONV", "0")             # both sides PAINT the grid (step_boxes would otherwise feed the box lists)
     torch.manual_seed(3)
     B, H, W, C, ncls = 3, 40, 56, 24, 5
     rng = np.random.default_rng(12)
@@ -462,3 +464,51 @@ def test_prefetched_box_batches_train_exactly_like_step_boxes(dense):
         res[mode] = (losses, eng.flat_grad.clone(), m.flat_parameters.clone())
     assert res["prefetch"][0] == res["plain"][0], (res["prefetch"][0], res["plain"][0])
     assert torch.equal(res["prefetch"][1], res["plain"][1]) and torch.equal(res["prefetch"][2], res["plain"][2])
+
+
+@pytest.mark.parametrize("dtype,C", [("fp32", 24), ("bf16", 24), ("bf16", 100)])
+def test_first_conv_fed_with_box_lists_matches_the_painted_grid(dtype, C, monkeypatch):
+    """MSAU_CONV_OWNER (csrc/ownerconv.hip): TrainEngine.step_boxes with a feature table never paints the embedding grid -- the
+    first conv gathers per-tap partial products T[feature row][tap][co], its weight gradient sums the output gradient per box
+    and tap -- against the same steps on the painted tensor (MSAU_OWNER_CONV=0).  Same rounded operands, fp32 sums in another
+    order: losses, the first conv's weight and bias gradient, the whole gradient and the updated parameters agree to rounding.
+    Overlapping boxes (the last one painted owns the pixel), boxes over the edge, an empty sample, a feature row used twice."""
+    torch.manual_seed(3)
+    B, H, W, ncls = 4, 40, 56, 5
+    rng = np.random.default_rng(21)
+    boxes, labs = [], []
+    for b in range(B - 1):                                  # the last sample stays empty
+        for i in range(16):
+            y0, x0 = int(rng.integers(0, H - 4)), int(rng.integers(0, W - 6))
+            y1, x1 = y0 + int(rng.integers(1, 6)), x0 + int(rng.integers(2, 14))
+            boxes.append((b, y0, y1, x0, x1, len(boxes) if i else 0))          # feature row 0 is shared by three boxes
+            labs.append((b, y0, y1, x0, x1, int(rng.integers(1, ncls))))
+    boxes, labs = np.asarray(boxes, np.int32), np.asarray(labs, np.int32)
+    feats = rng.standard_normal((len(boxes), C)).astype(np.float32)
+    kw = dict(scale_space_num=3, res_depth=2, featRoot=8, final_act="softmax", num_blocks=2, dtype=dtype, seed=4, deterministic=True)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MSAU_OWNER_CONV", mode)
+        m = MSAUWrapper(C, ncls, kw).cuda()
+        eng = TrainEngine(m)
+        losses = [float(eng.step_boxes(boxes, labs, B, H, W, feats=feats)) for _ in range(3)]
+        torch.cuda.synchronize()
+        plan = m._plan_for_shape(B, H, W, torch.device("cuda", 0), True)
+        assert (getattr(plan, "_owner_keep", None) is not None) == (mode == "1")
+        c = next(op for op in plan.ops if getattr(op, "x1", None) is plan.x_in)
+        wo, bo, n = plan.poff[c.wname], plan.poff[c.bname], int(np.prod(plan.pshape[c.wname]))
+        g = eng.flat_grad.float().cpu()
+        res[mode] = (losses, g, m.flat_parameters.float().cpu(), g[wo:wo + n].clone(), g[bo:bo + 8].clone())
+    tol = 2e-2 if dtype == "bf16" else 2e-4
+    for a, b in zip(res["1"][0], res["0"][0]):
+        assert abs(a - b) < (2e-3 if dtype == "bf16" else 1e-5) * abs(b), (res["1"][0], res["0"][0])
+    assert float(res["0"][3].abs().max()) > 0 and err(res["1"][3], res["0"][3], True) < tol
+    assert float(res["0"][4].abs().max()) > 0 and err(res["1"][4], res["0"][4], True) < tol
+    assert err(res["1"][1], res["0"][1], True) < tol
+    assert err(res["1"][2], res["0"][2], True) < (1e-3 if dtype == "bf16" else 1e-5)
+    # and a step on a painted tensor afterwards goes back to the tensor-fed launches
+    monkeypatch.setenv("MSAU_OWNER_CONV", "1")
+    x = torch.randn(B, C, H, W, device="cuda")
+    lab = torch.randint(0, ncls, (B, H, W), device="cuda")
+    l0 = float(eng.step(x, lab))
+    assert np.isfinite(l0)
