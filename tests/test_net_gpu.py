@@ -408,7 +408,18 @@ def test_fused_residual_pair_is_bit_identical_to_two_launches(monkeypatch, dtype
             assert {8, 16} <= widths or (channels == 8 and 8 in widths), widths
         else:
             assert n_act == 0
-        acts = {a.name: (a.data.clone(), a.grad.clone() if a.grad is not None else None) for a in plan.acts}
+        # gradients the fused launches no longer materialise: of the block's input when the LRN backward rides on the launch
+        # (MSAU_PAIR_LRN_BWD writes the gradient of the LRN's INPUT instead), of the block's inner tensor when the first conv's
+        # weight gradient does (MSAU_PAIR_WGRAD1: consumed from LDS)
+        gone = set()
+        for pr in plan.pairs:
+            if pr.active and pr.bdesc is not None:
+                lrn = getattr(pr.c1.x1, "lrn_producer", None)
+                if lrn is not None and lrn.bwd_fused_into is pr:
+                    gone.add(pr.c1.x1.name)
+                if pr.c1.wg_fused:
+                    gone.add(pr.c1.out.name)
+        acts = {a.name: (a.data.clone(), a.grad.clone() if (a.grad is not None and a.name not in gone) else None) for a in plan.acts}
         with torch.no_grad():
             pred = m.predict_nhwc(x)[0].clone()             # forward-only plan (buffer reuse) takes the fused path too
         outs.append((float(loss), eng.flat_grad.clone(), m.flat_parameters.clone(), acts, pred))
@@ -428,7 +439,7 @@ def test_fused_residual_pair_is_bit_identical_to_two_launches(monkeypatch, dtype
             assert torch.equal(a1[name][0], a0[name][0]), ("activation", name)
         else:
             assert err(a1[name][0].float().cpu(), a0[name][0].float().cpu(), True) < 5e-2, ("activation", name)
-        if a0[name][1] is not None:
+        if a0[name][1] is not None and a1[name][1] is not None:
             if exact:
                 assert torch.equal(a1[name][1], a0[name][1]), ("gradient", name)
             else:
