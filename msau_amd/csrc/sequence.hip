@@ -3,7 +3,12 @@
 // step is then a handful of C calls instead of ~450 Python -> ctypes round trips.
 #include "msau_common.h"
 
+#include <condition_variable>
 #include <cstdlib>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -69,6 +74,73 @@ extern "C" int msau_probe_read(float* us, int cap, int* n) {
     return 0;
 }
 
+// ---- a second host thread for the side stream's launches -----------------------------------------------------------------
+// A sweep of small images (the reference trains batch 1, a shape per document: tools/funsd_loop.py) is bound by the HOST: ~320
+// launches at ~4.4 us of hipLaunchKernel each, one thread.  The side stream's ~90 launches need nothing from the calling thread
+// but the event they wait for, so a worker thread (one per calling thread, started on first use) enqueues them while the caller
+// goes on with the main stream.  Results cannot change: stream order and event dependencies are what they were.  The caller
+// drains the worker wherever it needs the side stream's tail (join, comm fork, end of the call).  MSAU_SIDE_THREAD=1 turns it on
+// (off by default: see the measurement at its use).
+namespace {
+struct SideWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv, cv_done;
+    std::deque<std::function<int()>> q;
+    bool stop = false;
+    int pending = 0, rc = 0, dev = 0;
+    char err[512] = "";
+    void run() {
+        (void)hipSetDevice(dev);
+        for (;;) {
+            std::function<int()> f;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                f = std::move(q.front());
+                q.pop_front();
+            }
+            const int r = f();
+            std::lock_guard<std::mutex> lk(m);
+            if (r && !rc) { rc = r; snprintf(err, sizeof(err), "%s", msau_last_error()); }
+            if (--pending == 0) cv_done.notify_all();
+        }
+    }
+    void push(std::function<int()> f) {
+        std::lock_guard<std::mutex> lk(m);
+        q.push_back(std::move(f));
+        ++pending;
+        cv.notify_one();
+    }
+    int drain() {
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return pending == 0; });
+        const int r = rc;
+        rc = 0;
+        if (r) return msau_set_error(r, "%s", err);
+        return 0;
+    }
+    ~SideWorker() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+            cv.notify_one();
+        }
+        if (th.joinable()) th.join();
+    }
+};
+SideWorker* side_worker() {
+    static thread_local SideWorker* w = nullptr;                // leaked on purpose at process exit: no HIP calls from static destructors
+    if (!w) {
+        w = new SideWorker();
+        (void)hipGetDevice(&w->dev);
+        w->th = std::thread([p = w] { p->run(); });
+    }
+    return w;
+}
+}  // namespace
+
 extern "C" int msau_run_ops(void* stream, const msau_op* ops, int n) {
     MSAU_CHECK_ARG(ops || n == 0, "run_ops: null list");
     for (int i = 0; i < n; ++i) {
@@ -118,6 +190,16 @@ extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_strea
     hipStream_t s2 = side2_on ? side2 : nullptr;
     bool s2_open = false;                                      // work on s2 that ss has not been ordered behind yet
     unsigned turn = 0;
+    // measured 2026-10-04: NO gain -- tools/funsd_loop.py 661.9 -> 659.3 docs/s with identical host time per step (1.377 ms), the
+    // batch-16 step 3.234 -> 3.241 ms: two threads launching into two streams of one device take turns in the runtime.  Off by default.
+    static const int thread_on = std::getenv("MSAU_SIDE_THREAD") ? atoi(std::getenv("MSAU_SIDE_THREAD")) : 0;
+    bool any_probe = false;
+    for (int i = 0; i < n; ++i) any_probe = any_probe || (ops[i].kind & MSAU_OP_PROBE);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(ms, &cap);                      // a sweep being captured into a graph stays on one thread
+    SideWorker* worker = (thread_on && !s2 && !any_probe && cap == hipStreamCaptureStatusNone) ? side_worker() : nullptr;     // (probe events live in the caller's thread)
+    auto drain = [&]() -> int { return worker ? worker->drain() : 0; };
+    struct DrainGuard { SideWorker* w; ~DrainGuard() { if (w) (void)w->drain(); } } drain_guard{worker};     // every return path: the op list is the caller's again
     auto close_s2 = [&]() -> int {
         if (!s2_open) return 0;
         hipEvent_t ev;
@@ -133,11 +215,44 @@ extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_strea
         hipEvent_t ev;
         int rc = next_event(&ev);
         if (rc) return rc;
-        if (hipEventRecord(ev, ms) != hipSuccess || hipStreamWaitEvent(ss, ev, 0) != hipSuccess ||
-            (s2 && hipStreamWaitEvent(s2, ev, 0) != hipSuccess))
-            return msau_set_error(MSAU_ERR_HIP, "run_ops_overlap: fork failed");
+        if (hipEventRecord(ev, ms) != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "run_ops_overlap: fork failed");
         // weight gradients of one shape released together share a grid (msau_conv2d_wgrad_group)
         static const bool group_off = std::getenv("MSAU_WGRAD_GROUP") && std::getenv("MSAU_WGRAD_GROUP")[0] == '0';
+        if (worker) {
+            // the worker thread waits for the fork and enqueues the batch; this thread goes on with the main stream
+            worker->push([ss, side_stream, ev, batch = std::move(pending)]() -> int {
+                if (hipStreamWaitEvent(ss, ev, 0) != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "run_ops_overlap: fork failed");
+                std::vector<char> done(batch.size(), 0);
+                for (size_t i = 0; i < batch.size(); ++i) {
+                    if (done[i]) continue;
+                    const msau_op& o = batch[i].first;
+                    if (!group_off && o.kind == MSAU_OP_WGRAD) {
+                        const msau_wgrad_desc* ds[4] = {static_cast<const msau_wgrad_desc*>(o.args), nullptr, nullptr, nullptr};
+                        int n = 1;
+                        for (size_t j = i + 1; j < batch.size() && n < 4; ++j) {
+                            const msau_op& p = batch[j].first;
+                            if (done[j] || p.kind != MSAU_OP_WGRAD || p.dtype != o.dtype) continue;
+                            if (!msau_conv2d_wgrad_groupable(o.dtype, ds[0], static_cast<const msau_wgrad_desc*>(p.args))) continue;
+                            ds[n++] = static_cast<const msau_wgrad_desc*>(p.args);
+                            done[j] = 1;
+                        }
+                        if (n > 1) {
+                            const int rc = msau_conv2d_wgrad_group(side_stream, o.dtype, ds, n);
+                            if (rc) return rc;
+                            continue;
+                        }
+                    }
+                    const int rc = run_one(side_stream, o, batch[i].second);
+                    if (rc) return rc;
+                }
+                return 0;
+            });
+            pending.clear();
+            any_side = true;
+            return 0;
+        }
+        if (hipStreamWaitEvent(ss, ev, 0) != hipSuccess || (s2 && hipStreamWaitEvent(s2, ev, 0) != hipSuccess))
+            return msau_set_error(MSAU_ERR_HIP, "run_ops_overlap: fork failed");
         std::vector<char> done(pending.size(), 0);
         for (size_t i = 0; i < pending.size(); ++i) {
             if (done[i]) continue;
@@ -176,7 +291,9 @@ extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_strea
     };
     auto join_side = [&]() -> int {
         hipEvent_t ev;
-        int rc = close_s2();
+        int rc = drain();                                        // everything released so far is enqueued on the side stream
+        if (rc) return rc;
+        rc = close_s2();
         if (rc) return rc;
         rc = next_event(&ev);
         if (rc) return rc;
@@ -212,6 +329,8 @@ extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_strea
             // that completed it) and on the main stream, on a stream of its own; the sweep goes on
             if (!cs) return msau_set_error(MSAU_ERR_ARG, "run_ops_dp: op %d needs the comm stream", i);
             int rc = flush();
+            if (rc) return rc;
+            rc = drain();
             if (rc) return rc;
             rc = close_s2();
             if (rc) return rc;
@@ -251,6 +370,8 @@ extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_strea
     }
     {
         int rc = flush();
+        if (rc) return rc;
+        rc = drain();                                            // the op list and the descriptors belong to the caller again after this call
         if (rc) return rc;
         rc = close_s2();
         if (rc) return rc;
