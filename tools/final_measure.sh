@@ -16,4 +16,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -o r03 -- pyth
 MSAU_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_serial" -o r03s -- python3 "$R/bench.py" --no-secondary --no-cpu-baseline --no-roofline --steps 30 --warmup 10 > "$O/prof_serial.log" 2>&1 || { tail -5 "$O/prof_serial.log"; exit 1; }
 find "$O/prof" "$O/prof_serial" -name "*kernel_trace.csv" -delete        # large; the stats are what is kept
 cd "$R"
-ls -R "$O" | head -40
+ls "$O"

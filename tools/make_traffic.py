@@ -13,6 +13,7 @@ import csv
 import glob
 import json
 import os
+import re
 import subprocess
 import sys
 
@@ -70,23 +71,45 @@ def main():
     # ---- the residual pair at level 0 / 1 (row-streaming kernels): forward launch and data-gradient launch
     for c, tag in ((8, "C8"), (16, "C16")):
         res = passes(f"pair{c}", ["python3", os.path.join(tools, "pair_bench.py"), "3", str(c)])
-        fw = [n for n in res["FETCH_SIZE"] if f"rowpair_c{c}_kernel<false" in n or f"rowpair_c{c}_kernelILb0" in n]
-        bw = [n for n in res["FETCH_SIZE"] if f"rowpair_c{c}_kernel<true" in n or f"rowpair_c{c}_kernelILb1" in n]
-        assert len(fw) == 1 and len(bw) == 1, (fw, bw, list(res["FETCH_SIZE"]))
+        def targs(n):
+            """template arguments of a rowpair kernel name, mangled or demangled, as a tuple of 0/1"""
+            m = re.search(r"rowpair_c\d+_kernelI((?:Lb[01]E)+)E", n)
+            if m:
+                return tuple(int(x) for x in re.findall(r"Lb([01])E", m.group(1)))
+            m = re.search(r"rowpair_c\d+_kernel<([^>]*)>", n)
+            return tuple(1 if t.strip() in ("true", "1") else 0 for t in m.group(1).split(",")) if m else ()
+        names = [n for n in res["FETCH_SIZE"] if f"rowpair_c{c}_kernel" in n]
+        fw = [n for n in names if targs(n)[0] == 0]
+        bw = [n for n in names if targs(n)[0] == 1 and not any(targs(n)[2:] if c == 8 else ())]     # the plain data-gradient launch
+        assert len(fw) == 1 and len(bw) == 1, (fw, bw, names)
         nt = n8 if c == 8 else n8 // 2                          # 16 channels at half the resolution: half the bytes
         planes = 2 * B * (H if c == 8 else H // 2) * -(-(W if c == 8 else W // 2) // (30 if c == 8 else 14)) * 32
         fwd = avg_entry(res, fw, f"residual pair forward (x0 -> r1, out, two ballot planes), B=16 C={c}", 3 * nt + planes)
         bwd = avg_entry(res, bw, f"residual pair data gradient (g + two ballot planes -> g_r1, g_x0), B=16 C={c}", 3 * nt + planes)
-        kernels[f"rowpair_kernel<bf16,{tag}>"] = {
-            "launch": f"mean of the forward and the data-gradient launch (6 each per step), B=16 C={c}", "mangled": fwd["mangled"] + " | " + bwd["mangled"],
-            "hbm_bytes_per_launch": (fwd["hbm_bytes_per_launch"] + bwd["hbm_bytes_per_launch"]) // 2,
-            "alg_bytes_of_measured_launch": (fwd["alg_bytes_of_measured_launch"] + bwd["alg_bytes_of_measured_launch"]) // 2,
-            "forward": fwd, "backward": bwd, "git_sha": sha}
+        ent = {"forward": fwd, "backward": bwd, "git_sha": sha}
+        parts = [(fwd, 6), (bwd, 6)]
+        if c == 8:
+            # the launches the step actually runs at 8 channels: the first conv's weight gradient rides on every data-gradient launch
+            # (x0 read, the intermediate gradient not written, one slab per workgroup), the LRN backward on the encoder block's (a read,
+            # da written instead of dx)
+            slabs = 768 * 8 * 80 * 4
+            wg1 = [n for n in names if targs(n) == (1, 1, 0, 1)]
+            both = [n for n in names if targs(n) == (1, 1, 1, 1)]
+            if len(wg1) == 1 and len(both) == 1:
+                ent["backward_wgrad1"] = avg_entry(res, wg1, "data gradient + first conv's weight gradient (g, x0, planes -> g_x0, slabs), B=16 C=8", 3 * nt + planes + slabs)
+                ent["backward_lrn_wgrad1"] = avg_entry(res, both, "data gradient + LRN backward + first conv's weight gradient (g, x0, a, planes -> da, slabs), B=16 C=8", 4 * nt + planes + slabs)
+                parts = [(fwd, 6), (ent["backward_wgrad1"], 3), (ent["backward_lrn_wgrad1"], 3)]
+        tot = sum(k for _, k in parts)
+        ent.update({"launch": f"mean over the step's {tot} launches ({', '.join(str(k) + ' x ' + e['launch'].split(' (')[0] for e, k in parts)}), B=16 C={c}",
+                    "mangled": " | ".join(e["mangled"] for e, _ in parts),
+                    "hbm_bytes_per_launch": sum(e["hbm_bytes_per_launch"] * k for e, k in parts) // tot,
+                    "alg_bytes_of_measured_launch": sum(e["alg_bytes_of_measured_launch"] * k for e, k in parts) // tot})
+        kernels[f"rowpair_kernel<bf16,{tag}>"] = ent
     # ---- 8 -> 8 3x3 at level 0: forward (row-streaming), data gradient (tile kernel), weight gradient
     res = passes("l0", ["python3", os.path.join(tools, "kbench.py"), "--only", "L0 8->8", "--iters", "3"])
     names = list(res["FETCH_SIZE"])
     rc = [n for n in names if "rowconv8_kernel" in n]
-    wg = [n for n in names if "wgrad_lean_kernel" in n]
+    wg = [n for n in names if "rowwgrad8_kernel" in n] or [n for n in names if "wgrad_lean_kernel" in n]
     if rc:
         e = avg_entry(res, rc[:1], "rowconv8 plain forward 8 -> 8 3x3 (bias only), B=16 336x256", 2 * n8)
         e["git_sha"] = sha
@@ -94,14 +117,13 @@ def main():
     if wg:
         e = avg_entry(res, wg[:1], "weight gradient 8 -> 8 3x3 (x, g read once; slabs written), B=16 336x256", 2 * n8)
         e["git_sha"] = sha
-        kernels["wgrad_lean_kernel<bf16,C8,CO8,K3>"] = e
+        kernels["rowwgrad_kernel<bf16,C8,CO8,K3>" if "rowwgrad8_kernel" in wg[0] else "wgrad_lean_kernel<bf16,C8,CO8,K3>"] = e
     # ---- the normalisation / pooling / boundary passes (tools/norm_bench.py: one launch of each per iteration, fixed order)
     sys.path.insert(0, tools)
     res = passes("norm", ["python3", os.path.join(tools, "norm_bench.py"), "3"])
     fams = {"lrn_fwd": ("lrn_fast_kernel", False), "lrn_bwd": ("lrn_fast_kernel", True), "pool_fwd": ("pool_fwd_kernel", None),
             "pool_bwd": ("pool_bwd_kernel", None), "msau_nchw_to_nhwc": ("nchw_to_nhwc", None)}
     # per-dispatch rows in launch order: norm_bench launches (3 warm-up + 3 timed) x each op, op after op
-    import re
     order = [("lrn_fwd<bf16,C8>", 2 * n8), ("lrn_bwd<bf16,C8>", 3 * n8), ("pool_fwd<bf16,C8>", n8 + n8 // 4 + n8 // 8), ("pool_bwd<bf16,C8>", n8 + n8 // 4 + n8 // 8),
              ("lrn_fwd<bf16,C16>", n8), ("lrn_bwd<bf16,C16>", 3 * n8 // 2), ("pool_fwd<bf16,C16>", n8 // 2 + n8 // 8 + n8 // 16),
              ("pool_bwd<bf16,C16>", n8 // 2 + n8 // 8 + n8 // 16), ("msau_nchw_to_nhwc", B * 64 * H * W * 6)]
