@@ -1128,8 +1128,8 @@ const RowsEnv& rows_env() {
 // segment height: a wave takes one task; aim for MSAU_ROWS_WAVES tasks in one round, at least 8 rows each.
 int segment_rows(int B, int H, int nstrips, int warm, bool c16 = false) {
     const RowsEnv& e = rows_env();
-    if (c16 && e.sh16 > 0) return e.sh16 < H ? e.sh16 : H;
     if (e.sh > 0) return e.sh < H ? e.sh : H;
+    if (c16 && e.sh16 > 0) return e.sh16 < H ? e.sh16 : H;
     int nseg = e.waves / (B * nstrips);
     if (nseg < 1) nseg = 1;
     int sh = cdiv(H, nseg);
