@@ -341,6 +341,9 @@ class ConvOp(Op):
         w.nslabs = 1
         L.call("msau_wgrad_geometry", P.dtype, C.byref(w), C.byref(wg))
         nslabs = max(1, min(wg.max_slabs, int(os.environ.get('MSAU_SLAB_CAP', '384')), max(64, (int(os.environ.get('MSAU_SLAB_MB', '3')) << 20) // max(wg.slab_bytes, 1))))
+        if conv and x1 is P.x_in and x2 is None and int(os.environ.get('MSAU_SLAB_FIRST', '0')) > 0:
+            # the net's first conv closes the backward sweep ALONE on the device: its workgroup count is what fills the CUs, not a budget
+            nslabs = max(1, min(wg.max_slabs, int(os.environ['MSAU_SLAB_FIRST'])))
         w.nslabs = nslabs
         slab_elems = wg.slab_bytes // 4
         self.slab_off = P.alloc_slab(nslabs * slab_elems)
