@@ -990,9 +990,16 @@ struct RowWgradArgs {
 
 constexpr int WG_WAVES = 8;                                               // waves per workgroup = tasks per slab and round
 
-template <bool RELU_IN>
+// KS = 4 (the end conv, model/model.py:375-376,390; SAME padding 1 before / 2 after): the horizontal taps kx - 1 = -1 .. 2 need a
+// second x fragment two pixels further on (a' = 2: with b = 0 it is kx = 3; its other three quadrants repeat taps and are dropped);
+// an x row serves four output rows.  Slab: [co][(ky * 4 + kx) * 8 + ci], ones column 128, 144 columns.
+template <bool RELU_IN, int KS = 3>
 __global__ __launch_bounds__(64 * WG_WAVES) void rowwgrad8_kernel(const RowWgradArgs a) {
-    __shared__ __align__(16) unsigned char smem[WG_WAVES * 2 * WG_ROW + 8 * 80 * 4];
+    static_assert(KS == 3 || KS == 4, "3x3 and 4x4");
+    constexpr int NF = KS == 4 ? 2 : 1;                                   // x fragments per row
+    constexpr int KEXT = KS == 4 ? 144 : 80, ONESC = KS * KS * 8;
+    constexpr int XL = KS == 4 ? 36 : 34;                                 // lanes that stage x
+    __shared__ __align__(16) unsigned char smem[WG_WAVES * 2 * WG_ROW + 8 * KEXT * 4];
     const msau_wgrad_desc& d = a.d;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1013,7 +1020,11 @@ __global__ __launch_bounds__(64 * WG_WAVES) void rowwgrad8_kernel(const RowWgrad
     };
     const u32x4 ones_bits = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
     const bf16x8 ONES = __builtin_bit_cast(bf16x8, ones_bits);
-    f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accb = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[KS][NF], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc[k][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int gw = blockIdx.x * WG_WAVES + wave, nw = gridDim.x * WG_WAVES;
     for (int task = gw; task < a.ntasks; task += nw) {                    // wave-uniform
@@ -1024,60 +1035,64 @@ __global__ __launch_bounds__(64 * WG_WAVES) void rowwgrad8_kernel(const RowWgrad
         const long long img = (long long)b * a.img_bytes;
         const __amdgpu_buffer_rsrc_t rx = rsrc_of(static_cast<const char*>(d.x1) + img, a.img_bytes);
         const __amdgpu_buffer_rsrc_t rg = rsrc_of(static_cast<const char*>(d.g) + img, a.img_bytes);
-        // x: lanes 0..33 hold image columns x0 - 1 + lane; g: lanes 0..29 hold the own columns x0 + lane (staged at pixel 1 + lane)
+        // x: lanes 0..XL-1 hold image columns x0 - 1 + lane; g: lanes 0..29 hold the own columns x0 + lane (staged at pixel 1 + lane)
         const int cx = x0 - 1 + lane, cg = x0 + lane;
-        const unsigned xcol = lane < 34 && (unsigned)cx < (unsigned)W ? (unsigned)(cx * 16) : kOOB;
+        const unsigned xcol = lane < XL && (unsigned)cx < (unsigned)W ? (unsigned)(cx * 16) : kOOB;
         const unsigned gcol = lane < 30 && cg < W ? (unsigned)(cg * 16) : kOOB;
         auto load_x = [&](int r) -> u32x4 {
-            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)r < (unsigned)H && r <= y1 ? (unsigned)(r * a.row_bytes) + xcol : kOOB, 0, 0);
+            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)r < (unsigned)H && r <= y1 + KS - 3 ? (unsigned)(r * a.row_bytes) + xcol : kOOB, 0, 0);
             if constexpr (RELU_IN) v = __builtin_bit_cast(u32x4, relu_bits(v));
             return v;
         };
         auto load_g = [&](int r) -> u32x4 {
             return __builtin_amdgcn_raw_buffer_load_b128(rg, r >= y0 && r < y1 ? (unsigned)(r * a.row_bytes) + gcol : kOOB, 0, 0);
         };
-        auto stage_x = [&](u32x4 v) { if (lane < 34) *reinterpret_cast<u32x4*>(xbuf + lane * 16) = v; };
+        auto stage_x = [&](u32x4 v) { if (lane < XL) *reinterpret_cast<u32x4*>(xbuf + lane * 16) = v; };
         auto stage_g = [&](u32x4 v) { if (lane < 30) *reinterpret_cast<u32x4*>(gbuf + (1 + lane) * 16) = v; };
-        bf16x8 AX[3];
-        u32x4 PX[3], PG[3];
-        {   // fragments of x rows y0 - 1 and y0; the first three rows of the loop are requested behind them, before the staging
-            const u32x4 r0 = load_x(y0 - 1), r1 = load_x(y0);
+        auto frags = [&](bf16x8 (&ax)[NF]) {
+            ax[0] = frag_of(xbuf);
+            if constexpr (NF == 2) ax[1] = frag_of(xbuf + 2 * 16);
+        };
+        // AX[k]: fragments of x rows; at step I (output row y) row y - 1 + k lives in AX[(I + k) % KS]
+        bf16x8 AX[KS][NF];
+        u32x4 PX[KS], PG[KS];
+        {   // fragments of x rows y0 - 1 .. y0 + KS - 3; the first KS rows of the loop are requested behind them, before the staging
+            u32x4 r0[KS - 1];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { PX[k] = load_x(y0 + 1 + k); PG[k] = load_g(y0 + k); }
-            stage_x(r0);
-            __builtin_amdgcn_wave_barrier();
-            AX[0] = frag_of(xbuf);
-            __builtin_amdgcn_wave_barrier();
-            stage_x(r1);
-            __builtin_amdgcn_wave_barrier();
-            AX[1] = frag_of(xbuf);
-            __builtin_amdgcn_wave_barrier();
+            for (int k = 0; k < KS - 1; ++k) r0[k] = load_x(y0 - 1 + k);
+#pragma unroll
+            for (int k = 0; k < KS; ++k) { PX[k] = load_x(y0 + KS - 2 + k); PG[k] = load_g(y0 + k); }
+#pragma unroll
+            for (int k = 0; k < KS - 1; ++k) {
+                stage_x(r0[k]);
+                __builtin_amdgcn_wave_barrier();
+                frags(AX[k]);
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         auto step = [&](auto ic, const int tg) {
             constexpr int I = decltype(ic)::value;
             const int y = tg + I;
-            stage_x(PX[I]);                                               // x row y + 1
+            stage_x(PX[I]);                                               // x row y + KS - 2
             stage_g(PG[I]);                                               // g row y
-            PX[I] = load_x(y + 4);
-            PG[I] = load_g(y + 3);
+            PX[I] = load_x(y + 2 * KS - 2);
+            PG[I] = load_g(y + KS);
             __builtin_amdgcn_wave_barrier();
-            AX[(I + 2) % 3] = frag_of(xbuf);
+            frags(AX[(I + KS - 1) % KS]);
             const bf16x8 BG = frag_of(gbuf);
             __builtin_amdgcn_wave_barrier();
-            acc[0] = mma8(AX[I % 3], BG, acc[0]);                         // ky 0: x row y - 1
-            acc[1] = mma8(AX[(I + 1) % 3], BG, acc[1]);
-            acc[2] = mma8(AX[(I + 2) % 3], BG, acc[2]);
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky)                               // ky: x row y - 1 + ky
+#pragma unroll
+                for (int f = 0; f < NF; ++f) acc[ky][f] = mma8(AX[(I + ky) % KS][f], BG, acc[ky][f]);
             accb = mma8(ONES, BG, accb);
             __builtin_amdgcn_sched_barrier(0);
         };
-        for (int tg = y0; tg < y1; tg += 3) {
-            step(IC<0>{}, tg);
-            step(IC<1>{}, tg);
-            step(IC<2>{}, tg);
-        }
+        for (int tg = y0; tg < y1; tg += KS)
+            [&]<int... K>(std::integer_sequence<int, K...>) { (step(IC<K>{}, tg), ...); }(std::make_integer_sequence<int, KS>{});
     }
     // ---- the waves' sums -> one slab, fixed order
-    for (int i = threadIdx.x; i < 8 * 80; i += 64 * WG_WAVES) slab[i] = 0.f;
+    for (int i = threadIdx.x; i < 8 * KEXT; i += 64 * WG_WAVES) slab[i] = 0.f;
     __syncthreads();
     const int n = lane & 15, kg = lane >> 4, bb = n >> 3, co = n & 7;
 #pragma unroll
@@ -1089,22 +1104,28 @@ __global__ __launch_bounds__(64 * WG_WAVES) void rowwgrad8_kernel(const RowWgrad
                 if (!(aa == 1 && bb == 1)) {
                     const int kx = aa - bb + 1;
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) slab[co * 80 + (ky * 3 + kx) * 8 + ci] += acc[ky][jj];
+                    for (int ky = 0; ky < KS; ++ky) slab[co * KEXT + (ky * KS + kx) * 8 + ci] += acc[ky][0][jj];
+                }
+                if constexpr (NF == 2) {
+                    if (aa == 0 && bb == 0) {                              // a' = 2, b = 0: kx = 3
+#pragma unroll
+                        for (int ky = 0; ky < KS; ++ky) slab[co * KEXT + (ky * KS + 3) * 8 + ci] += acc[ky][1][jj];
+                    }
                 }
             }
-            if (kg == 0 && bb == 0) slab[co * 80 + 72] += accb[0];
+            if (kg == 0 && bb == 0) slab[co * KEXT + ONESC] += accb[0];
         }
         __syncthreads();
     }
-    float* out = d.slabs + (size_t)blockIdx.x * (8 * 80);
-    for (int i = threadIdx.x; i < 8 * 80; i += 64 * WG_WAVES) out[i] = slab[i];
+    float* out = d.slabs + (size_t)blockIdx.x * (8 * KEXT);
+    for (int i = threadIdx.x; i < 8 * KEXT; i += 64 * WG_WAVES) out[i] = slab[i];
 }
 
 constexpr int kFwd1 = MSAU_PAIR_RELU_IN | MSAU_PAIR_RELU_MID, kFwd2 = MSAU_CONV_ADD | MSAU_CONV_RELU_OUT;
 constexpr int kBwd1 = MSAU_PAIR_MASK_MID, kBwd2 = MSAU_CONV_MASK_A | MSAU_CONV_ADD;
 
 // environment switches of this file, read once; msau_reload_env() makes the next call read them again (tests, A/B tools)
-struct RowsEnv { int on, sh, sh16, waves, min_tasks, maxc, conv, wgrad, dout, pairwg; };
+struct RowsEnv { int on, sh, sh16, waves, min_tasks, maxc, conv, wgrad, wgrad4, dout, pairwg; };
 RowsEnv g_env;
 bool g_env_ok = false;
 const RowsEnv& rows_env() {
@@ -1116,6 +1137,7 @@ const RowsEnv& rows_env() {
         g_env.waves = geti("MSAU_ROWS_WAVES", 3072);             // tasks (= waves) per launch to aim for
         g_env.min_tasks = geti("MSAU_ROWS_MIN_TASKS", 16);       // below: the tile kernels (a wave per task needs a few tasks per XCD at least)
         g_env.wgrad = geti("MSAU_WGRAD_ROWS", 1);                // the 8 -> 8 3x3 weight gradients on the row kernel
+        g_env.wgrad4 = geti("MSAU_WGRAD_ROWS4", 0);              // ... and the 4x4 end conv's: correct (tests), but 13 us per step SLOWER than the tile kernel beside the main stream: off
         g_env.conv = geti("MSAU_CONV_ROWS", 1);                  // single convolutions of the 8-channel level on the row kernels
         g_env.pairwg = geti("MSAU_PAIR_WGRAD", 1);               // the first conv's weight gradient inside the pair's data-gradient launch
         g_env.dout = geti("MSAU_DOUT_ROWS", 1);                  // the two-output data gradients (8 -> 8 + 8, 3x3 and 1x1) on the row kernels
@@ -1297,10 +1319,11 @@ int msau_rowconv_launch(hipStream_t s, int dtype, const msau_conv_desc* d, int k
 int msau_rowwgrad_takes(int dtype, const msau_wgrad_desc* d, int cch, int nchunks, int kextc) {
     const RowsEnv& e = rows_env();
     if (!e.on || !e.wgrad || dtype != MSAU_BF16) return 0;
-    if (d->C1 != 8 || d->C2 != 0 || d->Cout != 8 || d->KH != 3 || d->KW != 3 || d->dil != 1 || d->stride != 1) return 0;
-    if (d->pad_t != 1 || d->pad_l != 1 || d->Hin != d->Hout || d->Win != d->Wout) return 0;
+    if (d->C1 != 8 || d->C2 != 0 || d->Cout != 8 || (d->KH != 3 && d->KH != 4) || d->KW != d->KH || d->dil != 1 || d->stride != 1) return 0;
+    if (d->pad_t != 1 || d->pad_l != 1 || d->Hin != d->Hout || d->Win != d->Wout) return 0;        // (4x4: the SAME padding, 1 before / 2 after)
     if (d->flags & ~MSAU_CONV_RELU_IN) return 0;
-    if (cch != 8 || nchunks != 1 || kextc != 80 || d->nslabs < 1) return 0;
+    if (cch != 8 || nchunks != 1 || kextc != (d->KH == 4 ? 144 : 80) || d->nslabs < 1) return 0;
+    if (d->KH == 4 && !e.wgrad4) return 0;
     if ((int64_t)d->Hout * d->Wout * 16 >= (1ll << 31)) return 0;
     if ((int64_t)d->B * cdiv(d->Wout, 30) * cdiv(d->Hout, 8) < e.min_tasks) return 0;
     return 1;
@@ -1318,14 +1341,18 @@ int msau_rowwgrad_launch(hipStream_t s, const msau_wgrad_desc* d) {
     if (nseg < 1) nseg = 1;
     int sh = e.sh > 0 ? e.sh : cdiv(d->Hout, nseg);
     if (sh < 9) sh = 9;
-    sh = roundup(sh, 3);
+    sh = roundup(sh, d->KH);
     a.SH = sh < d->Hout ? sh : d->Hout;
     a.nseg = cdiv(d->Hout, a.SH);
     a.ntasks = d->B * a.nstrips * a.nseg;
     a.row_bytes = d->Wout * 16;
     a.img_bytes = (unsigned)d->Hout * (unsigned)a.row_bytes;
-    a.kext = 80;
-    if (d->flags & MSAU_CONV_RELU_IN) hipLaunchKernelGGL((rowwgrad8_kernel<true>), dim3(d->nslabs), dim3(64 * WG_WAVES), 0, s, a);
+    a.kext = d->KH == 4 ? 144 : 80;
+    const bool relu = d->flags & MSAU_CONV_RELU_IN;
+    if (d->KH == 4) {
+        if (relu) hipLaunchKernelGGL((rowwgrad8_kernel<true, 4>), dim3(d->nslabs), dim3(64 * WG_WAVES), 0, s, a);
+        else hipLaunchKernelGGL((rowwgrad8_kernel<false, 4>), dim3(d->nslabs), dim3(64 * WG_WAVES), 0, s, a);
+    } else if (relu) hipLaunchKernelGGL((rowwgrad8_kernel<true>), dim3(d->nslabs), dim3(64 * WG_WAVES), 0, s, a);
     else hipLaunchKernelGGL((rowwgrad8_kernel<false>), dim3(d->nslabs), dim3(64 * WG_WAVES), 0, s, a);
     MSAU_CHECK_LAUNCH("rowwgrad8_kernel");
     return 0;

@@ -269,7 +269,7 @@ def _wdesc(x, g, slabs, cin, cout, k, nslabs):
     w = L.WgradDesc()
     w.B, w.Hin, w.Win, w.Hout, w.Wout = B, H, W, H, W
     w.C1, w.C2, w.Cout, w.KH, w.KW = cin, 0, cout, k, k
-    w.dil, w.pad_t, w.pad_l, w.stride, w.flags = 1, k // 2, k // 2, 1, 0
+    w.dil, w.pad_t, w.pad_l, w.stride, w.flags = 1, (k - 1) // 2, (k - 1) // 2, 1, 0      # SAME: 4x4 pads 1 before, 2 after (layers/utils.py:10-19)
     w.x1, w.x2, w.g, w.slabs, w.nslabs = x.data_ptr(), None, g.data_ptr(), slabs.data_ptr(), nslabs
     return w
 
@@ -362,14 +362,19 @@ def test_chunked_first_conv_vs_autograd(dtype, cin, cout, hw, B):
                                            (8, 8, 3, (64, 80)), (16, 16, 3, (50, 37)),
                                            # the row-streaming instance (conv_rows.hip, bf16): strips ending inside / at the image edge,
                                            # fewer rows than one segment, one column
-                                           (8, 8, 3, (57, 61)), (8, 8, 3, (90, 29)), (8, 8, 3, (17, 30)), (8, 8, 3, (200, 1))])
+                                           (8, 8, 3, (57, 61)), (8, 8, 3, (90, 29)), (8, 8, 3, (17, 30)), (8, 8, 3, (200, 1)),
+                                           # ... and its 4x4 form (the end conv: two x fragments per row, four rows carried)
+                                           (8, 8, 4, (64, 80)), (8, 8, 4, (57, 61)), (8, 8, 4, (90, 29)), (8, 8, 4, (19, 31)), (8, 8, 4, (200, 1))])
 @pytest.mark.parametrize("dtype", DT)
-def test_weight_gradient_slabs_vs_fp32_autograd_on_the_same_rounded_inputs(cin, cout, k, hw, dtype):
+def test_weight_gradient_slabs_vs_fp32_autograd_on_the_same_rounded_inputs(cin, cout, k, hw, dtype, monkeypatch):
     """bf16 x bf16 products are exact in fp32, so the lean weight-gradient instances (pixel-split, two-wave-set, plain) must
     agree with an fp32 autograd weight gradient of the SAME bf16-rounded tensors up to summation order: 2e-5 of the largest
     entry -- three orders of magnitude tighter than the bf16 network tolerances, tight enough to see a lost or doubled tile"""
     torch.manual_seed(18)
     lib = L.load()
+    if k == 4:
+        monkeypatch.setenv("MSAU_WGRAD_ROWS4", "1")        # (the 4x4 row instance is off by default: measured slower in the step)
+        lib.msau_reload_env()
     s = torch.cuda.current_stream().cuda_stream
     B, (H, W) = 3, hw
     td = torch.bfloat16 if dtype == L.BF16 else torch.float32
@@ -384,7 +389,7 @@ def test_weight_gradient_slabs_vs_fp32_autograd_on_the_same_rounded_inputs(cin, 
     slab_elems = geom.slab_bytes // 4
     slabs = torch.full((nslabs * slab_elems,), float("nan"), device="cuda")
     d = _wdesc(x, g, slabs, cin, cout, k, nslabs)
-    if (cin, cout, k) == (8, 8, 3) and dtype == L.BF16 and B * -(-W // 30) * -(-H // 8) >= 16:
+    if (cin, cout) == (8, 8) and k in (3, 4) and dtype == L.BF16 and B * -(-W // 30) * -(-H // 8) >= 16:
         L.check(lib.msau_wgrad_geometry(dtype, C.byref(d), C.byref(geom)), "geometry")
         assert geom.lean == 2                             # the row-streaming instance takes it
     L.check(lib.msau_conv2d_wgrad(s, dtype, C.byref(d)), "wgrad")
@@ -398,6 +403,9 @@ def test_weight_gradient_slabs_vs_fp32_autograd_on_the_same_rounded_inputs(cin, 
     O.conv_same(xr, w, b).backward(gr)
     got_w = tot[:, :k * k * cin].view(cout, k * k, cin).permute(0, 2, 1).reshape(cout, cin, k, k)      # slab k = [tap][channel]
     got_b = tot[:, k * k * cin]
+    if k == 4:
+        monkeypatch.delenv("MSAU_WGRAD_ROWS4")
+        lib.msau_reload_env()
     assert float((got_w - w.grad).abs().max()) < 2e-5 * float(w.grad.abs().max())
     assert float((got_b - b.grad).abs().max()) < 2e-5 * float(b.grad.abs().max())
 
