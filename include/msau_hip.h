@@ -207,6 +207,8 @@ typedef struct {
     int32_t reserved0;
     const void* wg1_x;          /* MSAU_PAIR_WGRAD1: x0, [B][H][W][C]                                                     */
     float* wg1_slabs;           /* [msau_conv_pair_wgrad_slabs()][C][80] partial sums, one slab per workgroup             */
+    int32_t wg1_nslabs;         /* the slab count the caller allocated: the launch refuses to write another number        */
+    int32_t reserved1;
 } msau_conv_pair_desc;
 int msau_conv_pair_applicable(int dtype, const msau_conv_pair_desc* d);
 int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc* d);

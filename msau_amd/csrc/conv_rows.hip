@@ -1214,6 +1214,9 @@ int msau_rowpair_launch(hipStream_t s, const msau_conv_pair_desc* d) {
     a.img_bytes = (unsigned)d->H * (unsigned)a.row_bytes;
     a.plane_img = (unsigned)d->H * (unsigned)a.nstrips * 32u;
     const dim3 grid(8 * (a.tasks_per_xcd / 4)), block(256);
+    if (d->flags1 & MSAU_PAIR_WGRAD1)        // (the task split follows MSAU_ROWS_* switches: a plan built under other settings must not be launched)
+        MSAU_CHECK_ARG((int)grid.x == d->wg1_nslabs, "conv_pair: MSAU_PAIR_WGRAD1 launch has %d workgroups, the caller allocated %d slabs "
+                       "(msau_conv_pair_wgrad_slabs under other MSAU_ROWS_* settings?)", (int)grid.x, d->wg1_nslabs);
     if (c8) {
         const bool lrnb = d->flags1 & MSAU_PAIR_LRN_BWD, wg1 = d->flags1 & MSAU_PAIR_WGRAD1;
         if (bwd && lrnb && wg1) hipLaunchKernelGGL((rowpair_c8_kernel<true, true, true, true>), grid, block, 0, s, a);

@@ -612,6 +612,7 @@ class PairOp:
                     b.wg1_x, b.wg1_slabs = _ptr(x0.data), 1                 # (placeholder: the slab arena does not exist yet)
                     ns = int(L.load().msau_conv_pair_wgrad_slabs(P.dtype, C.byref(b)))
                     if ns > 0:
+                        b.wg1_nslabs = ns
                         self.wg_slab_off = P.alloc_slab(ns * 640)
                         u.slab_off, u.nslabs = self.wg_slab_off, ns
                         u.b_src_off, u.b_nslabs = self.wg_slab_off + 72, ns

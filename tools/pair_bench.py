@@ -129,6 +129,7 @@ for (H, W, Cc) in ((336, 256, 8), (168, 128, 16)):
             q.lrn_a, q.lrn_da, q.lrn_alpha_over_n, q.lrn_beta, q.lrn_k = la.data_ptr(), lda.data_ptr(), 1e-4 / 8, 0.75, 1.0
             slabs = torch.zeros(4096 * 640, device=dev)
             q.wg1_x, q.wg1_slabs = x.data_ptr(), slabs.data_ptr()
+            q.wg1_nslabs = int(lib.msau_conv_pair_wgrad_slabs(L.BF16, C.byref(q))) if fl & L.PAIR_WGRAD1 else 0
             if lib.msau_conv_pair_applicable(L.BF16, C.byref(q)):
                 res[tag] = timed(lambda: L.check(lib.msau_conv_pair(s, L.BF16, C.byref(q))))
     mb = n * 2 / 1e6
