@@ -416,8 +416,9 @@ class MSAUWrapper(nn.Module):
                 plan.predict(self._flat, **kw)                        # warm-up outside capture
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=gs):
-                    plan.predict(self._flat, **kw)
+                with _capture_section():
+                    with torch.cuda.graph(g, stream=gs):
+                        plan.predict(self._flat, **kw)
                 cache[kind] = (g, static)
             g, static = cache[kind]
             static.copy_(ref, non_blocking=True)
@@ -435,6 +436,32 @@ class MSAUWrapper(nn.Module):
         """Masked CE of final + aux logits over pixels with label != 0 (model/model.py:446-459).
         Accepts label_mask [B,H,W] (the reference: B = 1): per-sample masked mean, then mean over B."""
         return _MaskedCEFunction.apply(out_grid, out_grid_aux, label_mask)
+
+
+# A stream capture is in "global" mode: a device synchronisation (or a graph's destruction) from ANY Python context while it runs --
+# e.g. the finaliser of another engine, whenever the garbage collector gets to it -- makes hipStreamEndCapture abort the process
+# (seen once in four full GPU test runs, 2026-10-04).  Graphs whose engine dies during a capture wait in _graveyard until the next
+# safe point (TrainEngine.step / _drop_graphs outside a capture).
+_capturing = 0
+_graveyard: list = []
+
+
+class _capture_section:
+    def __enter__(self):
+        global _capturing
+        _capturing += 1
+
+    def __exit__(self, *exc):
+        global _capturing
+        _capturing -= 1
+        return False
+
+
+def _bury_graphs():
+    """destroy the graphs of dead engines: not while a replay may still be running (ROCm 7.2: the process segfaults), not during a capture"""
+    if _graveyard and not _capturing:
+        torch.cuda.synchronize()
+        _graveyard.clear()
 
 
 def _ru4(n: int) -> int:
@@ -485,10 +512,10 @@ class TrainEngine:
         model = model_ref()
         if model is not None:
             doomed = [plan._tgraphs.pop(token) for plan in model._plans.values() if token in plan.__dict__.get("_tgraphs", {})]
-            if doomed and torch.cuda.is_available():
-                # a graph must not be destroyed while a replay of it is still running (ROCm 7.2: the process segfaults)
-                torch.cuda.synchronize()
-            del doomed
+            if doomed:
+                _graveyard.extend(doomed)            # (this may be a finaliser running in the middle of somebody's stream capture)
+                del doomed
+                _bury_graphs()
 
     def _invalidate_graphs(self):
         """lr / betas / eps / max_norm are by-value arguments of msau_clip_adam_step, frozen into a captured optimiser graph:
@@ -589,6 +616,7 @@ class TrainEngine:
             return loss
         # The captured graphs hold the plan's buffer addresses: they are stored ON the plan (as predict_nhwc does), so
         # that an evicted / rebuilt plan can never be replayed through a stale graph.
+        _bury_graphs()
         graphs = plan.__dict__.setdefault("_tgraphs", {})
         key = self._token
         cur = torch.cuda.current_stream()
@@ -601,11 +629,13 @@ class TrainEngine:
                 self._fwd_bwd(plan, sx, sl)
                 torch.cuda.synchronize()
                 g1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1, stream=gs):
-                    loss = self._fwd_bwd(plan, sx, sl)
+                with _capture_section():
+                    with torch.cuda.graph(g1, stream=gs):
+                        loss = self._fwd_bwd(plan, sx, sl)
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, stream=gs):
-                    self._optim()
+                with _capture_section():
+                    with torch.cuda.graph(g2, stream=gs):
+                        self._optim()
                 graphs[key] = (g1, g2, loss, sx, sl)
             g1, g2, loss, sx, sl = graphs[key]
             sx.copy_(x, non_blocking=True)
