@@ -415,7 +415,7 @@ class MSAUWrapper(nn.Module):
                 kw = dict(ids=static) if ids is not None else dict(x_nchw=static)
                 plan.predict(self._flat, **kw)                        # warm-up outside capture
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
+                g = _keep_graph(torch.cuda.CUDAGraph())
                 with _capture_section():
                     with torch.cuda.graph(g, stream=gs):
                         plan.predict(self._flat, **kw)
@@ -444,6 +444,21 @@ class MSAUWrapper(nn.Module):
 # safe point (TrainEngine.step / _drop_graphs outside a capture).
 _capturing = 0
 _graveyard: list = []
+# FINDING (MI355X / ROCm 7.2 / torch 2.10, 2026-10-04): destroying a captured graph (hipGraphExecDestroy / hipGraphDestroy through
+# torch.cuda.CUDAGraph's destructor) and capturing another one afterwards crashes the process -- abort inside hipStreamEndCapture or a
+# segmentation fault, in about half of the runs of tests/test_train_gpu.py on its own, on the tree of any day of this round; with the
+# graph objects kept alive: 0 of 12.  So a captured graph is never destroyed: one extra reference at creation (its kernel-argument
+# storage and private pool stay; the static input copies are separate tensors and ARE freed with the engine).  Graph mode is opt-in and
+# slower than eager launches here (section 2 of DESIGN.md); MSAU_GRAPH_DESTROY=1 restores destruction at safe points.
+_immortal: list = []
+
+
+def _keep_graph(g):
+    if os.environ.get("MSAU_GRAPH_DESTROY", "0") != "1":
+        import ctypes
+        ctypes.pythonapi.Py_IncRef(ctypes.py_object(g))
+        _immortal.append(g)
+    return g
 
 
 class _capture_section:
@@ -461,7 +476,7 @@ def _bury_graphs():
     """destroy the graphs of dead engines: not while a replay may still be running (ROCm 7.2: the process segfaults), not during a capture"""
     if _graveyard and not _capturing:
         torch.cuda.synchronize()
-        _graveyard.clear()
+        _graveyard.clear()          # (the static input copies go; the graph objects themselves are immortal unless MSAU_GRAPH_DESTROY=1)
 
 
 def _ru4(n: int) -> int:
@@ -628,11 +643,11 @@ class TrainEngine:
                 # warm up outside capture (hipFuncSetAttribute calls, lazy allocations)
                 self._fwd_bwd(plan, sx, sl)
                 torch.cuda.synchronize()
-                g1 = torch.cuda.CUDAGraph()
+                g1 = _keep_graph(torch.cuda.CUDAGraph())
                 with _capture_section():
                     with torch.cuda.graph(g1, stream=gs):
                         loss = self._fwd_bwd(plan, sx, sl)
-                g2 = torch.cuda.CUDAGraph()
+                g2 = _keep_graph(torch.cuda.CUDAGraph())
                 with _capture_section():
                     with torch.cuda.graph(g2, stream=gs):
                         self._optim()
