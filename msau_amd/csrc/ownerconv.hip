@@ -66,12 +66,10 @@ __global__ __launch_bounds__(256) void owner_wj_kernel(const float* __restrict__
 __global__ __launch_bounds__(64) void owner_table_mfma_kernel(const bf16_t* __restrict__ wj, const float* __restrict__ feats, float* __restrict__ table,
                                                               int n_vec, int C, int Cp) {
     const int lane = threadIdx.x, lr = lane & 15, lg = lane >> 4;
-    const int v0 = blockIdx.x * 16;
+    const int v0 = blockIdx.x * 16, t0 = blockIdx.y;              // 16 feature rows x one 16-column tile of j per wave (five tiles: 163 -> 815 waves at cfg 4)
     const int vr = v0 + lr < n_vec ? v0 + lr : n_vec - 1;
     const float* row = feats + (size_t)vr * C;
-    f32x4 acc[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const bool vec = (C & 3) == 0;
     for (int c0 = 0; c0 < Cp; c0 += 32) {
         const int c = c0 + lg * 8;
@@ -84,21 +82,15 @@ __global__ __launch_bounds__(64) void owner_table_mfma_kernel(const bf16_t* __re
 #pragma unroll
             for (int k = 0; k < 8; ++k) a[k] = (bf16_t)(c + k < C ? row[c + k] : 0.f);
         }
-#pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            const bf16x8 b = load8<bf16_t>(wj + (size_t)(t * 16 + lr) * Cp + c);
-            acc[t] = mma8(a, b, acc[t]);
-        }
+        const bf16x8 b = load8<bf16_t>(wj + (size_t)(t0 * 16 + lr) * Cp + c);
+        acc = mma8(a, b, acc);
     }
     // D: column = lane & 15 (j within the tile), row = 4 (lane >> 4) + reg (feature row within the 16)
+    const int j = t0 * 16 + lr;
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
-        const int j = t * 16 + lr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int v = v0 + 4 * lg + r;
-            if (j < 72 && v < n_vec) table[(size_t)v * 72 + j] = acc[t][r];
-        }
+    for (int r = 0; r < 4; ++r) {
+        const int v = v0 + 4 * lg + r;
+        if (j < 72 && v < n_vec) table[(size_t)v * 72 + j] = acc[r];
     }
 }
 
@@ -271,7 +263,7 @@ int msau_ownerconv_fwd(hipStream_t s, int dtype, const msau_conv_desc* d) {
         } else {
             const int Cp = roundup(c->C, 32);                              // (wt holds max(C, 32) * 72 floats >= 80 * Cp bf16)
             hipLaunchKernelGGL(owner_wj_kernel, dim3(cdiv(80 * Cp, 256)), dim3(256), 0, s, c->w, reinterpret_cast<bf16_t*>(c->wt), c->C, Cp);
-            hipLaunchKernelGGL(owner_table_mfma_kernel, dim3(cdiv(c->n_vec, 16)), dim3(64), 0, s, reinterpret_cast<const bf16_t*>(c->wt), c->feats, c->table, c->n_vec, c->C, Cp);
+            hipLaunchKernelGGL(owner_table_mfma_kernel, dim3(cdiv(c->n_vec, 16), 5), dim3(64), 0, s, reinterpret_cast<const bf16_t*>(c->wt), c->feats, c->table, c->n_vec, c->C, Cp);
         }
         MSAU_CHECK_LAUNCH("owner_table");
     }
@@ -287,7 +279,7 @@ int msau_ownerconv_fwd(hipStream_t s, int dtype, const msau_conv_desc* d) {
 
 // slabs an MSAU_CONV_OWNER weight gradient writes (= ways the box range is split): what the slab reduction must be told
 int msau_ownerconv_slabs(const msau_wgrad_desc* d) {
-    int k = 32;
+    int k = 96;                                                     // (32: 50 us for the 2605 boxes of the bench's cfg-4 batch; each part is a dependent chain of loads)
     if (k > d->nslabs) k = d->nslabs;
     return k < 1 ? 1 : k;
 }

@@ -522,7 +522,9 @@ def test_first_conv_fed_with_box_lists_matches_the_painted_grid(dtype, C, monkey
         wo, bo, n = plan.poff[c.wname], plan.poff[c.bname], int(np.prod(plan.pshape[c.wname]))
         g = eng.flat_grad.float().cpu()
         res[mode] = (losses, g, m.flat_parameters.float().cpu(), g[wo:wo + n].clone(), g[bo:bo + 8].clone())
-    tol = 2e-2 if dtype == "bf16" else 2e-4
+    # (third step: Adam's first updates are lr * sign(g), so entries whose gradient is rounding noise take different signs on the two
+    #  paths and the trajectories part at the 1e-4 level even in fp32)
+    tol = 2e-2 if dtype == "bf16" else 1e-3
     for a, b in zip(res["1"][0], res["0"][0]):
         assert abs(a - b) < (2e-3 if dtype == "bf16" else 1e-5) * abs(b), (res["1"][0], res["0"][0])
     assert float(res["0"][3].abs().max()) > 0 and err(res["1"][3], res["0"][3], True) < tol
