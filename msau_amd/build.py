@@ -26,6 +26,9 @@ EXTRA_FLAGS = {"elementwise.hip": ["-Xclang", "-target-feature", "-Xclang", "-pa
                # ... and, since round 3 put the LRN backward into the residual pair's epilogue (MSAU_PAIR_LRN_BWD: the same adjoint-window
                # chains as lrn_fast_kernel, beside the same side-stream kernels), WITHOUT packed-fp32 instructions like elementwise.hip:
                # the compiler had produced 31 op_sel'd v_pk_*_f32 in exactly those two instances (tests/test_host_cpu.py reads the ISA)
+               # attention on the matrix cores: MFMA results in VGPRs as well (the statistics kernel read every score back with
+               # v_accvgpr_read: a quarter of its vector instructions)
+               "attention_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "conv_rows.hip": ["-std=c++20"] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.environ.get("MSAU_ROWS_VGPR_FORM", "1") != "0" else [])
                                 + (["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] if os.environ.get("MSAU_ROWS_PACKED_FP32", "0") != "1" else [])
                                 + (["-DMSAU_ROWCONV_PF=" + os.environ["MSAU_ROWCONV_PF"]] if os.environ.get("MSAU_ROWCONV_PF") else [])}

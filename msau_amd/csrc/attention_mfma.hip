@@ -15,13 +15,33 @@
 //   mode DF (own j, sweep i): ds = P (h_i . dy_j - delta_i) ; acc[d][j] += g^T[d][i] ds   -> df
 // plus a statistics kernel (row max m_i and row sum Z_i of exp).
 #include "msau_common.h"
+#include <type_traits>
+
+#ifdef MSAU_STAMPS
+__device__ unsigned long long* g_attn_stamps = nullptr;       // diagnostic build only
+extern "C" int msau_debug_set_attn_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &p, sizeof(p)); }
+#define ASTAMP(i) do { if (g_attn_stamps && threadIdx.x == 0) g_attn_stamps[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ASTAMP(i) do {} while (0)
+#endif
 
 namespace {
 
 enum { M_O = 0, M_DH = 1, M_DG = 2, M_DF = 3 };
-constexpr int CHUNK = 256;                // sweep rows staged in LDS per barrier phase (128: -0.3 %)
+// Geometry of a sweep workgroup (round 4).  The round-3 form -- 4 groups of 16 own positions x 2 sweep halves = 512 threads, 336
+// workgroups for 16 samples of 1344 positions -- left 176 CUs with one workgroup (two waves per SIMD: latency-bound, 12.5 us) and
+// 80 CUs with two (18 us, the launch's duration); phase stamps, profiles/r04_attention.md.  Now OG groups of own positions per
+// workgroup so that N = 1344 gives 14 workgroups per sample = 224 equal workgroups, ONE per CU, three waves per SIMD; the sweep
+// side is staged CH rows at a time (one workgroup per CU: the LDS is there) -- half the barriers and half as many bytes staged.
+template <int CS> struct SweepGeom {
+    static constexpr int OG = 6;                          // groups of 16 own positions per workgroup
+    static constexpr int SW = 2;                          // waves sharing a group: they split the swept rows (partial sums meet in LDS)
+    static constexpr int CH = CS <= 64 ? 512 : 256;       // sweep rows staged in LDS per barrier phase
+    static constexpr int NT = 64 * OG * SW;
+    static constexpr int TS = CS * 2 + 32;                // padded row stride of the C tensor tile: 8 rows x 32 B of a tr-read hit 64 distinct banks
+    template <int DS> static constexpr int lds() { return (CH * DS * 2 + 64) + CH * TS + 2 * CH * 4; }
+};
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr int kSweepWays = 2;             // waves sharing one group of own positions in the sweeps (see attn_sweep_body)
 
 typedef __attribute__((address_space(3))) bf16x4* lds_v4;
 
@@ -39,135 +59,163 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// statistics: m_i = max_j s[i][j], Z_i = sum_j exp(s[i][j] - m_i).  Wave = 16 rows i (as MFMA rows),
-// f of the whole sample in LDS.
+// statistics: m_i = max_j s[i][j], Z_i = sum_j exp(s[i][j] - m_i).  Wave = 16 rows i (as MFMA rows) x half of the columns.
+//
+// Round 4.  The round-3 form issued 4557 vector instructions per wave where ~1700 do the work: fmaxf's NaN canonicalisation
+// (`v_max_f32 x, x` on both operands), a v_accvgpr_read of every score, and a v_cndmask per score for columns beyond N that
+// only the last tile can have (PMC + ISA, profiles/r04_attention.md); and its 336 four-wave workgroups left a quarter of
+// the CUs with twice the work of the rest.  Now: the geometry of the sweeps (6 row groups x 2 column halves = 768 threads,
+// 224 equal workgroups at N = 1344), f of the sample staged in LDS once, full tiles without validity tests, v_med3 maxima,
+// MFMA results in VGPRs (build flag); the two halves' (m, Z) pairs meet in LDS.
+// (A version without LDS -- every lane loading its column's d-vector from global memory, one group of four tiles ahead --
+// was load-latency bound at 14.5 us: a group is ~250 cycles of work, an L2 hit 500-800.)
 // ---------------------------------------------------------------------------------------------
+// max without fmaxf's NaN canonicalisation (`v_max_f32 x, x` on every operand): med3(a, b, huge) IS max(a, b) for numbers below huge.
+// (Not inline asm: the compiler pads MFMA -> VALU read hazards only for instructions it can see; a hand-written v_max3_f32
+// right behind the MFMA that produced its operand read the OLD register: NaNs at N = 1344.)
+__device__ __forceinline__ float max2f(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, 3.0e38f); }      // (with +inf itself LLVM folds it back to maxnum + canonicalize)
+__device__ __forceinline__ float max3f(float a, float b, float c) { return max2f(max2f(a, b), c); }
+
+constexpr int kStatOG = 6, kStatNT = 64 * kStatOG * 2;
+
 template <int DS>
-__global__ __launch_bounds__(256) void attn_stats_mfma(const bf16_t* __restrict__ f, const bf16_t* __restrict__ g,
-                                                       float* __restrict__ stats, int N) {
+__global__ __launch_bounds__(kStatNT) void attn_stats_mfma(const bf16_t* __restrict__ f, const bf16_t* __restrict__ g,
+                                                           float* __restrict__ stats, int N) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int OG = kStatOG, NT = kStatNT, KG = DS / 8, RB = DS * 2;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all % OG, half = wave_all / OG;
     const int lr = lane & 15, lg = lane >> 4;
-    const int Npad = (N + 15) & ~15;
-    constexpr int RB = DS * 2;                                   // bytes per f / g row
-    // stage f[b] (zero rows beyond N) + one zero slot
-    for (int r = tid; r < Npad; r += 256) {
-#pragma unroll
-        for (int c = 0; c < DS / 8; ++c) {
-            bf16x8 v = zero8<bf16_t>();
-            if (r < N) v = load8<bf16_t>(f + ((size_t)b * N + r) * DS + c * 8);
-            *reinterpret_cast<bf16x8*>(smem + r * RB + c * 16) = v;
-        }
+    const int Npad = (N + 15) & ~15, T = Npad / 16;                  // column tiles
+    // stage f[b] (zero rows beyond N)
+    for (int idx = tid; idx < Npad * KG; idx += NT) {
+        const int r = idx / KG, c = idx - r * KG;
+        bf16x8 v = zero8<bf16_t>();
+        if (r < N) v = load8<bf16_t>(f + ((size_t)b * N + r) * DS + c * 8);
+        *reinterpret_cast<bf16x8*>(smem + r * RB + c * 16) = v;
     }
-    const int zoff = Npad * RB;
-    if (tid < 2) *reinterpret_cast<bf16x8*>(smem + zoff + tid * 16) = zero8<bf16_t>();
+    float* comb = reinterpret_cast<float*>(smem + Npad * RB);        // [OG][16 rows][2]: the second half's (m log2e, Z)
+    const int i0 = (blockIdx.x * OG + wave) * 16;
+    bf16x8 afrag = zero8<bf16_t>();                                  // A: g rows, k = d (lane groups lg < KG)
+    if (lg < KG && i0 + lr < N) afrag = load8<bf16_t>(g + ((size_t)b * N + i0 + lr) * DS + lg * 8);
     __syncthreads();
-    const int i0 = (blockIdx.x * 4 + wave) * 16;
-    if (i0 >= N) return;
-    bf16x8 afrag = zero8<bf16_t>();                               // A: G rows, k = d (lanes g < DS/8)
-    if (lg < DS / 8 && i0 + lr < N) afrag = load8<bf16_t>(g + ((size_t)b * N + i0 + lr) * DS + lg * 8);
-    // Two passes over the columns instead of one online-softmax sweep: the running (m, Z) update is a serial chain of two
-    // exponentials per score tile, and with one or two waves per SIMD nothing hides it (84 tiles x ~450 cycles).  Pass 1
-    // takes the row maximum (MFMA + max only), pass 2 sums exp(s - m) with the final m: twice the (cheap) MFMAs, half the
-    // exponentials, and the tiles of a pass are independent -- four in flight.
+    // this wave's column tiles [t0, t1); a lane's fragment of tile t: row t*16 + lr, bytes (lg % KG)*16 (the lane groups beyond d
+    // re-read real data: the A operand is zero there)
+    const int t0 = half ? (T + 1) / 2 : 0, t1 = half ? T : (T + 1) / 2;
+    const unsigned char* fcol = smem + lr * RB + (lg & (KG - 1)) * 16;
+    auto score = [&](int t) {
+        const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(fcol + t * 16 * RB);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    };
+    const bool tail = (N & 15) != 0;                                 // the LAST tile has columns beyond N
+    const int tf = (tail && t1 == T) ? t1 - 1 : t1;                  // full tiles end here
     float m[4], Z[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { m[r] = -1e30f; Z[r] = 0.f; }
-    const int boff = lg < DS / 8 ? lg * 16 : -1;
-    auto score = [&](int j0) {
-        bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(smem + (boff < 0 ? zoff : (j0 + lr) * RB + boff));
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-    };
-    const int Nq = Npad & ~63;                                     // whole groups of four 16-column tiles
-    for (int j0 = 0; j0 < Nq; j0 += 64) {
+    // ---- pass 1: maxima
+    int t = t0;
+    for (; t + 4 <= tf; t += 4) {
         f32x4 s4[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) s4[t] = score(j0 + t * 16);
+        for (int u = 0; u < 4; ++u) s4[u] = score(t + u);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const bool valid = j0 + t * 16 + lr < N;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m[r] = valid ? fmaxf(m[r], s4[t][r]) : m[r];
-        }
+        for (int r = 0; r < 4; ++r) m[r] = max3f(max3f(m[r], s4[0][r], s4[1][r]), s4[2][r], s4[3][r]);
     }
-    for (int j0 = Nq; j0 < Npad; j0 += 16) {
-        const f32x4 s = score(j0);
-        const bool valid = j0 + lr < N;
+    for (; t < t1; ++t) {
+        const f32x4 s = score(t);
+        const bool valid = t * 16 + lr < N;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) m[r] = valid ? fmaxf(m[r], s[r]) : m[r];
+        for (int r = 0; r < 4; ++r) m[r] = valid ? max2f(m[r], s[r]) : m[r];
     }
-    // the row maximum over all columns: merge the 16 column-lanes of each row group
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) m[r] = fmaxf(m[r], __shfl_xor(m[r], o, 64));
+        for (int r = 0; r < 4; ++r) m[r] = max2f(m[r], __shfl_xor(m[r], o, 64));
     }
     float ml[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) ml[r] = m[r] * LOG2E;
-    for (int j0 = 0; j0 < Nq; j0 += 64) {
+    // ---- pass 2: Z = sum exp(s - m) over this half's columns, with this half's maximum
+    t = t0;
+    for (; t + 4 <= tf; t += 4) {
         f32x4 s4[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) s4[t] = score(j0 + t * 16);
+        for (int u = 0; u < 4; ++u) s4[u] = score(t + u);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const bool valid = j0 + t * 16 + lr < N;
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Z[r] += valid ? __builtin_amdgcn_exp2f(s4[t][r] * LOG2E - ml[r]) : 0.f;
-        }
+            for (int r = 0; r < 4; ++r) Z[r] += __builtin_amdgcn_exp2f(__builtin_fmaf(s4[u][r], LOG2E, -ml[r]));
     }
-    for (int j0 = Nq; j0 < Npad; j0 += 16) {
-        const f32x4 s = score(j0);
-        const bool valid = j0 + lr < N;
+    for (; t < t1; ++t) {
+        const f32x4 s = score(t);
+        const bool valid = t * 16 + lr < N;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Z[r] += valid ? __builtin_amdgcn_exp2f(s[r] * LOG2E - ml[r]) : 0.f;
+        for (int r = 0; r < 4; ++r) Z[r] += valid ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], LOG2E, -ml[r])) : 0.f;
     }
-    // sum over the 16 column-lanes
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) Z[r] += __shfl_xor(Z[r], o, 64);
     }
-    if (lr == 0) {
+    // ---- the two halves: (m, Z) = (max, Z1 2^(ml1 - ml) + Z2 2^(ml2 - ml)); an empty half has m = -1e30, Z = 0
+    if (half == 1 && lr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { comb[(wave * 16 + lg * 4 + r) * 2] = m[r]; comb[(wave * 16 + lg * 4 + r) * 2 + 1] = Z[r]; }
+    }
+    __syncthreads();
+    if (half == 0 && lr == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            int i = i0 + lg * 4 + r;
-            if (i < N) { stats[((size_t)b * N + i) * 2] = m[r]; stats[((size_t)b * N + i) * 2 + 1] = Z[r]; }
+            const int i = i0 + lg * 4 + r;
+            const float m2 = comb[(wave * 16 + lg * 4 + r) * 2], z2 = comb[(wave * 16 + lg * 4 + r) * 2 + 1];
+            const float mm = max2f(m[r], m2);
+            const float zz = Z[r] * __builtin_amdgcn_exp2f((m[r] - mm) * LOG2E) + z2 * __builtin_amdgcn_exp2f((m2 - mm) * LOG2E);
+            if (i < N) { stats[((size_t)b * N + i) * 2] = mm; stats[((size_t)b * N + i) * 2 + 1] = zz; }
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // the four sweep modes
+//
+// Round 4 (PMC: the waves of the round-3 form issued 30 % of their cycles and sat at s_waitcnt / barriers for the rest; the
+// step loop was one serial chain -- fragment read, wait, MFMA, exp, read, wait, MFMA -- of ~75 vector instructions per step):
+//   * softmax statistics enter as ONE number per row, lse2 = m log2(e) + log2(Z): P = exp2(s log2(e) - lse2) -- one fma and
+//     one exp per score, no multiply by 1/Z;
+//   * the lane groups beyond d read their row's first 16 bytes again instead of a zero slot (the own-side operand is zero
+//     there): every LDS address of a step is then a per-lane base plus a compile-time offset;
+//   * a full chunk's steps are unrolled phase by phase -- all score tiles, then all exponentials, then all second products --
+//     so that the reads and MFMAs of one step hide behind the arithmetic of another.
 // ---------------------------------------------------------------------------------------------
-template <int DS, int CS, int MODE, int SW>
+template <int DS, int CS, int MODE>
 __device__ __forceinline__ void attn_sweep_body(const bf16_t* __restrict__ f, const bf16_t* __restrict__ g,
                                                 const bf16_t* __restrict__ h, const bf16_t* __restrict__ xdy,
                                                 const float* __restrict__ stats, float* __restrict__ delta,
                                                 bf16_t* __restrict__ out, int N) {
     constexpr bool OWN_I = (MODE == M_DH || MODE == M_DG);        // own positions are rows of s
     constexpr bool ACC_C = (MODE == M_O || MODE == M_DH);         // second product over the C tensor
-    constexpr int CTC = CS / 16, KSC = CS / 32;
+    constexpr int CTC = CS / 16, KSC = CS / 32, KG = DS / 8;
     constexpr int RB = DS * 2;                                    // bytes per d-vector row
-    constexpr int TS = CS * 2 + 16;                               // padded row stride of the C tensor tile
-    constexpr int VS_BYTES = CHUNK * RB + 64;                     // + slack for tr-reads past the last row / zero slot
+    using G = SweepGeom<CS>;
+    constexpr int SW = G::SW, OG = G::OG, CHUNK = G::CH, TS = G::TS;
+    constexpr int VS_BYTES = CHUNK * RB + 64;                     // + slack for tr-reads past the last row
     constexpr int TS_BYTES = CHUNK * TS;
+    constexpr int NSTEP = CHUNK / 32, KW = NSTEP / SW;            // steps per chunk; steps per wave of a full chunk
+    constexpr int KU = KW >= 2 ? 2 : 1;                           // ... of which KU run side by side (4: 132-188 VGPRs, one workgroup per CU)
+    static_assert(NSTEP % SW == 0 && (NSTEP / SW) % 2 == 0, "the sweep ways divide the steps of a chunk");
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* vs = smem;                                     // sweep-side d-vectors  [CHUNK][DS]
     unsigned char* ts = smem + VS_BYTES;                          // sweep-side C tensor   [CHUNK][CS] (padded)
-    float* st_m = reinterpret_cast<float*>(smem + VS_BYTES + TS_BYTES);      // [CHUNK] (own = j modes)
-    float* st_z = st_m + CHUNK;
-    float* st_d = st_z + CHUNK;
+    float* st_l = reinterpret_cast<float*>(smem + VS_BYTES + TS_BYTES);      // [CHUNK] lse2 of the sweep rows (own = j modes)
+    float* st_d = st_l + CHUNK;                                              // [CHUNK] delta of the sweep rows (mode DF)
 
     // SW waves share a group of 16 own positions and split the swept rows between them (wave w takes the 32-row steps
-    // w/4, w/4 + SW, ...): the sweep is one dependent chain per wave (fragment read -> MFMA -> exp -> MFMA), and with 336
-    // workgroups of four waves a SIMD held one or two of them -- nothing to overlap the chain with.  The SW partial
-    // accumulators meet in LDS after the last chunk (fixed order).
-    constexpr int NT = 256 * SW;
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
-    const int wave = wave_all & 3, part_id = wave_all >> 2;
+    // w/4, w/4 + SW, ...).  The SW partial accumulators meet in LDS after the last chunk (fixed order).
+    constexpr int NT = G::NT;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all % OG, part_id = wave_all / OG;
     const int lr = lane & 15, lg = lane >> 4;
-    const int o0 = (blockIdx.x * 4 + wave) * 16;                  // this wave's own positions
+    const int o0 = (blockIdx.x * OG + wave) * 16;                 // this wave's own positions
     const int own = o0 + lr;
     const bool own_ok = own < N;
     const size_t ob = (size_t)b * N + (own_ok ? own : 0);
@@ -178,7 +226,7 @@ __device__ __forceinline__ void attn_sweep_body(const bf16_t* __restrict__ f, co
 
     // own-side operands (B operands: lane (column own, k-group lg))
     bf16x8 vo = zero8<bf16_t>();
-    if (lg < DS / 8 && own_ok) vo = load8<bf16_t>(own_v + ob * DS + lg * 8);
+    if (lg < KG && own_ok) vo = load8<bf16_t>(own_v + ob * DS + lg * 8);
     bf16x8 to[ACC_C ? 1 : KSC];
     if constexpr (!ACC_C) {
         const bf16_t* own_t = (MODE == M_DG) ? h : xdy;
@@ -188,10 +236,9 @@ __device__ __forceinline__ void attn_sweep_body(const bf16_t* __restrict__ f, co
             if (own_ok) to[ks] = load8<bf16_t>(own_t + ob * CS + ks * 32 + lg * 8);
         }
     }
-    float om = 0.f, oiz = 0.f, odl = 0.f;
+    float olse = 0.f, odl = 0.f;
     if (OWN_I && own_ok) {
-        om = stats[ob * 2] * LOG2E;
-        oiz = 1.f / stats[ob * 2 + 1];
+        olse = __builtin_fmaf(stats[ob * 2], LOG2E, __builtin_amdgcn_logf(stats[ob * 2 + 1]));
         if (MODE == M_DG) odl = delta[ob];
     }
 
@@ -201,20 +248,26 @@ __device__ __forceinline__ void attn_sweep_body(const bf16_t* __restrict__ f, co
     for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int q4 = lr >> 2, p4 = lr & 3;                          // tr-read address roles inside a 16-lane group
-    const int zoff = CHUNK * RB + 32;                             // zero slot inside vs
-    if (tid < 2) *reinterpret_cast<bf16x8*>(vs + CHUNK * RB + tid * 16 + 16) = zero8<bf16_t>();
+    // per-lane LDS bases of a step's operands; a step at sweep row s0 adds s0 * (row stride), a compile-time number in the
+    // unrolled path (this wave's first step of a chunk, part_id, is folded in here)
+    const unsigned char* a_vs = vs + (part_id * 32 + lr) * RB + (lg & (KG - 1)) * 16;            // score A operand: row s0 + t*16 + lr
+    const unsigned char* a_ts = ts + (part_id * 32 + lr) * TS + lg * 16;                          // D A operand (modes DG / DF)
+    const unsigned char* a_trt = ts + (part_id * 32 + lg * 4 + q4) * TS + p4 * 8;                // tr-read base in the C tile
+    const unsigned char* a_trv = vs + (part_id * 32 + lg * 4 + q4) * RB + p4 * 8;                // tr-read base in the d-vector tile
+    const float* a_l = st_l + part_id * 32 + lg * 4;
+    const float* a_d = st_d + part_id * 32 + lg * 4;
 
     // ---- sweep-side staging with a one-chunk register prefetch: the global loads of chunk k+1 are in flight while
-    // chunk k is consumed (the sweeps are latency-bound: 11 chunks, each one load round trip otherwise)
-    constexpr int NV = (CHUNK * (DS / 8) + NT - 1) / NT, NTT = (CHUNK * (CS / 8) + NT - 1) / NT;
+    // chunk k is consumed
+    constexpr int NV = (CHUNK * KG + NT - 1) / NT, NTT = (CHUNK * (CS / 8) + NT - 1) / NT;
     bf16x8 pv[NV], ptn[NTT];
-    float pm = 0.f, piz = 0.f, pdl = 0.f;
+    float pl = 0.f, pdl = 0.f;
     auto issue = [&](int r0) {
 #pragma unroll
         for (int it = 0; it < NV; ++it) {
-            const int idx = tid + it * NT, r = idx / (DS / 8), c = idx % (DS / 8);
+            const int idx = tid + it * NT, r = idx / KG, c = idx % KG;
             pv[it] = zero8<bf16_t>();
-            if (idx < CHUNK * (DS / 8) && r0 + r < N) pv[it] = load8<bf16_t>(sweep_v + ((size_t)b * N + r0 + r) * DS + c * 8);
+            if (idx < CHUNK * KG && r0 + r < N) pv[it] = load8<bf16_t>(sweep_v + ((size_t)b * N + r0 + r) * DS + c * 8);
         }
 #pragma unroll
         for (int it = 0; it < NTT; ++it) {
@@ -223,109 +276,131 @@ __device__ __forceinline__ void attn_sweep_body(const bf16_t* __restrict__ f, co
             if (idx < CHUNK * (CS / 8) && r0 + r < N) ptn[it] = load8<bf16_t>(sweep_t + ((size_t)b * N + r0 + r) * CS + c * 8);
         }
         if (!OWN_I && tid < CHUNK) {
-            pm = 0.f; piz = 0.f; pdl = 0.f;
+            pl = 3e38f; pdl = 0.f;                                // rows beyond N: P = exp2(-huge) = 0
             if (r0 + tid < N) {
                 const size_t qq = (size_t)b * N + r0 + tid;
-                pm = stats[qq * 2] * LOG2E; piz = 1.f / stats[qq * 2 + 1];
+                pl = __builtin_fmaf(stats[qq * 2], LOG2E, __builtin_amdgcn_logf(stats[qq * 2 + 1]));
                 if (MODE == M_DF) pdl = delta[qq];
             }
         }
     };
+    ASTAMP(0);
     issue(0);
+
+    // one 32-row step, phase by phase (K steps side by side): row offset of step k = k * SW * 32 (+ `extra` rows, run time)
+    auto run_steps = [&](auto KC, int extra) {
+        constexpr int K = decltype(KC)::value;
+        const unsigned char* pvs = a_vs + extra * RB;
+        const unsigned char* pts = a_ts + extra * TS;
+        const unsigned char* ptt = a_trt + extra * TS;
+        const unsigned char* ptv = a_trv + extra * RB;
+        const float* plse = a_l + extra;
+        const float* pdel = a_d + extra;
+        f32x4 S[K][2];
+        // ---- score tiles: rows = sweep positions, columns = own positions
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(pvs + (k * SW * 32 + t * 16) * RB);
+                S[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, vo, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            }
+        // ---- d(beta)[sweep][own] = sum_c T_sweep[c] * T_own[c]  (modes DG / DF)
+        f32x4 D[ACC_C ? 1 : K][2];
+        if constexpr (!ACC_C) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    D[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KSC; ++ks) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(pts + (k * SW * 32 + t * 16) * TS + ks * 64);
+                        D[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, to[ks], D[k][t], 0, 0, 0);
+                    }
+                }
+        }
+        // ---- P = exp(s - m) / Z = exp2(s log2e - lse2)   (lane: rows 4*lg + r of each tile, column lr)
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 ll;
+                if constexpr (OWN_I) ll = f32x4{olse, olse, olse, olse};
+                else ll = *reinterpret_cast<const f32x4*>(plse + k * SW * 32 + t * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[k][t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[k][t][r], LOG2E, -ll[r]));
+                if constexpr (!ACC_C) {
+                    f32x4 dl;
+                    if constexpr (OWN_I) dl = f32x4{odl, odl, odl, odl};
+                    else dl = *reinterpret_cast<const f32x4*>(pdel + k * SW * 32 + t * 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) S[k][t][r] *= (D[k][t][r] - dl[r]);
+                }
+            }
+        // ---- second product: the two tiles of a step are the 8 k-values of its B operand
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bf16x8 bop = pack8(S[k][0], S[k][1]);
+            if constexpr (ACC_C) {
+#pragma unroll
+                for (int ct = 0; ct < CTC; ++ct) {
+                    const unsigned char* base = ptt + (k * SW * 32) * TS + ct * 32;
+                    const bf16x8 a = tr_pair(base, base + 16 * TS);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bop, acc[ct], 0, 0, 0);
+                }
+            } else {
+                const unsigned char* base = ptv + (k * SW * 32) * RB;
+                const bf16x8 a = tr_pair(base, base + 16 * RB);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bop, acc[0], 0, 0, 0);
+            }
+        }
+    };
 
     for (int r0 = 0; r0 < N; r0 += CHUNK) {
         __syncthreads();                                          // the previous chunk has been consumed
 #pragma unroll
         for (int it = 0; it < NV; ++it) {
-            const int idx = tid + it * NT, r = idx / (DS / 8), c = idx % (DS / 8);
-            if (idx < CHUNK * (DS / 8)) *reinterpret_cast<bf16x8*>(vs + r * RB + c * 16) = pv[it];
+            const int idx = tid + it * NT, r = idx / KG, c = idx % KG;
+            if (idx < CHUNK * KG) *reinterpret_cast<bf16x8*>(vs + r * RB + c * 16) = pv[it];
         }
 #pragma unroll
         for (int it = 0; it < NTT; ++it) {
             const int idx = tid + it * NT, r = idx / (CS / 8), c = idx % (CS / 8);
             if (idx < CHUNK * (CS / 8)) *reinterpret_cast<bf16x8*>(ts + r * TS + c * 16) = ptn[it];
         }
-        if (!OWN_I && tid < CHUNK) { st_m[tid] = pm; st_z[tid] = piz; st_d[tid] = pdl; }
+        if (!OWN_I && tid < CHUNK) { st_l[tid] = pl; st_d[tid] = pdl; }
         __syncthreads();
+        if (r0 < 6 * CHUNK) ASTAMP(1 + 2 * (r0 / CHUNK));
         if (r0 + CHUNK < N) issue(r0 + CHUNK);
 
         const int nstep = min(CHUNK, ((N - r0 + 31) / 32) * 32) / 32;
-        for (int st = part_id; st < nstep; st += SW) {
-            const int s0 = st * 32;
-            // ---- two 16x16 score tiles: rows = sweep positions, columns = own positions
-            f32x4 S[2];
+        if (nstep == NSTEP) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int row = s0 + t * 16 + lr;
-                bf16x8 a = *reinterpret_cast<const bf16x8*>(vs + (lg < DS / 8 ? row * RB + lg * 16 : zoff));
-                S[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, vo, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            }
-            // ---- P = exp(s - m) / Z  (lane: rows 4*lg + r of each tile, column lr)
-            f32x4 P[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f32x4 mm, zz;
-                if constexpr (OWN_I) { mm = f32x4{om, om, om, om}; zz = f32x4{oiz, oiz, oiz, oiz}; }
-                else {
-                    mm = *reinterpret_cast<const f32x4*>(st_m + s0 + t * 16 + lg * 4);
-                    zz = *reinterpret_cast<const f32x4*>(st_z + s0 + t * 16 + lg * 4);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) P[t][r] = __builtin_amdgcn_exp2f(S[t][r] * LOG2E - mm[r]) * zz[r];
-            }
-            if constexpr (ACC_C) {
-                const bf16x8 bop = pack8(P[0], P[1]);
-                const unsigned char* base = ts + (s0 + lg * 4 + q4) * TS + p4 * 8;
-#pragma unroll
-                for (int ct = 0; ct < CTC; ++ct) {
-                    bf16x8 a = tr_pair(base + ct * 32, base + 16 * TS + ct * 32);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bop, acc[ct], 0, 0, 0);
-                }
-            } else {
-                // d(beta)[sweep][own] = sum_c T_sweep[c] * T_own[c]
-                f32x4 D[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    D[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    const unsigned char* rowp = ts + (s0 + t * 16 + lr) * TS + lg * 16;
-#pragma unroll
-                    for (int ks = 0; ks < KSC; ++ks) {
-                        bf16x8 a = *reinterpret_cast<const bf16x8*>(rowp + ks * 64);
-                        D[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, to[ks], D[t], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    f32x4 dl;
-                    if constexpr (OWN_I) dl = f32x4{odl, odl, odl, odl};
-                    else dl = *reinterpret_cast<const f32x4*>(st_d + s0 + t * 16 + lg * 4);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) P[t][r] *= (D[t][r] - dl[r]);
-                }
-                const bf16x8 bop = pack8(P[0], P[1]);
-                const unsigned char* base = vs + (s0 + lg * 4 + q4) * RB + p4 * 8;
-                bf16x8 a = tr_pair(base, base + 16 * RB);
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bop, acc[0], 0, 0, 0);
-            }
+            for (int u = 0; u < KW / KU; ++u) run_steps(std::integral_constant<int, KU>{}, u * KU * SW * 32);
+        } else {
+            for (int st = part_id; st < nstep; st += SW) run_steps(std::integral_constant<int, 1>{}, (st - part_id) * 32);
         }
+        if (r0 < 6 * CHUNK) { asm volatile("" :: "v"(acc[0][0])); ASTAMP(2 + 2 * (r0 / CHUNK)); }
     }
 
     // ---- the SW partial sums of a group of own positions: parts 1.. through LDS, part 0 adds them in order and finishes
     if constexpr (SW > 1) {
         __syncthreads();                                          // the last chunk has been consumed
-        static_assert((SW - 1) * 4 * NACC * 1024 <= TS_BYTES, "the partial sums are parked in the C-tensor tile");
+        static_assert((SW - 1) * OG * NACC * 1024 <= TS_BYTES, "the partial sums are parked in the C-tensor tile");
         f32x4* red = reinterpret_cast<f32x4*>(ts);                // [part - 1][wave][tile][lane]
         if (part_id > 0) {
 #pragma unroll
-            for (int i = 0; i < NACC; ++i) red[(((part_id - 1) * 4 + wave) * NACC + i) * 64 + lane] = acc[i];
+            for (int i = 0; i < NACC; ++i) red[(((part_id - 1) * OG + wave) * NACC + i) * 64 + lane] = acc[i];
         }
         __syncthreads();
         if (part_id > 0) return;
 #pragma unroll
         for (int p = 1; p < SW; ++p)
 #pragma unroll
-            for (int i = 0; i < NACC; ++i) acc[i] += red[(((p - 1) * 4 + wave) * NACC + i) * 64 + lane];
+            for (int i = 0; i < NACC; ++i) acc[i] += red[(((p - 1) * OG + wave) * NACC + i) * 64 + lane];
     }
+    ASTAMP(13);
     // ---- epilogue: lane (column own, q = lg) holds rows 4q + r of every accumulator tile
     if constexpr (ACC_C) {
         float part = 0.f;
@@ -366,29 +441,36 @@ __device__ __forceinline__ void attn_sweep_body(const bf16_t* __restrict__ f, co
 }
 
 template <int DS, int CS, int MODE>
-__global__ __launch_bounds__(256 * kSweepWays) void attn_sweep_mfma(const bf16_t* __restrict__ f, const bf16_t* __restrict__ g,
+__global__ __launch_bounds__(SweepGeom<CS>::NT, CS <= 64 ? SweepGeom<CS>::NT / 256 : 1) void attn_sweep_mfma(const bf16_t* __restrict__ f, const bf16_t* __restrict__ g,
                                                        const bf16_t* __restrict__ h, const bf16_t* __restrict__ xdy,
                                                        const float* __restrict__ stats, float* __restrict__ delta,
                                                        bf16_t* __restrict__ out, int N) {
-    attn_sweep_body<DS, CS, MODE, kSweepWays>(f, g, h, xdy, stats, delta, out, N);
+    attn_sweep_body<DS, CS, MODE>(f, g, h, xdy, stats, delta, out, N);
 }
 
 // dg and df need the same inputs (delta from the DH sweep) and nothing from each other: one launch, blockIdx.z picks
 // the mode, twice the workgroups in flight (the sweeps are latency-bound at 336 workgroups).
 template <int DS, int CS>
-__global__ __launch_bounds__(256 * kSweepWays) void attn_sweep_dgdf(const bf16_t* __restrict__ f, const bf16_t* __restrict__ g,
+__global__ __launch_bounds__(SweepGeom<CS>::NT, CS <= 64 ? SweepGeom<CS>::NT / 256 : 1) void attn_sweep_dgdf(const bf16_t* __restrict__ f, const bf16_t* __restrict__ g,
                                                        const bf16_t* __restrict__ h, const bf16_t* __restrict__ dy,
                                                        const float* __restrict__ stats, float* __restrict__ delta,
                                                        bf16_t* __restrict__ dg, bf16_t* __restrict__ df, int N) {
-    if (blockIdx.z == 0) attn_sweep_body<DS, CS, M_DG, kSweepWays>(f, g, h, dy, stats, delta, dg, N);
-    else attn_sweep_body<DS, CS, M_DF, kSweepWays>(f, g, h, dy, stats, delta, df, N);
+    if (blockIdx.z == 0) attn_sweep_body<DS, CS, M_DG>(f, g, h, dy, stats, delta, dg, N);
+    else attn_sweep_body<DS, CS, M_DF>(f, g, h, dy, stats, delta, df, N);
 }
 
 template <int DS, int CS, int MODE>
 int launch_sweep(hipStream_t s, const bf16_t* f, const bf16_t* g, const bf16_t* h, const bf16_t* xdy, const float* stats,
                  float* delta, bf16_t* out, int B, int N) {
-    constexpr int lds = (CHUNK * DS * 2 + 64) + CHUNK * (CS * 2 + 16) + 3 * CHUNK * 4;
-    hipLaunchKernelGGL((attn_sweep_mfma<DS, CS, MODE>), dim3(cdiv(N, 64), B), dim3(256 * kSweepWays), lds, s, f, g, h, xdy, stats, delta, out, N);
+    using G = SweepGeom<CS>;
+    constexpr int lds = G::template lds<DS>();
+    static bool attr_set = false;
+    if (!attr_set && lds > 60 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_sweep_mfma<DS, CS, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
+        if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_sweep_mfma<DS, CS, MODE>), dim3(cdiv(N, G::OG * 16), B), dim3(G::NT), lds, s, f, g, h, xdy, stats, delta, out, N);
     MSAU_CHECK_LAUNCH("attn_sweep_mfma");
     return 0;
 }
@@ -397,7 +479,7 @@ template <int DS, int CS>
 int fwd_t(hipStream_t s, const void* f, const void* g, const void* h, const void* x, void* y, float* stats, int B, int N) {
     const bf16_t* fp = static_cast<const bf16_t*>(f); const bf16_t* gp = static_cast<const bf16_t*>(g);
     const int Npad = (N + 15) & ~15;
-    const size_t lds = (size_t)Npad * DS * 2 + 64;
+    const size_t lds = (size_t)Npad * DS * 2 + kStatOG * 16 * 2 * 4;
     if (lds > 150 * 1024) return msau_set_error(MSAU_ERR_LDS, "selfattn: N=%d too large for the statistics kernel", N);
     static bool attr_set = false;
     if (!attr_set) {
@@ -406,7 +488,7 @@ int fwd_t(hipStream_t s, const void* f, const void* g, const void* h, const void
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((attn_stats_mfma<DS>), dim3(cdiv(N, 64), B), dim3(256), lds, s, fp, gp, stats, N);
+    hipLaunchKernelGGL((attn_stats_mfma<DS>), dim3(cdiv(N, kStatOG * 16), B), dim3(kStatNT), lds, s, fp, gp, stats, N);
     MSAU_CHECK_LAUNCH("attn_stats_mfma");
     return launch_sweep<DS, CS, M_O>(s, fp, gp, static_cast<const bf16_t*>(h), static_cast<const bf16_t*>(x), stats, nullptr,
                                      static_cast<bf16_t*>(y), B, N);
@@ -419,8 +501,15 @@ int bwd_t(hipStream_t s, const void* f, const void* g, const void* h, const void
     const bf16_t* hp = static_cast<const bf16_t*>(h); const bf16_t* dyp = static_cast<const bf16_t*>(dy);
     int rc = launch_sweep<DS, CS, M_DH>(s, fp, gp, hp, dyp, stats, ws, static_cast<bf16_t*>(dh), B, N);
     if (rc) return rc;
-    constexpr int lds = (CHUNK * DS * 2 + 64) + CHUNK * (CS * 2 + 16) + 3 * CHUNK * 4;
-    hipLaunchKernelGGL((attn_sweep_dgdf<DS, CS>), dim3(cdiv(N, 64), B, 2), dim3(256 * kSweepWays), lds, s, fp, gp, hp, dyp, stats, ws,
+    using G = SweepGeom<CS>;
+    constexpr int lds = G::template lds<DS>();
+    static bool attr_set = false;
+    if (!attr_set && lds > 60 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_sweep_dgdf<DS, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
+        if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_sweep_dgdf<DS, CS>), dim3(cdiv(N, G::OG * 16), B, 2), dim3(G::NT), lds, s, fp, gp, hp, dyp, stats, ws,
                        static_cast<bf16_t*>(dg), static_cast<bf16_t*>(df), N);
     MSAU_CHECK_LAUNCH("attn_sweep_dgdf");
     return 0;
@@ -432,7 +521,7 @@ int bwd_t(hipStream_t s, const void* f, const void* g, const void* h, const void
 // (the statistics kernel keeps f of one whole sample in LDS: larger images take the VALU kernels of attention.hip)
 int msau_attn_mfma_supported(int Ds, int Cs, int N) {
     if (!((Ds == 8 && (Cs == 32 || Cs == 64)) || (Ds == 16 && Cs == 128))) return 0;
-    return (size_t)((N + 15) & ~15) * Ds * 2 + 64 <= 150 * 1024;
+    return (size_t)((N + 15) & ~15) * Ds * 2 + kStatOG * 16 * 2 * 4 <= 150 * 1024;
 }
 
 int msau_attn_mfma_fwd(hipStream_t s, const void* f, const void* g, const void* h, const void* x, void* y, float* stats,

@@ -21,7 +21,15 @@ struct LeanArgs {
     unsigned mag_tx, mag_ty;                     // ceil(2^32 / tiles_x), ceil(2^32 / tiles_y)
     int per_xcd;                                 // tiles per XCD chunk (0: plain grid-stride tile order)
     int ct_total;                                // SPLIT: 16-row output-channel tiles of the whole conv (grid.y of them)
+#ifdef MSAU_STAMPS
+    unsigned long long* stamps;                  // diagnostic build only: 8 words per workgroup (s_memrealtime at phase ends)
+#endif
 };
+#ifdef MSAU_STAMPS
+#define STAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 
 template <typename T, int CIN8, int CT, int KS, bool DUAL, int DIL = 1, int WGW = 1, int STRIDE = 1>
 struct LeanCfg {
@@ -67,6 +75,7 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
     static_assert(!IDS || (!DUAL && STRIDE == 1 && UPS == 1 && !DOUT && !SPLIT), "id-mask input: plain single-source instances");
     static_assert(!SPLIT || (CT == 1 && !DUAL && !DOUT && WGW == 1), "SPLIT instances are single-source, one tile per workgroup");
     static_assert((STRIDE == 1 && UPS == 1) || (!DUAL && !DOUT && WGW == 1 && DIL == 1 && STRIDE * UPS == 2), "strided / upsampling instances");
+    STAMP(0);
     const int cty = SPLIT ? (int)blockIdx.y : 0;                 // this workgroup's channel tile
     const int CTT = SPLIT ? a.ct_total : CT;                     // channel tiles of the conv
     using Cfg = LeanCfg<T, CIN8, CT, KS, DUAL, DIL, WGW, STRIDE>;
@@ -124,6 +133,7 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
     constexpr int NIT = (NITEMS + NT - 1) / NT;
     constexpr int NSRC = DUAL ? 2 : 1;
     constexpr bool PIPE = IDS || NIT * NSRC <= 6;
+    constexpr bool OPF = CIN8 >= 4 && !DOUT && EPI != EPI_HEAD && EPI != EPI_LRN;     // epilogue operands prefetched (levels 2-3)
     V8 pre[IDS ? 1 : NSRC][IDS ? 1 : NIT];
     constexpr int NIDS = (Cfg::NPIX + NT - 1) / NT;            // id-mask input: tile pixels per thread
     int pre_id[IDS ? NIDS : 1];
@@ -212,7 +222,10 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
         tend = min(a.ntiles, (xcd + 1) * a.per_xcd);
         tstep = gridDim.x >> 3;
     }
-    if (PIPE && tile0 < tend) issue_loads(tile0);
+    // the first tile's loads go out ahead of the weight loads in EVERY instance: where a tile is too large for the register
+    // pipeline (!PIPE: the 64-channel and dilated level-3 tiles) the kernel used to fetch the weights, wait, write them to LDS
+    // and only then ask for its one tile -- two memory round trips of ~1 us each in a launch of 5 us (phase stamps, round 4)
+    if (tile0 < tend) issue_loads(tile0);
     if constexpr (!Cfg::WREG) {
         // weights -> LDS, behind the first tile's loads and up to 8 loads in flight per thread.  As a plain loop this was
         // load -> wait -> write per 256 x 16 bytes BEFORE the first tile was even requested: 3 (32 -> 16 rows, 3x3) to 18
@@ -242,14 +255,39 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
         }
     }
 
+    STAMP(1);
     for (int tile = tile0; tile < tend; tile += tstep) {
         int b, oy0, ox0;
         decode(tile, b, oy0, ox0);
         __syncthreads();                                       // previous tile's fragment reads are done
-        if (!PIPE) issue_loads(tile);
+        if (!PIPE && tile != tile0) issue_loads(tile);
         write_lds();
         __syncthreads();
+        if (tile == tile0) STAMP(2);
         if (PIPE && tile + tstep < tend) issue_loads(tile + tstep);
+        // epilogue operands (mask / residual / accumulate tensors) of the small-image instances: requested BEFORE the MFMAs,
+        // consumed after them -- loaded inside the epilogue they were a third serial round trip (1.0 us of a 6.5 us launch)
+        const int oyw = oy0 + wave * 4;
+        V4 o_ma[OPF ? CT : 1][4], o_add[OPF ? CT : 1][4], o_acc[OPF ? CT : 1][4], o_mb[OPF ? CT : 1][4];
+        if constexpr (OPF) {
+            if ((flags & (MSAU_CONV_MASK_A | MSAU_CONV_ADD | MSAU_CONV_ACCUM | MSAU_CONV_MASK_B)) && ox0 + cwt * 16 + lr < d.Wout) {
+                const char* y = static_cast<const char*>(d.y) + ((long long)(b * d.Hout + oyw)) * a.out_row + (long long)ox0 * a.out_px;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    if (lg * (CTT * 4) + (cty + ct) * 4 >= Cout) continue;
+#pragma unroll
+                    for (int pt = 0; pt < 4; ++pt) {
+                        if (oyw + pt < d.Hout) {                       // scalar
+                            const char* yp = y + (unsigned)(lane_out + ct * 4 * ESZ + pt * a.out_row);
+                            if (flags & MSAU_CONV_MASK_A) o_ma[ct][pt] = *reinterpret_cast<const V4*>(yp + delta_ma);
+                            if (flags & MSAU_CONV_ADD) o_add[ct][pt] = *reinterpret_cast<const V4*>(yp + delta_add);
+                            if (flags & MSAU_CONV_ACCUM) o_acc[ct][pt] = *reinterpret_cast<const V4*>(yp);
+                            if (flags & MSAU_CONV_MASK_B) o_mb[ct][pt] = *reinterpret_cast<const V4*>(yp + delta_mb);
+                        }
+                    }
+                }
+            }
+        }
 
         f32x4 acc[CT][4];
 #pragma unroll
@@ -274,7 +312,7 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
         }
 
         // ---- epilogue: lane (pixel lr of row ty, q = lg) owns channels q*CT*4 + ct*4 + {0..3}
-        const int oyw = oy0 + wave * 4;
+        if (tile == tile0) { asm volatile("" :: "v"(acc[0][0][0])); STAMP(3); }
         if constexpr (DOUT) {
             // two output tensors (MSAU_CONV_DOUT): Cout = 2 * CT*8, so lane groups q = 0,1 hold the channels of y and
             // q = 2,3 those of y2; flags, base and mask pointers are picked per lane
@@ -351,17 +389,20 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
                         f32x4 v = acc[ct][pt] + bv[ct];
                         if (flags & (MSAU_CONV_MASK_A | MSAU_CONV_ADD | MSAU_CONV_ACCUM | MSAU_CONV_RELU_OUT | MSAU_CONV_MASK_B)) {
                             if (flags & MSAU_CONV_MASK_A) {
-                                V4 m = *reinterpret_cast<const V4*>(yp + delta_ma);
+                                V4 m;
+                                if constexpr (OPF) m = o_ma[ct][pt]; else m = *reinterpret_cast<const V4*>(yp + delta_ma);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : 0.f;
                             }
                             if (flags & MSAU_CONV_ADD) {
-                                V4 r = *reinterpret_cast<const V4*>(yp + delta_add);
+                                V4 r;
+                                if constexpr (OPF) r = o_add[ct][pt]; else r = *reinterpret_cast<const V4*>(yp + delta_add);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
                             }
                             if (flags & MSAU_CONV_ACCUM) {
-                                V4 r = *reinterpret_cast<const V4*>(yp);
+                                V4 r;
+                                if constexpr (OPF) r = o_acc[ct][pt]; else r = *reinterpret_cast<const V4*>(yp);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
                             }
@@ -370,7 +411,8 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
                                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                             }
                             if (flags & MSAU_CONV_MASK_B) {
-                                V4 m = *reinterpret_cast<const V4*>(yp + delta_mb);
+                                V4 m;
+                                if constexpr (OPF) m = o_mb[ct][pt]; else m = *reinterpret_cast<const V4*>(yp + delta_mb);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : 0.f;
                             }
@@ -517,6 +559,15 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
             }
         }
     }
+#ifdef MSAU_STAMPS
+    if (a.stamps && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(4);
+        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 5] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 }
 
 
@@ -963,6 +1014,9 @@ int msau_conv_lean_try(hipStream_t s, int dtype, const msau_conv_desc* d, int kc
     a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
     a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
     a.ct_total = CT;
+#ifdef MSAU_STAMPS
+    a.stamps = std::getenv("MSAU_STAMP_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(std::getenv("MSAU_STAMP_PTR"), nullptr, 0)) : nullptr;
+#endif
     if (d->stride * d->ups == 2)
         return dtype == MSAU_F32 ? lean_strided<float>(s, a, cin8, CT, d->ups == 2) : lean_strided<bf16_t>(s, a, cin8, CT, d->ups == 2);
     if (d->flags & MSAU_CONV_IDS) {                              // id-mask input: the 64 -> 8/16 3x3 first conv (ids_capable)
