@@ -40,7 +40,8 @@ int msau_version(void);
 /* sizeof() of the structs below as the library was compiled, for bindings that mirror them (a mirror that is too short
  * makes the library read past it): which = 0 msau_conv_desc, 1 msau_wgrad_desc, 2 msau_pack_entry, 3 msau_unpack_entry,
  * 4 msau_op, 5 msau_lrn_args, 6 msau_pool_args, 7 msau_attn_args, 8 msau_csum_args, 9 msau_reduce_args,
- * 10 msau_conv_pack_geom, 11 msau_wgrad_geom, 12 msau_conv_pair_desc, 13 msau_box_args, 14 msau_allreduce_args; -1 for anything else. */
+ * 10 msau_conv_pack_geom, 11 msau_wgrad_geom, 12 msau_conv_pair_desc, 13 msau_box_args, 14 msau_allreduce_args, 15 msau_owner_ctx;
+ * -1 for anything else. */
 int msau_sizeof(int which);
 
 /* ------------------------------------------------------------------------------------------
@@ -529,11 +530,14 @@ typedef struct {
     const int32_t* boxes;       /* [n_boxes][6] = sample, y0, y1, x0, x1, value (= row of feats)                               */
     const float* feats;         /* [n_vec][C] fp32 feature table                                                              */
     const float* w;             /* the conv's fp32 master weight, OIHW [8][C][3][3] (rounded to the storage type on the fly)   */
-    float* wt;                  /* workspace, max(C, 32) * 72 floats (the weight re-ordered and rounded for the table product)  */
+    float* wt;                  /* workspace, wt_floats >= 72 * roundup(C, 32) floats (the weight re-ordered and rounded for the table
+                                   product: fp32 storage uses 72 * C floats, bf16 storage 80 * roundup(C, 32) bf16 values)          */
     float* table;               /* workspace, n_vec * 72 floats  (forward)                                                    */
     float* sums;                /* workspace, n_boxes * 72 floats (weight gradient)                                           */
     float* csum;                /* workspace, csum_blocks * 8 floats (bias gradient partials, msau_channel_sum)               */
     int32_t n_boxes, n_vec, C, csum_blocks;
+    int32_t wt_floats;          /* floats the caller allocated behind `wt`: the launch refuses a workspace that is too small      */
+    int32_t reserved0;
 } msau_owner_ctx;
 
 int msau_owner_slabs(const msau_wgrad_desc* d);   /* slabs an MSAU_CONV_OWNER weight gradient of this descriptor writes (<= d->nslabs) */

@@ -107,7 +107,7 @@ class AllreduceArgs(C.Structure):
 
 class OwnerCtx(C.Structure):
     _fields_ = [(n, vp) for n in ("owner", "boxes", "feats", "w", "wt", "table", "sums", "csum")] + \
-               [(n, i32) for n in ("n_boxes", "n_vec", "C", "csum_blocks")]
+               [(n, i32) for n in ("n_boxes", "n_vec", "C", "csum_blocks", "wt_floats", "reserved0")]
 
 
 OP_SIDE = 0x100

@@ -26,6 +26,9 @@ EXTRA_FLAGS = {"elementwise.hip": ["-Xclang", "-target-feature", "-Xclang", "-pa
                # ... and, since round 3 put the LRN backward into the residual pair's epilogue (MSAU_PAIR_LRN_BWD: the same adjoint-window
                # chains as lrn_fast_kernel, beside the same side-stream kernels), WITHOUT packed-fp32 instructions like elementwise.hip:
                # the compiler had produced 31 op_sel'd v_pk_*_f32 in exactly those two instances (tests/test_host_cpu.py reads the ISA)
+               # the box-list-fed first conv (cfg 4's bf16 train path, beside the same side-stream kernels): its fp32 partial-sum loops
+               # compiled to 247 packed-fp32 instructions, 91 of them with op_sel_hi -- the pattern the rule above is about
+               "ownerconv.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
                # attention on the matrix cores: MFMA results in VGPRs as well (the statistics kernel read every score back with
                # v_accvgpr_read: a quarter of its vector instructions)
                "attention_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],

@@ -251,6 +251,10 @@ int msau_ownerconv_fwd(hipStream_t s, int dtype, const msau_conv_desc* d) {
     const msau_owner_ctx* c = static_cast<const msau_owner_ctx*>(d->x1);
     MSAU_CHECK_ARG(c && c->owner && c->feats && c->w && c->wt && c->table && c->n_vec >= 0 && c->n_boxes >= 0 && (c->n_boxes == 0 || c->boxes) &&
                    c->C > 0 && c->C <= d->C1, "conv2d: bad MSAU_CONV_OWNER context");
+    // the re-ordered weight: 72 * C floats (fp32 storage) or 80 * roundup(C, 32) bf16 values -- the caller says what it allocated
+    const int64_t wt_need = dtype == MSAU_F32 ? (int64_t)72 * c->C : (int64_t)40 * roundup(c->C, 32);
+    MSAU_CHECK_ARG(c->wt_floats >= wt_need, "conv2d: MSAU_CONV_OWNER workspace wt holds %d floats, %lld needed (72 * roundup(C, 32) always suffices)",
+                   c->wt_floats, (long long)wt_need);
     const int64_t npix = (int64_t)d->B * d->Hout * d->Wout;
     int64_t blocks = cdiv64(npix, 256);
     if (blocks > 16384) blocks = 16384;
@@ -261,7 +265,7 @@ int msau_ownerconv_fwd(hipStream_t s, int dtype, const msau_conv_desc* d) {
             hipLaunchKernelGGL(owner_wt_kernel<float>, gw, dim3(256), 0, s, c->w, c->wt, c->C);
             hipLaunchKernelGGL(owner_table_kernel<float>, gt, dim3(64), 0, s, c->wt, c->feats, c->table, c->n_vec, c->C);
         } else {
-            const int Cp = roundup(c->C, 32);                              // (wt holds max(C, 32) * 72 floats >= 80 * Cp bf16)
+            const int Cp = roundup(c->C, 32);                              // (80 * Cp bf16 values: checked against wt_floats above)
             hipLaunchKernelGGL(owner_wj_kernel, dim3(cdiv(80 * Cp, 256)), dim3(256), 0, s, c->w, reinterpret_cast<bf16_t*>(c->wt), c->C, Cp);
             hipLaunchKernelGGL(owner_table_mfma_kernel, dim3(cdiv(c->n_vec, 16), 5), dim3(64), 0, s, reinterpret_cast<const bf16_t*>(c->wt), c->feats, c->table, c->n_vec, c->C, Cp);
         }

@@ -15,7 +15,7 @@ int msau_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* msau_last_error(void) { return g_err; }
-extern "C" int msau_version(void) { return 5; }
+extern "C" int msau_version(void) { return 6; }
 
 // sizeof() of every struct that crosses the ABI by pointer, so that a binding can check its mirror (tests/test_host_cpu.py)
 extern "C" int msau_sizeof(int which) {

@@ -554,7 +554,10 @@ class TrainEngine:
         Python between the launches.  gloo groups (CPU tests, several ranks on one card) and MSAU_DP_NATIVE=0 keep
         msau_amd/dp.py::GradSync."""
         import torch.distributed as dist
-        if not self.sync.active or self.use_graph or os.environ.get("MSAU_DP_NATIVE", "1") == "0":
+        # Opt-in (MSAU_DP_NATIVE=1) since round 4: the path has only ever run at world size 1 on the one-GPU boxes this tree is
+        # measured on (tests/test_dp_gpu.py: bit-equal to the torch.distributed path there, where an all-reduce is the identity);
+        # until a run with >= 2 RCCL ranks has shown the same, a multi-GPU job takes the GradSync path that the 2-rank tests cover.
+        if not self.sync.active or self.use_graph or os.environ.get("MSAU_DP_NATIVE", "0") != "1":
             return
         if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != "nccl":
             return
@@ -582,7 +585,11 @@ class TrainEngine:
         # MSAU_DP_BUCKETS=1: ONE all-reduce of the whole flat gradient after the backward instead of a bucket per stage
         # issued while the earlier stages' backward still runs (fewer launches and joins, no overlap)
         self._ar_native = False
-        if self._comm is not None and self.sync.active and plan.overlap_wgrad:
+        # the native sequence needs one bucket per backward segment + the end-conv tail (stage_buckets drops EMPTY buckets: then
+        # the counts differ and the exchange stays with GradSync), and the per-launch profiling path does not run sequences at all
+        native = self._comm is not None and self.sync.active and plan.overlap_wgrad and L._profiler is None \
+            and len(self.sync.buckets) == len(plan._bwd_segs) + 1
+        if native:
             if getattr(plan, "_dp_flat", None) != self.flat_grad.data_ptr() or getattr(plan, "_dp_comm", None) != self._comm:
                 plan.set_native_dp(self._comm, self._comm_stream, self.sync.buckets, self.flat_grad)
                 plan._dp_comm = self._comm

@@ -1458,14 +1458,14 @@ class Plan:
         n_vec = int(feats.shape[0])
         ctx = L.OwnerCtx()
         blocks = max(1, min(256, c.out.npix // 1024))
-        wt = torch.empty((max(self.x_in.C, 32) * 72,), dtype=torch.float32, device=self.device)
+        wt = torch.empty((_ru(self.x_in.C, 32) * 72,), dtype=torch.float32, device=self.device)      # msau_owner_ctx.wt_floats
         table = torch.empty((max(n_vec, 1) * 72,), dtype=torch.float32, device=self.device)
         sums = torch.empty((max(n_boxes, 1) * 72,), dtype=torch.float32, device=self.device)
         csum = torch.empty((blocks * 8,), dtype=torch.float32, device=self.device)
         ctx.owner, ctx.boxes, ctx.feats = owner.data_ptr(), (boxes.data_ptr() if n_boxes else None), feats.data_ptr()
         ctx.w = flat_params.data_ptr() + 4 * self.poff[c.wname]
         ctx.wt, ctx.table, ctx.sums, ctx.csum = wt.data_ptr(), table.data_ptr(), sums.data_ptr(), csum.data_ptr()
-        ctx.n_boxes, ctx.n_vec, ctx.C, ctx.csum_blocks = n_boxes, n_vec, self.x_in.C, blocks
+        ctx.n_boxes, ctx.n_vec, ctx.C, ctx.csum_blocks, ctx.wt_floats = n_boxes, n_vec, self.x_in.C, blocks, wt.numel()
         c.fdesc.flags |= L.CONV_OWNER
         c.fdesc.x1 = C.addressof(ctx)
         if c.wdesc is not None:

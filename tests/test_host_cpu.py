@@ -247,7 +247,7 @@ def test_isa_of_the_built_kernels_has_no_cross_half_packed_fp32_adds(tmp_path):
     pattern from coming back unnoticed:
       * elementwise.o has NO packed-fp32 instruction at all (the flag is in force);
       * the translation units of the bf16 train path that run on the main stream beside the weight gradients (conv, conv_lean,
-        conv_pair, conv_rows, wgrad_lean, conv_wgrad, attention_mfma, pack, raster) have NO packed-fp32 instruction with
+        conv_pair, conv_rows, wgrad_lean, conv_wgrad, attention_mfma, pack, raster, ownerconv) have NO packed-fp32 instruction with
         op_sel / op_sel_hi;
       * attention.hip (the fp32-storage VALU attention) and boxconv.hip do use them -- known, counted, outside the bf16 path."""
     import shutil
@@ -272,7 +272,7 @@ def test_isa_of_the_built_kernels_has_no_cross_half_packed_fp32_adds(tmp_path):
         lines = [ln for ln in dis.splitlines() if pk.search(ln)]
         counts[name] = (len(lines), sum(1 for ln in lines if "op_sel" in ln))
     assert counts["elementwise"] == (0, 0), counts["elementwise"]
-    clean = ("conv", "conv_lean", "conv_pair", "conv_rows", "wgrad_lean", "conv_wgrad", "attention_mfma", "pack", "raster")
+    clean = ("conv", "conv_lean", "conv_pair", "conv_rows", "wgrad_lean", "conv_wgrad", "attention_mfma", "pack", "raster", "ownerconv")
     assert all(counts[n][1] == 0 for n in clean), {n: counts[n] for n in clean}
     assert counts["conv_lean"][0] > 0                 # the check does see packed instructions where they are
     assert counts["attention"][1] > 0 or counts["boxconv"][1] >= 0

@@ -489,7 +489,7 @@ def test_prefetched_box_batches_train_exactly_like_step_boxes(dense, monkeypatch
     assert torch.equal(res["prefetch"][1], res["plain"][1]) and torch.equal(res["prefetch"][2], res["plain"][2])
 
 
-@pytest.mark.parametrize("dtype,C", [("fp32", 24), ("bf16", 24), ("bf16", 100)])
+@pytest.mark.parametrize("dtype,C", [("fp32", 24), ("bf16", 24), ("bf16", 33), ("bf16", 100)])     # 33: roundup(C, 32) > max(C, 32) -- the workspace
 def test_first_conv_fed_with_box_lists_matches_the_painted_grid(dtype, C, monkeypatch):
     """MSAU_CONV_OWNER (csrc/ownerconv.hip): TrainEngine.step_boxes with a feature table never paints the embedding grid -- the
     first conv gathers per-tap partial products T[feature row][tap][co], its weight gradient sums the output gradient per box
@@ -537,3 +537,77 @@ def test_first_conv_fed_with_box_lists_matches_the_painted_grid(dtype, C, monkey
     lab = torch.randint(0, ncls, (B, H, W), device="cuda")
     l0 = float(eng.step(x, lab))
     assert np.isfinite(l0)
+
+
+def _paint_dense_cpu(boxes, feats, B, H, W):
+    """CPU painter of a box list, as data_generator_funsd_bert.py:64-93 leaves the grid: boxes in order, later ones overwrite,
+    numpy slicing clips at the edge; value = row of the feature table"""
+    C = feats.shape[1]
+    grid = np.zeros((B, C, H, W), np.float32)
+    for b, y0, y1, x0, x1, v in boxes:
+        grid[b, :, max(y0, 0):max(y1, 0), max(x0, 0):max(x1, 0)] = feats[v][:, None, None]
+    return grid
+
+
+def _paint_labels_cpu(labs, B, H, W):
+    lab = np.zeros((B, H, W), np.int64)
+    for b, y0, y1, x0, x1, v in labs:
+        lab[b, max(y0, 0):max(y1, 0), max(x0, 0):max(x1, 0)] = v
+    return lab
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_box_list_fed_step_at_the_size_of_baseline_config_4_vs_oracle(dtype):
+    """BASELINE configs[3] at its own size through the path that carries its headline number: 768 embedding channels (12 chunks
+    of 64), 336x256, 2 stages, TrainEngine.step_boxes with a feature table (MSAU_CONV_OWNER: the grid is never painted) --
+    against the CPU oracle's forward + loss + backward on the grid a CPU painter paints from the same boxes
+    (data_generator_funsd_bert.py:64-93,240): the loss, the first conv's weight and bias gradient, every other parameter
+    gradient.  Text-line-like boxes, some overlapping, some over the edge, one sample nearly empty."""
+    from oracle import msau_oracle as O
+    B, H, W, C, ncls, stages = 2, 336, 256, 768, 5, 2
+    rng = np.random.default_rng(44)
+    boxes, labs = [], []
+    for b, nlines in ((0, 70), (1, 3)):
+        for i in range(nlines):
+            h = int(rng.integers(2, 7)); w = int(rng.integers(12, 120))
+            y0 = int(rng.integers(-2, H - 2)); x0 = int(rng.integers(-6, W - 8))
+            boxes.append((b, y0, y0 + h, x0, x0 + w, len(boxes)))
+            labs.append((b, y0, y0 + h, x0, x0 + w, int(rng.integers(1, ncls))))
+    boxes, labs = np.asarray(boxes, np.int32), np.asarray(labs, np.int32)
+    feats = rng.standard_normal((len(boxes), C)).astype(np.float32)
+    if dtype == "bf16":
+        feats = torch.from_numpy(feats).bfloat16().float().numpy()          # bf16-representable: both sides see the same inputs
+    cfg = dict(O.DEFAULT_CFG, channels=C, num_blocks=stages)
+    sd = O.init_params(cfg, seed=45)
+    kw = dict(scale_space_num=4, res_depth=2, featRoot=8, final_act="softmax", num_blocks=stages, dtype=dtype)
+    m = MSAUWrapper(C, ncls, kw)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    eng = TrainEngine(m)
+    loss = eng.step_boxes(boxes, labs, B, H, W, feats=feats)
+    torch.cuda.synchronize()
+    plan = m._plan_for_shape(B, H, W, torch.device("cuda", 0), True)
+    assert getattr(plan, "_owner_keep", None) is not None, "the box-list path did not take the first conv"
+    # the checker
+    x = torch.from_numpy(_paint_dense_cpu(boxes, feats, B, H, W))
+    label = torch.from_numpy(_paint_labels_cpu(labs, B, H, W))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lr, ar = O.msau_forward(leaves, x, cfg)
+    ref_loss = O.msau_loss(lr, ar, label)
+    ref_loss.backward()
+    # (bf16: the gradient that reaches the first conv has come back through ~40 bf16 layers -- the bound is the network's, as for every other
+    #  parameter; the fp32 case is what pins the box-list arithmetic itself)
+    ltol, gtol, ftol = (1e-4, 3e-3, 2e-3) if dtype == "fp32" else (3e-2, 1e-1, 1e-1)
+    assert abs(float(loss) - float(ref_loss)) < ltol * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    c = next(op for op in plan.ops if getattr(op, "x1", None) is plan.x_in)
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in leaves.values() if p.grad is not None)))
+    for k, off in m._poff.items():
+        ref = leaves[k].grad
+        got = eng.flat_grad[off:off + leaves[k].numel()].view(leaves[k].shape).float().cpu()
+        if ref is None:
+            assert float(got.abs().max()) == 0.0, k
+            continue
+        tol = ftol if k in (c.wname, c.bname) else gtol
+        if float(ref.norm()) > 1e-4 * gn:
+            assert err(got, ref, True) < tol, (k, err(got, ref, True))
+    assert abs(float(eng.grad_norm) - gn) < (2e-3 if dtype == "fp32" else 3e-2) * gn
