@@ -87,6 +87,14 @@ int conv_geom(int dtype, int C1, int C2, int Cout, int KH, int KW, int dil, int 
         g.ngroups = g.kchunk / 8;
         if (tile_geom(g, 1, KH, KW, dil, stride, ups).total <= 150 * 1024) best = Cin;
     }
+    // 64 -> 32 3x3 with dilation 8 (the DATA GRADIENT of the level-3 entry conv), bf16: two chunks of 32 channels for the chunked
+    // instance of conv_lean.hip (round 4; the generic choice was four chunks of 16 for the generic kernel: 0.2 TB/s)
+    if (!best && g.esz == 2 && C2 == 0 && Cin == 64 && g.CT == 2 && KH == 3 && KW == 3 && dil == 8 && stride == 1 && ups == 1) {
+        g.cch = 32;
+        g.kchunk = roundup(g.taps * 32, 32);
+        g.ngroups = g.kchunk / 8;
+        if (tile_geom(g, 1, KH, KW, dil, stride, ups).total <= 150 * 1024) best = 32;
+    }
     for (int pass = 0; pass < 2 && !best; ++pass) {
         for (int c = (Cin < 128 ? Cin : 128); c >= 8; c -= 8) {
             if (Cin % c) continue;

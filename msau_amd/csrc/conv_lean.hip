@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
         } else {
         // MSAU_CONV_POOL keeps the rounded results (0 where nothing is stored: the zero padding of the pool)
         constexpr bool POOL_OK = EPI == EPI_POOL;
-        static_assert(EPI == EPI_NONE || (CT <= 2 && !DOUT && STRIDE == 1 && UPS == 1), "fused epilogues: <= 2 channel tiles, one output");
+        static_assert(EPI == EPI_NONE || ((CT <= 2 || EPI == EPI_LRN) && !DOUT && STRIDE == 1 && UPS == 1), "fused epilogues: <= 2 channel tiles (LRN: 4), one output");
         V4 keep[POOL_OK ? CT : 1][4];
         if constexpr (POOL_OK) {
 #pragma unroll
@@ -576,13 +576,16 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
 // generic kernel took the launch at 1.4 TB/s.  Here a persistent workgroup walks the chunks of its 16 x 16 tile with the
 // accumulators in registers: per chunk one 18 x 18 x 64 input tile and one 16 x 576 weight block go through LDS, both
 // prefetched into registers while the previous chunk's 72 MFMAs per wave run.
-template <typename T>
+// Round 4: the same walk for the data gradient of the level-3 entry conv (64 -> 32, dilation 8: a 32 x 32 halo tile of 64 channels
+// plus the weights is 184 KB -- no single-chunk instance fits, and the generic kernel took the launch at 0.2 TB/s): C8CH 8-channel
+// groups per chunk, CT channel tiles, dilation DIL.
+template <typename T, int C8CH = 8, int CT = 1, int DIL = 1>
 __global__ __launch_bounds__(256) void conv_chunked_kernel(const LeanArgs a, const int nchunks) {
-    using Cfg = LeanCfg<T, 8, 1, 3, false>;
+    using Cfg = LeanCfg<T, C8CH, CT, 3, false, DIL>;
     typedef typename Vec8<T>::type V8;
     typedef typename Vec4<T>::type V4;
-    constexpr int ESZ = Cfg::ESZ, TI = Cfg::TIW, PS = Cfg::PS, NKS = Cfg::NKS, WS = Cfg::WS;
-    constexpr int NPIX = Cfg::NPIX, NITX = (NPIX * 8 + 255) / 256, WG8 = NKS * 4, NITW = (16 * WG8 + 255) / 256;
+    constexpr int ESZ = Cfg::ESZ, TI = Cfg::TIW, PS = Cfg::PS, NKS = Cfg::NKS, WS = NKS * 32 * ESZ + 16;
+    constexpr int NPIX = Cfg::NPIX, NITX = (NPIX * C8CH + 255) / 256, WG8 = NKS * 4, NITW = (CT * 16 * WG8 + 255) / 256;
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* lds_w = smem + Cfg::IN_BYTES;
     const msau_conv_desc& d = a.d;
@@ -592,13 +595,17 @@ __global__ __launch_bounds__(256) void conv_chunked_kernel(const LeanArgs a, con
     int koff[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-        const int G = ks * 4 + lg, tap = G >> 3, cg = G & 7;
+        const int G = ks * 4 + lg, tap = G / C8CH, cg = G - tap * C8CH;
         const int ky = tap / 3, kx = tap - ky * 3;
-        koff[ks] = (ky * TI + kx) * PS + cg * 8 * ESZ;
+        koff[ks] = G < 9 * C8CH ? (ky * DIL * TI + kx * DIL) * PS + cg * 8 * ESZ : 0;
     }
     const unsigned char* pixp = smem + ((wave * 4) * TI + lr) * PS;
-    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (d.bias && lg * 4 < d.Cout) bv = *reinterpret_cast<const f32x4*>(d.bias + lg * 4);
+    f32x4 bv[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        bv[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (d.bias && lg * (CT * 4) + ct * 4 < d.Cout) bv[ct] = *reinterpret_cast<const f32x4*>(d.bias + lg * (CT * 4) + ct * 4);
+    }
     const T* wp = static_cast<const T*>(d.wpack);
     V8 xr[NITX], wr[NITW];
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
@@ -612,37 +619,39 @@ __global__ __launch_bounds__(256) void conv_chunked_kernel(const LeanArgs a, con
 #pragma unroll
             for (int it = 0; it < NITX; ++it) {
                 const int idx = tid + it * 256;
-                const int pix = idx >> 3, cg = idx & 7;
+                const int pix = idx / C8CH, cg = idx - pix * C8CH;
                 const int iy = pix / TI, ix = pix - iy * TI;
                 const int vy = vy0 + iy, vx = vx0 + ix;
                 xr[it] = zero8<T>();
-                if (idx < NPIX * 8 && (unsigned)vy < (unsigned)d.Hin && (unsigned)vx < (unsigned)d.Win)
-                    xr[it] = *reinterpret_cast<const V8*>(xb + (unsigned)(vy * a.in_row1 + vx * a.in_px1 + (ch * 64 + cg * 8) * ESZ));
+                if (idx < NPIX * C8CH && (unsigned)vy < (unsigned)d.Hin && (unsigned)vx < (unsigned)d.Win)
+                    xr[it] = *reinterpret_cast<const V8*>(xb + (unsigned)(vy * a.in_row1 + vx * a.in_px1 + (ch * C8CH * 8 + cg * 8) * ESZ));
             }
 #pragma unroll
             for (int it = 0; it < NITW; ++it) {
                 const int idx = tid + it * 256;
                 const int r = idx / WG8, g8 = idx - r * WG8;
                 wr[it] = zero8<T>();
-                if (idx < 16 * WG8) wr[it] = load8<T>(wp + ((size_t)ch * 16 + r) * a.kchunk + g8 * 8);
+                if (idx < CT * 16 * WG8) wr[it] = load8<T>(wp + ((size_t)ch * CT * 16 + r) * a.kchunk + g8 * 8);
             }
         };
-        f32x4 acc[4];
+        f32x4 acc[CT][4];
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) acc[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
         issue(0);
         for (int ch = 0; ch < nchunks; ++ch) {
             __syncthreads();                                      // the previous chunk's fragments have been read
 #pragma unroll
             for (int it = 0; it < NITX; ++it) {
                 const int idx = tid + it * 256;
-                if (idx < NPIX * 8) *reinterpret_cast<V8*>(smem + (idx >> 3) * PS + (idx & 7) * 8 * ESZ) = xr[it];
+                if (idx < NPIX * C8CH) *reinterpret_cast<V8*>(smem + (idx / C8CH) * PS + (idx % C8CH) * 8 * ESZ) = xr[it];
             }
 #pragma unroll
             for (int it = 0; it < NITW; ++it) {
                 const int idx = tid + it * 256;
                 const int r = idx / WG8, g8 = idx - r * WG8;
-                if (idx < 16 * WG8) *reinterpret_cast<V8*>(lds_w + r * WS + g8 * 8 * ESZ) = wr[it];
+                if (idx < CT * 16 * WG8) *reinterpret_cast<V8*>(lds_w + r * WS + g8 * 8 * ESZ) = wr[it];
             }
             __syncthreads();
             if (ch + 1 < nchunks) issue(ch + 1);
@@ -652,26 +661,33 @@ __global__ __launch_bounds__(256) void conv_chunked_kernel(const LeanArgs a, con
                 V8 bfrag[4];
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) bfrag[pt] = *reinterpret_cast<const V8*>(p + pt * TI * PS);
-                const V8 af = *reinterpret_cast<const V8*>(lds_w + lr * WS + (ks * 32 + lg * 8) * ESZ);
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt) acc[pt] = mma8(af, bfrag[pt], acc[pt]);
+                for (int ct = 0; ct < CT; ++ct) {
+                    const V8 af = *reinterpret_cast<const V8*>(lds_w + (ct * 16 + lr) * WS + (ks * 32 + lg * 8) * ESZ);
+#pragma unroll
+                    for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = mma8(af, bfrag[pt], acc[ct][pt]);
+                }
             }
         }
         const int oyw = oy0 + wave * 4;
-        if (ox0 + lr < d.Wout && lg * 4 < d.Cout) {
-            char* y = static_cast<char*>(d.y) + ((long long)(b * d.Hout + oyw) * d.Wout + ox0 + lr) * a.out_px + lg * 4 * ESZ;
+        if (ox0 + lr < d.Wout) {
+            char* y = static_cast<char*>(d.y) + ((long long)(b * d.Hout + oyw) * d.Wout + ox0 + lr) * a.out_px;
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) {
-                if (oyw + pt < d.Hout) {
-                    f32x4 v = acc[pt] + bv;
-                    if (d.flags & MSAU_CONV_RELU_OUT) {
+            for (int ct = 0; ct < CT; ++ct) {
+                if (lg * (CT * 4) + ct * 4 >= d.Cout) continue;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                for (int pt = 0; pt < 4; ++pt) {
+                    if (oyw + pt < d.Hout) {
+                        f32x4 v = acc[ct][pt] + bv[ct];
+                        if (d.flags & MSAU_CONV_RELU_OUT) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                        }
+                        V4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
+                        *reinterpret_cast<V4*>(y + (long long)pt * a.out_row + (lg * (CT * 4) + ct * 4) * ESZ) = o;
                     }
-                    V4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
-                    *reinterpret_cast<V4*>(y + (long long)pt * a.out_row) = o;
                 }
             }
         }
@@ -864,6 +880,7 @@ static int lean_epi_case(int dtype, const msau_conv_desc* d, int CT, int epi) {
         if (c8 == 2 && CT == 2 && d->dil == 4 && d->Cout == 32) return 4;
         if (c8 == 2 && CT == 1 && d->dil == 1 && d->Cout == 16) return 5;
         if (c8 == 2 && CT == 2 && d->dil == 2 && d->Cout == 32) return 6;
+        if (c8 == 4 && CT == 4 && d->dil == 8 && d->Cout == 64 && dtype == MSAU_BF16) return 8;     // the level-3 entry conv (round 4)
         // the net's first conv (64 one-hot channels -> featRoot 8): measured 9 us SLOWER per step than the conv + the 8.4 us stand-alone
         // LRN launch (the epilogue instance loses more than the launch costs): off unless MSAU_LRN_FIRST=1
         if (c8 == 8 && CT == 1 && d->dil == 1 && d->Cout == 8) {                    // (one query per step: read the switch every time)
@@ -891,6 +908,7 @@ int lean_epi(hipStream_t s, const LeanArgs& a, int which) {
         case 5: return launch_lean<T, 2, 1, 3, false, 1, 1, false, false, 1, 1, EPI_LRN>(s, a);
         case 6: return launch_lean<T, 2, 2, 3, false, 2, 1, false, false, 1, 1, EPI_LRN>(s, a);
         case 7: return launch_lean<T, 8, 1, 3, false, 1, 1, false, false, 1, 1, EPI_LRN>(s, a);
+        case 8: if constexpr (sizeof(T) == 2) return launch_lean<T, 4, 4, 3, false, 8, 1, false, false, 1, 1, EPI_LRN>(s, a); else return 0;
         case 10: return launch_lean<T, 2, 1, 1, true, 1, 1, false, false, 1, 1, EPI_POOL>(s, a);
         case 11: return launch_lean<T, 4, 1, 1, true, 1, 1, false, false, 1, 1, EPI_POOL>(s, a);
         case 12: return launch_lean<T, 8, 2, 1, true, 1, 1, false, false, 1, 1, EPI_POOL>(s, a);
@@ -954,19 +972,48 @@ int msau_conv_lean_head_capable(int dtype, const msau_conv_desc* d, int nchunks,
 }
 
 // 1 = handled by conv_chunked_kernel, 0 = not this shape.  (cch / kchunk / nchunks: the generic geometry = the packed image.)
-int msau_conv_chunked_capable(int dtype, const msau_conv_desc* d, int cch, int nchunks, int CT) {
+//   variant 1: many 64-channel chunks -> one 16-row tile, 3x3 (the 768 -> 8 first conv of cfg 4)
+//   variant 2: two 32-channel chunks -> two 16-row tiles, 3x3 dilation 8, bf16 (the data gradient of the level-3 entry conv)
+static int chunked_variant(int dtype, const msau_conv_desc* d, int cch, int nchunks, int CT) {
     static const bool off = std::getenv("MSAU_CONV_CHUNKED") && std::getenv("MSAU_CONV_CHUNKED")[0] == '0';
-    if (off || nchunks < 2 || cch != 64 || CT != 1 || d->C2 || d->KH != 3 || d->KW != 3 || d->dil != 1 || d->stride != 1 || d->ups != 1) return 0;
-    if (d->Hin != d->Hout || d->Win != d->Wout || d->pad_t < 0 || d->pad_l < 0 || d->pad_t > 2 || d->pad_l > 2) return 0;
+    if (off || nchunks < 2 || d->C2 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->ups != 1) return 0;
+    if (d->Hin != d->Hout || d->Win != d->Wout || d->pad_t < 0 || d->pad_l < 0 || d->pad_t > 2 * d->dil || d->pad_l > 2 * d->dil) return 0;
     if (d->flags & ~MSAU_CONV_RELU_OUT) return 0;
     const int esz = dtype == MSAU_F32 ? 4 : 2;
     if ((int64_t)d->Hin * d->Win * d->C1 * esz >= (1ll << 31)) return 0;              // 32-bit offsets inside an image
     const int64_t ntiles = (int64_t)d->B * cdiv(d->Wout, 16) * cdiv(d->Hout, 16);
-    return ntiles >= 64 && ntiles < (1 << 20) && cdiv(d->Wout, 16) < 4096 && cdiv(d->Hout, 16) < 4096;
+    if (!(ntiles >= 64 && ntiles < (1 << 20) && cdiv(d->Wout, 16) < 4096 && cdiv(d->Hout, 16) < 4096)) return 0;
+    if (cch == 64 && CT == 1 && d->dil == 1) return 1;
+    if (cch == 32 && CT == 2 && d->dil == 8 && nchunks == 2 && dtype == MSAU_BF16) return 2;
+    return 0;
+}
+int msau_conv_chunked_capable(int dtype, const msau_conv_desc* d, int cch, int nchunks, int CT) {
+    return chunked_variant(dtype, d, cch, nchunks, CT) != 0;
+}
+
+template <typename T, int C8CH, int CT, int DIL>
+static int launch_chunked(hipStream_t s, const LeanArgs& a, int nchunks) {
+    using Cfg = LeanCfg<T, C8CH, CT, 3, false, DIL>;
+    constexpr int lds = Cfg::IN_BYTES + CT * 16 * (Cfg::NKS * 32 * Cfg::ESZ + 16);
+    static_assert(lds + 256 <= MSAU_LDS_LIMIT, "chunked conv: tile + weight chunk must fit the LDS");
+    static bool attr_set = false;
+    if (!attr_set && lds > 60 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_chunked_kernel<T, C8CH, CT, DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
+        if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_chunked: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    int per_cu = MSAU_LDS_LIMIT / (lds + 256);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
+    int grid = 256 * per_cu;
+    if (grid > a.ntiles) grid = a.ntiles;
+    hipLaunchKernelGGL((conv_chunked_kernel<T, C8CH, CT, DIL>), dim3(grid), dim3(256), lds, s, a, nchunks);
+    MSAU_CHECK_LAUNCH("conv_chunked_kernel");
+    return 1;
 }
 
 int msau_conv_chunked_try(hipStream_t s, int dtype, const msau_conv_desc* d, int cch, int kchunk, int nchunks, int CT) {
-    if (!msau_conv_chunked_capable(dtype, d, cch, nchunks, CT)) return 0;
+    const int variant = chunked_variant(dtype, d, cch, nchunks, CT);
+    if (!variant) return 0;
     const int esz = dtype == MSAU_F32 ? 4 : 2;
     LeanArgs a;
     a.d = *d;
@@ -977,23 +1024,12 @@ int msau_conv_chunked_try(hipStream_t s, int dtype, const msau_conv_desc* d, int
     a.ntiles = d->B * a.tiles_x * a.tiles_y;
     a.mag_tx = (unsigned)((0x100000000ull + a.tiles_x - 1) / a.tiles_x);
     a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
-    a.per_xcd = 0; a.ct_total = 1;
-    const int lds = dtype == MSAU_F32 ? LeanCfg<float, 8, 1, 3, false>::LDS : LeanCfg<bf16_t, 8, 1, 3, false>::LDS;
-    static bool attr_set[2] = {false, false};
-    const void* fn = dtype == MSAU_F32 ? reinterpret_cast<const void*>(&conv_chunked_kernel<float>) : reinterpret_cast<const void*>(&conv_chunked_kernel<bf16_t>);
-    if (!attr_set[dtype == MSAU_F32] && lds > 60 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
-        if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_chunked: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set[dtype == MSAU_F32] = true;
-    }
-    int per_cu = MSAU_LDS_LIMIT / (lds + 256);
-    per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
-    int grid = 256 * per_cu;
-    if (grid > a.ntiles) grid = a.ntiles;
-    if (dtype == MSAU_F32) hipLaunchKernelGGL(conv_chunked_kernel<float>, dim3(grid), dim3(256), lds, s, a, nchunks);
-    else hipLaunchKernelGGL(conv_chunked_kernel<bf16_t>, dim3(grid), dim3(256), lds, s, a, nchunks);
-    MSAU_CHECK_LAUNCH("conv_chunked_kernel");
-    return 1;
+    a.per_xcd = 0; a.ct_total = CT;
+#ifdef MSAU_STAMPS
+    a.stamps = nullptr;
+#endif
+    if (variant == 2) return launch_chunked<bf16_t, 4, 2, 8>(s, a, nchunks);
+    return dtype == MSAU_F32 ? launch_chunked<float, 8, 1, 1>(s, a, nchunks) : launch_chunked<bf16_t, 8, 1, 1>(s, a, nchunks);
 }
 
 int msau_conv_lean_try(hipStream_t s, int dtype, const msau_conv_desc* d, int kchunk, int nchunks, int CT) {
