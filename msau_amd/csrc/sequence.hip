@@ -162,7 +162,19 @@ extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_strea
     static thread_local std::vector<hipEvent_t> pool;          // timing-disabled events, reused across calls
     hipStream_t ms = static_cast<hipStream_t>(stream), ss = static_cast<hipStream_t>(side_stream);
     size_t used = 0;
+    // Events recorded while the stream is being CAPTURED become part of that graph.  Diagnostic switch for the round-3 finding
+    // "destroy a captured graph, capture another: crash" (tools/repro/): MSAU_CAPTURE_FRESH_EVENTS=1 gives every fork / join of a
+    // captured sweep an event of its own that is never reused (nor destroyed) instead of one from the pool that eager sweeps and
+    // earlier captures have used.
+    static const bool fresh_in_capture = std::getenv("MSAU_CAPTURE_FRESH_EVENTS") && std::getenv("MSAU_CAPTURE_FRESH_EVENTS")[0] == '1';
+    hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
+    if (fresh_in_capture) (void)hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cap0);
     auto next_event = [&](hipEvent_t* ev) -> int {
+        if (cap0 != hipStreamCaptureStatusNone) {
+            hipError_t err = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+            if (err != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "run_ops_overlap: event: %s", hipGetErrorString(err));
+            return 0;
+        }
         if (used == pool.size()) {
             hipEvent_t e;
             hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);

@@ -444,20 +444,16 @@ class MSAUWrapper(nn.Module):
 # safe point (TrainEngine.step / _drop_graphs outside a capture).
 _capturing = 0
 _graveyard: list = []
-# FINDING (MI355X / ROCm 7.2 / torch 2.10, 2026-10-04): destroying a captured graph (hipGraphExecDestroy / hipGraphDestroy through
-# torch.cuda.CUDAGraph's destructor) and capturing another one afterwards crashes the process -- abort inside hipStreamEndCapture or a
-# segmentation fault, in about half of the runs of tests/test_train_gpu.py on its own, on the tree of any day of this round; with the
-# graph objects kept alive: 0 of 12.  So a captured graph is never destroyed: one extra reference at creation (its kernel-argument
-# storage and private pool stay; the static input copies are separate tensors and ARE freed with the engine).  Graph mode is opt-in and
-# slower than eager launches here (section 2 of DESIGN.md); MSAU_GRAPH_DESTROY=1 restores destruction at safe points.
-_immortal: list = []
-
-
+# FINDING (MI355X / ROCm 7.2 / torch 2.10; rounds 3-4).  Destroying a captured graph (torch.cuda.CUDAGraph's destructor ->
+# hipGraphExecDestroy / hipGraphDestroy) and capturing another one crashed the process -- abort inside the destruction or inside
+# hipStreamEndCapture, a segmentation fault, once a hang -- in half of the stand-alone runs of tests/test_train_gpu.py.  Round 4 narrowed
+# it down (tools/repro/, profiles/r04_graph_destroy.md): a stand-alone HIP program and a torch-only script that capture TWO-stream
+# sweeps (fork / join by events from a reused pool, eager sweeps in between), destroy and re-capture pass 240 / 120 cycles; this code
+# base with graph destruction crashes 4 of 8 runs when the captured backward forks its weight gradients onto the side stream and
+# 0 of 8 when the same sweep is captured on ONE stream.  So a captured sweep is single-stream (Plan.backward(single_stream=True): graph
+# mode is the slower, opt-in mode anyway, section 2 of DESIGN.md), graphs are ordinary objects again, and nothing is leaked: the
+# round-3 remedy (one immortal reference per captured graph) is gone.
 def _keep_graph(g):
-    if os.environ.get("MSAU_GRAPH_DESTROY", "0") != "1":
-        import ctypes
-        ctypes.pythonapi.Py_IncRef(ctypes.py_object(g))
-        _immortal.append(g)
     return g
 
 
@@ -476,7 +472,7 @@ def _bury_graphs():
     """destroy the graphs of dead engines: not while a replay may still be running (ROCm 7.2: the process segfaults), not during a capture"""
     if _graveyard and not _capturing:
         torch.cuda.synchronize()
-        _graveyard.clear()          # (the static input copies go; the graph objects themselves are immortal unless MSAU_GRAPH_DESTROY=1)
+        _graveyard.clear()          # (the graphs, their private pools and the static input copies go)
 
 
 def _ru4(n: int) -> int:
@@ -603,7 +599,7 @@ class TrainEngine:
             plan.backward(self.flat_grad, on_stage_done=lambda b, side: self.sync.start(nb - b, after=side))
             self._ar_started = True
         else:
-            plan.backward(self.flat_grad)
+            plan.backward(self.flat_grad, single_stream=self.use_graph)      # (a captured sweep stays on one stream: see _keep_graph)
             self._ar_started = False
         return loss
 

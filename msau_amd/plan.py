@@ -1650,7 +1650,7 @@ class Plan:
         self._dp_stream = comm_stream
         self._dp_flat = flat_grads.data_ptr()
 
-    def backward(self, flat_grads: torch.Tensor, on_stage_done=None, native_dp: bool = False):
+    def backward(self, flat_grads: torch.Tensor, on_stage_done=None, native_dp: bool = False, single_stream: bool = False):
         """Run the backward sweep (external gradients must already be in place) and write the flat fp32
         parameter gradient.  `on_stage_done(stage, side_stream)` is called after each stage's launches are
         enqueued (its slab reduction is the last thing on `side_stream`): the data-parallel engine starts that
@@ -1670,7 +1670,7 @@ class Plan:
         for ba in self._box_bwd_args:
             ba.flat_grads = flat_grads.data_ptr()
         arr, n, _ = self._bwd_seq
-        if not self.overlap_wgrad:
+        if not self.overlap_wgrad or single_stream:         # (single_stream: a sweep that is being captured into a HIP graph)
             L.call("msau_run_ops", s, arr, n)
             if on_stage_done is not None:
                 for b, _, _ in self._bwd_segs:
