@@ -105,18 +105,31 @@ def kernel_source_hash() -> str:
 def load_traffic(key):
     """HBM bytes per launch of `key` from the PMC file of this round -- only if it was measured on exactly these kernel
     sources (tools/make_traffic.py writes the hash); otherwise (None, reason)"""
-    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r04_traffic.json")
     try:
         tj = json.load(open(path))
     except Exception as e:                                   # noqa: BLE001
         return None, f"no traffic file ({e.__class__.__name__})"
     if tj.get("kernel_source_hash") != kernel_source_hash():
-        return None, (f"profiles/r03_traffic.json was measured on kernel sources {tj.get('kernel_source_hash')}, this tree is "
+        return None, (f"profiles/r04_traffic.json was measured on kernel sources {tj.get('kernel_source_hash')}, this tree is "
                       f"{kernel_source_hash()}: re-run tools/make_traffic.py")
     ent = tj.get("kernels", {}).get(key)
     if ent is None:
-        return None, f"profiles/r03_traffic.json has no entry for {key}"
+        return None, f"profiles/r04_traffic.json has no entry for {key}"
     return ent, None
+
+
+def load_pmc(key):
+    """SQ-counter numbers of the kernel family `key` from tools/pmc_step.py's file, if measured on these kernel sources"""
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))
+    except Exception as e:                                   # noqa: BLE001
+        return None, f"no PMC file ({e.__class__.__name__})"
+    if pj.get("kernel_source_hash") != kernel_source_hash():
+        return None, f"profiles/r04_pmc.json was measured on kernel sources {pj.get('kernel_source_hash')}, this tree is {kernel_source_hash()}: re-run tools/pmc_step.py"
+    fam = pj.get("families", {})
+    ent = fam.get(key) or next((v for k, v in fam.items() if key.startswith(k)), None)
+    return (ent, None) if ent else (None, f"profiles/r04_pmc.json has no family for {key}")
 
 
 def profile_pass(L, eng, plan, x, label, nprof):
@@ -425,6 +438,7 @@ def main():
         L.call("msau_probe_overhead", torch.cuda.current_stream().cuda_stream, 256, ctypes.byref(ov))
         achieved = bytes_probe / (insitu_us * 1e-6) / 1e9
         tr, why = load_traffic(key)
+        pm, pm_why = load_pmc(key)
         serial = {r[1]: 1e3 * r[0] / r[2] for r in rows}
         norm_ops = {}
         for k in sorted(norm_keys):
@@ -450,6 +464,10 @@ def main():
                 "alg_bytes_per_launch": round(bytes_probe),
                 "share_of_step": round(ms / total_ms, 3),
                 "mfma_frac": round((alg_flops / n_launch) / (insitu_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TF, 4),
+                # from counters (tools/pmc_step.py, inside the step): SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 32 SIMDs per shader
+                # engine) and vector instructions issued per matrix instruction
+                "mfma_busy": (pm or {}).get("mfma_busy"), "valu_per_mfma": (pm or {}).get("valu_per_mfma"),
+                "issue_frac": (pm or {}).get("issue_frac"), "pmc_note": pm_why or "profiles/r04_pmc.json (tools/pmc_step.py)",
                 "norm_ops": norm_ops,
                 "launches_per_step_total": int(sum(m[0] for m in plan.launch_meta.values())),
                 "whole_step": {"alg_GB": round(step_bytes / 1e9, 3),
