@@ -302,11 +302,6 @@ def secondary_measurements(args, L, MSAUWrapper, TrainEngine, dev, n_class):
     if hasattr(TrainEngine, "step_boxes"):
         run("cfg4 fed from box lists, the grid NEVER painted: the first conv gathers per-tap partial products per feature row, its weight gradient sums the output gradient per box (MSAU_CONV_OWNER, csrc/ownerconv.hip; SURVEY 8f N1)",
             768, 2, "bf16", args.batch, feed="box-lists")
-    if hasattr(TrainEngine, "prefetch_boxes") and os.environ.get("MSAU_BENCH_PREFETCH") == "1":
-        # measured 2026-10-04: 4829 against 4863 tiles/s un-prefetched -- the painter's 2.1 GB store beside the first conv's 2.1 GB
-        # read only shares the same HBM; bytes, not latency, are what cfg 4 pays for.  Kept as an opt-in line.
-        run("cfg4 fed from box lists, next batch painted while this one trains (TrainEngine.prefetch_boxes / step_prefetched: two input buffers, the painter on the side stream during the forward sweep)",
-            768, 2, "bf16", args.batch, feed="device-painted, prefetched")
     run("cfg2 in fp32 storage (the parity mode of the same kernels)", args.channels, args.stages, "fp32", args.batch)
     run("cfg5: model_box variant 512x384x64, 3-stage (BASELINE configs[4]; BoxConv2d is third-party: self-consistent only)", 64, 3,
         "bf16", args.batch, box=True, hw=(512, 384))

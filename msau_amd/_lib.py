@@ -290,15 +290,8 @@ def concurrent_stream(device=None, index: int = 0):
     probe = torch.zeros(1024, dtype=torch.float32, device=dev)
     torch.cuda.synchronize(dev)
     chosen, tried = None, []
-    prio = int(os.environ.get("MSAU_SIDE_PRIO", "0")) if index == 0 else 0
-    for _ in range(8):
-        if prio:
-            # the weight-gradient stream at an explicit queue priority (+1 = lowest): torch only offers default / high
-            h = vp()
-            call("msau_stream_create", prio, C.byref(h))
-            cand = torch.cuda.ExternalStream(h.value, device=dev)
-        else:
-            cand = torch.cuda.Stream(device=dev)
+    for _ in range(8):                                       # (an explicit lowest / highest queue priority for this stream: 0 %, round 3)
+        cand = torch.cuda.Stream(device=dev)
         tried.append(cand)                                   # keep rejected candidates alive: their queue slots stay taken
         call("msau_spin", main.cuda_stream, 3000)
         call("msau_fill_zero", cand.cuda_stream, probe.data_ptr(), 4096)

@@ -133,7 +133,6 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
     constexpr int NIT = (NITEMS + NT - 1) / NT;
     constexpr int NSRC = DUAL ? 2 : 1;
     constexpr bool PIPE = IDS || NIT * NSRC <= 6;
-    constexpr bool OPF = CIN8 >= 4 && !DOUT && EPI != EPI_HEAD && EPI != EPI_LRN;     // epilogue operands prefetched (levels 2-3)
     V8 pre[IDS ? 1 : NSRC][IDS ? 1 : NIT];
     constexpr int NIDS = (Cfg::NPIX + NT - 1) / NT;            // id-mask input: tile pixels per thread
     int pre_id[IDS ? NIDS : 1];
@@ -222,10 +221,11 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
         tend = min(a.ntiles, (xcd + 1) * a.per_xcd);
         tstep = gridDim.x >> 3;
     }
-    // the first tile's loads go out ahead of the weight loads in EVERY instance: where a tile is too large for the register
-    // pipeline (!PIPE: the 64-channel and dilated level-3 tiles) the kernel used to fetch the weights, wait, write them to LDS
-    // and only then ask for its one tile -- two memory round trips of ~1 us each in a launch of 5 us (phase stamps, round 4)
-    if (tile0 < tend) issue_loads(tile0);
+    // (Round 4 tried the first tile's loads ahead of the weight loads in the !PIPE instances too, and the epilogue operands requested
+    //  before the MFMAs: phase stamps showed no gain -- the loads of a workgroup complete in order, the staging is bound by the
+    //  ~60 KB it moves, not by round trips -- and the step LOST 20 us (3.182 vs 3.162 ms, interleaved A/B) to the extra live registers:
+    //  removed again, as round 2 had found for the PIPE instances.  profiles/HISTORY_r03_r04.md)
+    if (PIPE && tile0 < tend) issue_loads(tile0);
     if constexpr (!Cfg::WREG) {
         // weights -> LDS, behind the first tile's loads and up to 8 loads in flight per thread.  As a plain loop this was
         // load -> wait -> write per 256 x 16 bytes BEFORE the first tile was even requested: 3 (32 -> 16 rows, 3x3) to 18
@@ -260,35 +260,12 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
         int b, oy0, ox0;
         decode(tile, b, oy0, ox0);
         __syncthreads();                                       // previous tile's fragment reads are done
-        if (!PIPE && tile != tile0) issue_loads(tile);
+        if (!PIPE) issue_loads(tile);
         write_lds();
         __syncthreads();
         if (tile == tile0) STAMP(2);
         if (PIPE && tile + tstep < tend) issue_loads(tile + tstep);
-        // epilogue operands (mask / residual / accumulate tensors) of the small-image instances: requested BEFORE the MFMAs,
-        // consumed after them -- loaded inside the epilogue they were a third serial round trip (1.0 us of a 6.5 us launch)
         const int oyw = oy0 + wave * 4;
-        V4 o_ma[OPF ? CT : 1][4], o_add[OPF ? CT : 1][4], o_acc[OPF ? CT : 1][4], o_mb[OPF ? CT : 1][4];
-        if constexpr (OPF) {
-            if ((flags & (MSAU_CONV_MASK_A | MSAU_CONV_ADD | MSAU_CONV_ACCUM | MSAU_CONV_MASK_B)) && ox0 + cwt * 16 + lr < d.Wout) {
-                const char* y = static_cast<const char*>(d.y) + ((long long)(b * d.Hout + oyw)) * a.out_row + (long long)ox0 * a.out_px;
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    if (lg * (CTT * 4) + (cty + ct) * 4 >= Cout) continue;
-#pragma unroll
-                    for (int pt = 0; pt < 4; ++pt) {
-                        if (oyw + pt < d.Hout) {                       // scalar
-                            const char* yp = y + (unsigned)(lane_out + ct * 4 * ESZ + pt * a.out_row);
-                            if (flags & MSAU_CONV_MASK_A) o_ma[ct][pt] = *reinterpret_cast<const V4*>(yp + delta_ma);
-                            if (flags & MSAU_CONV_ADD) o_add[ct][pt] = *reinterpret_cast<const V4*>(yp + delta_add);
-                            if (flags & MSAU_CONV_ACCUM) o_acc[ct][pt] = *reinterpret_cast<const V4*>(yp);
-                            if (flags & MSAU_CONV_MASK_B) o_mb[ct][pt] = *reinterpret_cast<const V4*>(yp + delta_mb);
-                        }
-                    }
-                }
-            }
-        }
-
         f32x4 acc[CT][4];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -389,20 +366,17 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
                         f32x4 v = acc[ct][pt] + bv[ct];
                         if (flags & (MSAU_CONV_MASK_A | MSAU_CONV_ADD | MSAU_CONV_ACCUM | MSAU_CONV_RELU_OUT | MSAU_CONV_MASK_B)) {
                             if (flags & MSAU_CONV_MASK_A) {
-                                V4 m;
-                                if constexpr (OPF) m = o_ma[ct][pt]; else m = *reinterpret_cast<const V4*>(yp + delta_ma);
+                                V4 m = *reinterpret_cast<const V4*>(yp + delta_ma);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : 0.f;
                             }
                             if (flags & MSAU_CONV_ADD) {
-                                V4 r;
-                                if constexpr (OPF) r = o_add[ct][pt]; else r = *reinterpret_cast<const V4*>(yp + delta_add);
+                                V4 r = *reinterpret_cast<const V4*>(yp + delta_add);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
                             }
                             if (flags & MSAU_CONV_ACCUM) {
-                                V4 r;
-                                if constexpr (OPF) r = o_acc[ct][pt]; else r = *reinterpret_cast<const V4*>(yp);
+                                V4 r = *reinterpret_cast<const V4*>(yp);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
                             }
@@ -411,8 +385,7 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
                                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                             }
                             if (flags & MSAU_CONV_MASK_B) {
-                                V4 m;
-                                if constexpr (OPF) m = o_mb[ct][pt]; else m = *reinterpret_cast<const V4*>(yp + delta_mb);
+                                V4 m = *reinterpret_cast<const V4*>(yp + delta_mb);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : 0.f;
                             }
@@ -881,12 +854,8 @@ static int lean_epi_case(int dtype, const msau_conv_desc* d, int CT, int epi) {
         if (c8 == 2 && CT == 1 && d->dil == 1 && d->Cout == 16) return 5;
         if (c8 == 2 && CT == 2 && d->dil == 2 && d->Cout == 32) return 6;
         if (c8 == 4 && CT == 4 && d->dil == 8 && d->Cout == 64 && dtype == MSAU_BF16) return 8;     // the level-3 entry conv (round 4)
-        // the net's first conv (64 one-hot channels -> featRoot 8): measured 9 us SLOWER per step than the conv + the 8.4 us stand-alone
-        // LRN launch (the epilogue instance loses more than the launch costs): off unless MSAU_LRN_FIRST=1
-        if (c8 == 8 && CT == 1 && d->dil == 1 && d->Cout == 8) {                    // (one query per step: read the switch every time)
-            const char* v = std::getenv("MSAU_LRN_FIRST");
-            if (v && v[0] == '1') return 7;
-        }
+        // (the net's first conv, 64 one-hot channels -> featRoot 8, had an instance too: 9 us SLOWER per step than the conv + the 8.4 us
+        //  stand-alone LRN launch -- removed in round 4, profiles/HISTORY_r03_r04.md)
     }
     if (epi == EPI_POOL && d->dil == 1) {
         if (dual && k == 1 && !split) {
@@ -907,7 +876,6 @@ int lean_epi(hipStream_t s, const LeanArgs& a, int which) {
         case 4: return launch_lean<T, 2, 2, 3, false, 4, 1, false, false, 1, 1, EPI_LRN>(s, a);
         case 5: return launch_lean<T, 2, 1, 3, false, 1, 1, false, false, 1, 1, EPI_LRN>(s, a);
         case 6: return launch_lean<T, 2, 2, 3, false, 2, 1, false, false, 1, 1, EPI_LRN>(s, a);
-        case 7: return launch_lean<T, 8, 1, 3, false, 1, 1, false, false, 1, 1, EPI_LRN>(s, a);
         case 8: if constexpr (sizeof(T) == 2) return launch_lean<T, 4, 4, 3, false, 8, 1, false, false, 1, 1, EPI_LRN>(s, a); else return 0;
         case 10: return launch_lean<T, 2, 1, 1, true, 1, 1, false, false, 1, 1, EPI_POOL>(s, a);
         case 11: return launch_lean<T, 4, 1, 1, true, 1, 1, false, false, 1, 1, EPI_POOL>(s, a);

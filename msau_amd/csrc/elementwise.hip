@@ -158,19 +158,8 @@ __device__ __forceinline__ float pow_neg_beta(float d, float beta, bool beta075)
     return __expf(-beta * __logf(d));
 }
 
-// d^-1/2 without the transcendental unit: bit-trick seed + three Newton steps (relative error < 1e-7 for d in [1e-3, 1e6]).
-// Used by the LRN kernels when MSAU_LRN_VALU=1: the experiment that tells whether the run-to-run differences of the
-// level-0 LRN backward come from v_rsq_f32 / v_sqrt_f32 or from somewhere else.
-__device__ __forceinline__ float rsqrt_valu(float d) {
-    float y = __builtin_bit_cast(float, 0x5f3759dfu - (__builtin_bit_cast(unsigned, d) >> 1));
-    const float h = 0.5f * d;
-#pragma unroll
-    for (int it = 0; it < 3; ++it) y = y * (1.5f - h * y * y);
-    return y;
-}
-
 // F075: beta == 0.75 with the raw rsq / sqrt path compiled in alone (the reference's only setting); otherwise `powmode`
-// picks at run time (0 exp/log, 1 rsq/sqrt, 2 VALU Newton)
+// picks at run time (0 exp/log, 1 rsq/sqrt)
 template <typename T, int G, bool BWD, bool F075>
 __global__ void lrn_fast_kernel(const T* __restrict__ a, const T* __restrict__ dy, T* __restrict__ out,
                                 int64_t npix, float alpha_over_n, float beta, float k, int powmode_rt) {
@@ -221,7 +210,6 @@ __global__ void lrn_fast_kernel(const T* __restrict__ a, const T* __restrict__ d
             // raw v_rsq_f32 / v_sqrt_f32 (1 ulp each, d >= k > 0: no denormal or range fix-ups needed) instead of the
             // library forms, whose correction sequences are a dozen VCC-dependent instructions per call
             if (powmode == 1) { const float r = __builtin_amdgcn_rsqf(d); dnb[j] = r * __builtin_amdgcn_sqrtf(r); invd[j] = r * r; }
-            else if (powmode == 2) { const float r = rsqrt_valu(d); dnb[j] = r * (r * rsqrt_valu(r)); invd[j] = r * r; }   // sqrt(r) = r * r^-1/2
             else { dnb[j] = __expf(-beta * __logf(d)); invd[j] = __builtin_amdgcn_rcpf(d); }
         }
         typename Vec8<T>::type ov;
@@ -315,8 +303,7 @@ int lrn_dispatch(hipStream_t s, const void* a, const void* dy, void* out, int64_
     MSAU_CHECK_ARG(npix > 0 && C > 0 && C <= Cs && Cs % 8 == 0 && Cs <= 256 && n >= 1, "lrn: bad dims C=%d Cs=%d n=%d", C, Cs, n);
     const float aon = alpha / (float)n;
     const bool b075 = beta == 0.75f;
-    static const bool valu_only = std::getenv("MSAU_LRN_VALU") && std::getenv("MSAU_LRN_VALU")[0] == '1';
-    const int powmode = b075 ? (valu_only ? 2 : 1) : 0;
+    const int powmode = b075 ? 1 : 0;
     const T* ap = static_cast<const T*>(a);
     const T* gp = static_cast<const T*>(dy);
     T* op = static_cast<T*>(out);

@@ -130,10 +130,9 @@ class ConvOp(Op):
         """slab-reduction group: the stage, except for the level-0 encoder convs of stage 0.  They close the backward
         sweep, and whatever is reduced behind them is exposed; with a group of their own the bulk of stage 0 (the
         level-1..3 layers own most of the slab bytes) is reduced earlier, while the level-0 launches still run."""
-        # (round 3: MSAU_TAIL_LEVELS = 2..4 moves the stage's own reduction, 60 us of slab reads, up to where the level-1..3 encoder
-        #  launches begin: measured 0.0 % -- the side queue is busy throughout the backward sweep, so its END does not move)
-        n = int(os.environ.get("MSAU_TAIL_LEVELS", "1"))
-        return -1 if (self.stage == 0 and any(self.name.startswith(f"s0.d{l}.") for l in range(n))) else self.stage
+        # (moving the stage's own reduction further up -- a group for levels 0..1, 0..2 ... -- measured 0.0 %: the side queue is busy
+        #  throughout the backward sweep, so its END does not move; profiles/HISTORY_r03_r04.md)
+        return -1 if (self.stage == 0 and self.name.startswith("s0.d0.")) else self.stage
 
     def reads(self):
         return [t for t in (self.x1, self.x2, self.fwd_add) if t is not None]
@@ -341,9 +340,6 @@ class ConvOp(Op):
         w.nslabs = 1
         L.call("msau_wgrad_geometry", P.dtype, C.byref(w), C.byref(wg))
         nslabs = max(1, min(wg.max_slabs, int(os.environ.get('MSAU_SLAB_CAP', '384')), max(64, (int(os.environ.get('MSAU_SLAB_MB', '3')) << 20) // max(wg.slab_bytes, 1))))
-        if conv and x1 is P.x_in and x2 is None and int(os.environ.get('MSAU_SLAB_FIRST', '0')) > 0:
-            # the net's first conv closes the backward sweep ALONE on the device: its workgroup count is what fills the CUs, not a budget
-            nslabs = max(1, min(wg.max_slabs, int(os.environ['MSAU_SLAB_FIRST'])))
         w.nslabs = nslabs
         slab_elems = wg.slab_bytes // 4
         self.slab_off = P.alloc_slab(nslabs * slab_elems)
@@ -793,9 +789,8 @@ class LrnOp(Op):
         self.plan.rec_meta[C.addressof(self._ba)] = (self.bkey, self.bbytes)
         # (round 1 tagged this launch MSAU_OP_JOIN in deterministic mode: its results varied from run to run beside a
         # side-stream kernel.  Root cause found in round 2 -- packed-fp32 instructions, msau_amd/build.py -- so the join,
-        # and its 4 % cost, are gone; MSAU_LRN_JOIN=1 brings it back for experiments.)
-        join = L.OP_JOIN if (os.environ.get("MSAU_LRN_JOIN") == "1" and self.plan.overlap_wgrad) else 0
-        return [(L.OP_LRN_BWD | join, self._ba)]
+        # and its 4 % cost, are gone.)
+        return [(L.OP_LRN_BWD, self._ba)]
 
     def fwd(self, s):
         a, y = self.a, self.y

@@ -15,7 +15,7 @@ cut -c1-400 "$O/r04_final_bench.json"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -o r04 -- python3 "$R/bench.py" --no-secondary --no-cpu-baseline --steps 60 --warmup 10 > "$O/prof.log" 2>&1 || { tail -5 "$O/prof.log"; exit 1; }
 MSAU_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_serial" -o r04s -- python3 "$R/bench.py" --no-secondary --no-cpu-baseline --no-roofline --steps 30 --warmup 10 > "$O/prof_serial.log" 2>&1 || { tail -5 "$O/prof_serial.log"; exit 1; }
-python3 "$R/tools/timeline.py" $(find "$O/prof" -name "*kernel_trace.csv" | head -1) > "$O/r04_timeline.txt" 2>&1 || true
+bash "$R/tools/timeline.sh" "$O/tl" > /dev/null 2>&1; cp "$O/tl/timeline.txt" "$O/r04_timeline.txt" 2>/dev/null || true
 find "$O/prof" "$O/prof_serial" -name "*kernel_trace.csv" -delete        # large; the stats and the timeline are what is kept
 cp "$R/profiles/r04_traffic.json" "$R/profiles/r04_pmc.json" "$R/profiles/r04_pmc_step.txt" "$O/" 2>/dev/null
 cd "$R"
