@@ -179,7 +179,9 @@ extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_strea
         }
         if (side) {
             pending.emplace_back(o, i);
-            if ((int)pending.size() >= fork_every || (o.kind & 0xff) == MSAU_OP_WGRAD_REDUCE) {
+            // (a side-stream attention core closes the forward sweep's attention branch -- f, g, h, core: released at once, it has the
+            //  whole decoder of its stage to run beside)
+            if ((int)pending.size() >= fork_every || (o.kind & 0xff) == MSAU_OP_WGRAD_REDUCE || (o.kind & 0xff) == MSAU_OP_ATTN_FWD) {
                 int rc = flush();
                 if (rc) return rc;
             }

@@ -576,7 +576,7 @@ class TrainEngine:
 
     # -- pieces (each is a fixed launch sequence on the current stream) --
     def _fwd_bwd(self, plan: Plan, x, labels, ids=None, nhwc_ready=False, owner=None):
-        plan.forward(self.model._flat, x, export=False, ids=ids, nhwc_ready=nhwc_ready, owner=owner)
+        plan.forward(self.model._flat, x, export=False, ids=ids, nhwc_ready=nhwc_ready, owner=owner, single_stream=self.use_graph)
         loss = plan.loss_grads(labels)
         # MSAU_DP_BUCKETS=1: ONE all-reduce of the whole flat gradient after the backward instead of a bucket per stage
         # issued while the earlier stages' backward still runs (fewer launches and joins, no overlap)

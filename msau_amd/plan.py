@@ -930,6 +930,8 @@ class AttnCoreOp(Op):
             return []
         self._ba = self._args(True)
         self.plan.rec_meta[C.addressof(self._ba)] = (self.bkey, self.bbytes)
+        # (round 4: the core's backward as a side branch too -- released at the start of its stage's backward, the level-3 data gradients
+        #  waiting for an event right behind it -- made the step 65 us SLOWER: in the backward the side queue is as loaded as the main one)
         return [(L.OP_ATTN_BWD, self._ba)]
 
     def fwd(self, s):
@@ -1181,7 +1183,34 @@ class Plan:
             if not isinstance(op, ConvOp):
                 op.note()
         self._note_boundary()
-        self._fwd_seq = self._make_seq([r for op in self.ops for r in op.fwd_recs()])
+        # The bottleneck attention of a stage (f, g, h projections + core: model/layers/attention.py:152-162) feeds ONLY the next stage's
+        # level-3 coupling (model/model.py:149-150: the decoder consumes the pre-attention tensor), so in the forward sweep it is a side
+        # branch: its launches go to the side stream -- idle during the forward -- beside the stage's decoder, and the consumer of its
+        # output joins.  Training plans only (forward-only plans recycle activation buffers by sequential liveness).
+        side_ops, join_ops = set(), set()
+        if self.training and self.overlap_wgrad and os.environ.get("MSAU_ATTN_SIDE", "1") != "0":
+            for op in self.ops:
+                if isinstance(op, AttnCoreOp):
+                    branch = [c for c in self.ops if isinstance(c, ConvOp) and c.out in (op.f, op.g, op.h)]
+                    users = [c for c in self.ops if isinstance(c, ConvOp) and (c.x1 is op.y or c.x2 is op.y or c.fwd_add is op.y)]
+                    later = self.ops[self.ops.index(op) + 1:]
+                    if len(branch) == 3 and users and all(u in later for u in users) and \
+                            not any(t in (op.f, op.g, op.h) for o2 in later for t in o2.reads()):
+                        side_ops.update(id(c) for c in branch)
+                        side_ops.add(id(op))
+                        join_ops.add(id(min(users, key=self.ops.index)))
+        frecs = []
+        for op in self.ops:
+            for kind, args in op.fwd_recs():
+                if id(op) in side_ops:
+                    kind |= L.OP_SIDE
+                elif id(op) in join_ops:
+                    kind |= L.OP_JOIN
+                    join_ops.discard(id(op))                 # (a fused pair emits one record; only the first record of an op joins)
+                frecs.append((kind, args))
+        self._fwd_side = bool(side_ops)
+
+        self._fwd_seq = self._make_seq(frecs)
         self.pack_table = self._upload(self._pack_entries, L.PackEntry) if self._pack_entries else None
         self.unpack_table = self._upload(self._unpack_entries, L.UnpackEntry) if self._unpack_entries else None
         self._bwd_seq, self._bwd_segs, self._reduce_args = None, [], []
@@ -1539,7 +1568,7 @@ class Plan:
         return self.x_in.data
 
     def forward(self, flat_params: torch.Tensor, x_nchw: Optional[torch.Tensor], export: bool = True,
-                ids: Optional[torch.Tensor] = None, nhwc_ready: bool = False, owner=None):
+                ids: Optional[torch.Tensor] = None, nhwc_ready: bool = False, owner=None, single_stream: bool = False):
         """`ids` (int32 [B,H,W] character ids, -1 = empty) instead of `x_nchw`: the one-hot grid is painted on the device.
         `nhwc_ready`: the input buffer (`input_nhwc`) already holds the grid -- no boundary conversion at all."""
         s = self._stream()
@@ -1564,7 +1593,12 @@ class Plan:
             self._feed_ids(None)
             self.load_input(x_nchw)
         if L._profiler is None:
-            self._run_seq(self._fwd_seq, s)          # one C call enqueues the whole forward sweep
+            if self._fwd_side and not single_stream:
+                if self._side is None:
+                    self._side = L.concurrent_stream(self.device)
+                L.call("msau_run_ops_overlap", s, self._side.cuda_stream, self._fwd_seq[0], self._fwd_seq[1], 1)
+            else:
+                self._run_seq(self._fwd_seq, s)      # one C call enqueues the whole forward sweep
         else:
             for op in self.ops:
                 op.fwd(s)
