@@ -38,16 +38,16 @@ struct LeanCfg {
     static constexpr int TIW = (16 * WGW - 1) * STRIDE + 1 + (KS - 1) * DIL;  // input tile columns (output tile = 16 x 16*WGW)
     static constexpr int NT = 256 * WGW;                      // threads per workgroup
     static constexpr int PSRAW = CIN8 * 8 * ESZ;
-    static constexpr int PS = ((PSRAW / 16) % 2 == 0) ? PSRAW + 16 : PSRAW;
     static constexpr int NPIX = TI * TIW;
     // the packed image is chunk-major and a chunk never straddles the two sources: dual = 2 chunks
     static constexpr int NCH = DUAL ? 2 : 1;
     static constexpr int C8H = CIN8 / NCH;                    // 8-channel groups per chunk
+    static constexpr int PS = lds_pixel_stride(PSRAW, ESZ, C8H, STRIDE);      // pixel stride of the input tile in LDS
     static constexpr int NG = KS * KS * C8H;                  // real 8-channel k-groups per chunk
     static constexpr int NKSH = (NG + 3) / 4;                 // MFMA k-steps (32 k each) per chunk
     static constexpr int NKS = NCH * NKSH;
     static constexpr bool WREG = CT * NKS <= 8;               // weight fragments held in registers
-    static constexpr int WS = NKSH * 32 * ESZ + 16;           // LDS weight row stride (when !WREG), per chunk
+    static constexpr int WS = lds_wrow_stride(NKSH, ESZ);     // LDS weight row stride (when !WREG), per chunk
     static constexpr int IN_BYTES = ((NPIX * PS + 15) / 16) * 16;
     static constexpr int LDS = IN_BYTES + (WREG ? 0 : NCH * CT * 16 * WS);
 };
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void conv_chunked_kernel(const LeanArgs a, con
     using Cfg = LeanCfg<T, C8CH, CT, 3, false, DIL>;
     typedef typename Vec8<T>::type V8;
     typedef typename Vec4<T>::type V4;
-    constexpr int ESZ = Cfg::ESZ, TI = Cfg::TIW, PS = Cfg::PS, NKS = Cfg::NKS, WS = NKS * 32 * ESZ + 16;
+    constexpr int ESZ = Cfg::ESZ, TI = Cfg::TIW, PS = Cfg::PS, NKS = Cfg::NKS, WS = lds_wrow_stride(NKS, ESZ);
     constexpr int NPIX = Cfg::NPIX, NITX = (NPIX * C8CH + 255) / 256, WG8 = NKS * 4, NITW = (CT * 16 * WG8 + 255) / 256;
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* lds_w = smem + Cfg::IN_BYTES;
@@ -853,7 +853,10 @@ static int lean_epi_case(int dtype, const msau_conv_desc* d, int CT, int epi) {
         if (c8 == 2 && CT == 2 && d->dil == 4 && d->Cout == 32) return 4;
         if (c8 == 2 && CT == 1 && d->dil == 1 && d->Cout == 16) return 5;
         if (c8 == 2 && CT == 2 && d->dil == 2 && d->Cout == 32) return 6;
-        if (c8 == 4 && CT == 4 && d->dil == 8 && d->Cout == 64 && dtype == MSAU_BF16) return 8;     // the level-3 entry conv (round 4)
+        if (c8 == 4 && CT == 4 && d->dil == 8 && d->Cout == 64 && dtype == MSAU_BF16) {             // the level-3 entry conv (round 4)
+            const char* v = std::getenv("MSAU_LRN64");
+            if (!(v && v[0] == '0')) return 8;
+        }
         // (the net's first conv, 64 one-hot channels -> featRoot 8, had an instance too: 9 us SLOWER per step than the conv + the 8.4 us
         //  stand-alone LRN launch -- removed in round 4, profiles/HISTORY_r03_r04.md)
     }
@@ -962,7 +965,7 @@ int msau_conv_chunked_capable(int dtype, const msau_conv_desc* d, int cch, int n
 template <typename T, int C8CH, int CT, int DIL>
 static int launch_chunked(hipStream_t s, const LeanArgs& a, int nchunks) {
     using Cfg = LeanCfg<T, C8CH, CT, 3, false, DIL>;
-    constexpr int lds = Cfg::IN_BYTES + CT * 16 * (Cfg::NKS * 32 * Cfg::ESZ + 16);
+    constexpr int lds = Cfg::IN_BYTES + CT * 16 * lds_wrow_stride(Cfg::NKS, Cfg::ESZ);
     static_assert(lds + 256 <= MSAU_LDS_LIMIT, "chunked conv: tile + weight chunk must fit the LDS");
     static bool attr_set = false;
     if (!attr_set && lds > 60 * 1024) {

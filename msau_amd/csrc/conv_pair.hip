@@ -42,11 +42,11 @@ struct PairCfg {
     static constexpr int XH = 18, XW = IW + 2;                // input tile; the intermediate tile is allocated alike
     static constexpr int NT = 256 * TW;
     static constexpr int PSRAW = C * ESZ;
-    static constexpr int PS = ((PSRAW / 16) % 2 == 0) ? PSRAW + 16 : PSRAW;
+    static constexpr int PS = lds_pixel_stride(PSRAW, ESZ, C8, 1);
     static constexpr int NPIX = XH * XW;
     static constexpr int NG = 9 * C8;                         // real 8-channel k-groups
     static constexpr int NKS = (NG + 3) / 4;                  // MFMA k-steps of 32
-    static constexpr int WS = NKS * 32 * ESZ + 16;
+    static constexpr int WS = lds_wrow_stride(NKS, ESZ);
     static constexpr int W_BYTES = CT * 16 * WS;              // one conv's weights in LDS
     static constexpr int X_BYTES = ((NPIX * PS + 15) / 16) * 16;
     static constexpr int M_BYTES = BWD ? 16 * IW * C8 : 0;    // one mask tile: a byte per (lattice pixel, 8-channel group)

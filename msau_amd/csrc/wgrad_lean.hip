@@ -31,8 +31,19 @@ template <typename T, int C8, int CO8, int KS, int DIL = 1, int STRIDE = 1>
 struct WLeanCfg {
     static constexpr int ESZ = (int)sizeof(T);
     static constexpr int TI = 15 * STRIDE + (KS - 1) * DIL + 1;
-    static constexpr int PSX = ((C8 * 8 * ESZ / 16) % 2 == 0) ? C8 * 8 * ESZ + 16 : C8 * 8 * ESZ;
-    static constexpr int PSG = ((CO8 * 8 * ESZ / 16) % 2 == 0) ? CO8 * 8 * ESZ + 16 : CO8 * 8 * ESZ;
+    // Fragment reads (bf16): ds_read_b64_tr_b16, 8 bytes per lane, served in the two 32-lane halves; a half is conflict-free when
+    // its 32 lanes cover the 256-byte bank row once.  A half is lane groups lg = 0, 1 (or 2, 3): 4 pixels (q) x 4 channel quads (p)
+    // each, i.e. 8 pixels x 32 contiguous bytes.  NMAP: the 8 pixels are 8 CONSECUTIVE columns of one tile row (k index j of lane
+    // group lg <-> column (lg & 1) * 4 + j for j < 4, 8 + (lg & 1) * 4 + j - 4 above) and the pixel stride is 32 (mod 64) bytes, so
+    // the eight 32-byte pieces tile the bank row.  Rounds 1-3 took columns (lg & 1) * 8 + j at an odd number of 16-byte slots:
+    // pieces at odd 16-byte offsets overlap, a 2-way conflict on every read (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.45 on the
+    // 16- to 64-channel instances, profiles/r04_pmc_step.txt).  The 8-channel instances (16-byte pixels, two taps per k-tile) keep
+    // the old mapping: they measured 0-0.14.  The sum over pixels is the same set in another order.
+    static constexpr bool NMAP = ESZ == 2 && C8 >= 2;
+    static constexpr int QS = NMAP ? 4 : 8;                   // column step between lane groups lg & 1
+    static constexpr int HI = NMAP ? 8 : 4;                   // column step to the second half of a lane's k indices
+    static constexpr int PSX = NMAP ? lds_pixel_stride(C8 * 8 * ESZ, ESZ, C8, STRIDE) : (((C8 * 8 * ESZ / 16) % 2 == 0) ? C8 * 8 * ESZ + 16 : C8 * 8 * ESZ);
+    static constexpr int PSG = NMAP ? lds_pixel_stride(CO8 * 8 * ESZ, ESZ, CO8, 1) : (((CO8 * 8 * ESZ / 16) % 2 == 0) ? CO8 * 8 * ESZ + 16 : CO8 * 8 * ESZ);
     static constexpr int KREAL = KS * KS * C8 * 8;
     static constexpr int KEXT = ((KREAL + 8 + 15) / 16) * 16;
     static constexpr int NKT = KEXT / 16;
@@ -199,13 +210,13 @@ __global__ __launch_bounds__((WLeanCfg<T, C8, CO8, KS, DIL, STRIDE>::NTH)) void 
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
                 const int blk = wave * 2 + bb;                         // this wave's 32-pixel blocks
-                const int row = blk * 2 + (lg >> 1), col = (lg & 1) * 8 + q;
+                const int row = blk * 2 + (lg >> 1), col = (lg & 1) * Cfg::QS + q;
                 const unsigned char* ga = lds_g + (row * 16 + col) * PSG + 4 * p * 2;
                 bf16x8 afrag[CTN];
 #pragma unroll
                 for (int ct = 0; ct < CTN; ++ct) {
                     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(ga + ct * 32));
-                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(ga + 4 * PSG + ct * 32));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(ga + Cfg::HI * PSG + ct * 32));
                     afrag[ct] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
                 const int pb0 = (row * STRIDE * TI + col * STRIDE) * PSX;
@@ -216,7 +227,7 @@ __global__ __launch_bounds__((WLeanCfg<T, C8, CO8, KS, DIL, STRIDE>::NTH)) void 
                     // the test is a constant and the selects vanish from the other tiles
                     const bool abs_ok = (i + 1) * 16 > Cfg::KREAL;
                     const int o0 = (abs_ok && (e & WL_ABS)) ? (e & ~WL_ABS) : pb0 + e;
-                    const int o1 = (abs_ok && (e & WL_ABS)) ? (e & ~WL_ABS) : pb0 + 4 * STRIDE * PSX + e;
+                    const int o1 = (abs_ok && (e & WL_ABS)) ? (e & ~WL_ABS) : pb0 + Cfg::HI * STRIDE * PSX + e;
                     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o0));
                     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o1));
                     bf16x8 bfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -234,14 +245,14 @@ __global__ __launch_bounds__((WLeanCfg<T, C8, CO8, KS, DIL, STRIDE>::NTH)) void 
 #pragma unroll UNR
             for (int bq = 0; bq < NBLK; ++bq) {
                 const int blk = Cfg::W2 ? wset * 4 + bq : bq;
-                // pixels m0 = blk*32 + lg*8 + q (+4): row = blk*2 + (lg>>1), col = (lg&1)*8 + q (+4)
-                const int row = blk * 2 + (lg >> 1), col = (lg & 1) * 8 + q;
+                // pixels of lane group lg: row = blk*2 + (lg>>1), columns (lg&1)*QS + q and + HI (see WLeanCfg::NMAP)
+                const int row = blk * 2 + (lg >> 1), col = (lg & 1) * Cfg::QS + q;
                 const unsigned char* ga = lds_g + (row * 16 + col) * PSG + 4 * p * 2;
                 bf16x8 afrag[CTN];
 #pragma unroll
                 for (int ct = 0; ct < CTN; ++ct) {
                     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(ga + ct * 32));
-                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(ga + 4 * PSG + ct * 32));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(ga + Cfg::HI * PSG + ct * 32));
                     afrag[ct] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
                 const int pb0 = (row * STRIDE * TI + col * STRIDE) * PSX;
@@ -249,7 +260,7 @@ __global__ __launch_bounds__((WLeanCfg<T, C8, CO8, KS, DIL, STRIDE>::NTH)) void 
                 for (int i = 0; i < NKW; ++i) {                        // rounds this wave does not own read zeros (see `wave`)
                     const int e = coloff[i];
                     const int o0 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + e;
-                    const int o1 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + 4 * STRIDE * PSX + e;
+                    const int o1 = (e & WL_ABS) ? (e & ~WL_ABS) : pb0 + Cfg::HI * STRIDE * PSX + e;
                     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o0));
                     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o1));
                     bf16x8 bfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -354,7 +365,9 @@ __global__ __launch_bounds__((WLeanCfg<T, C8, CO8, KS, DIL, STRIDE>::NTH)) void 
 // meet in LDS after the last tile.  The bias gradient (the ones column of the slab) is summed from the gradient tile's
 // interior by the threads that stage it.  Slab layout unchanged: slab[co][tap * 64 + ci], ones column at 576.
 struct WIn64 {
-    static constexpr int PSX = 64 * 2 + 16, PSG = 8 * 2 + 16, TG = 18;
+    // (strides and pixel mapping: see WLeanCfg::NMAP -- x pixels 160 bytes apart, 8 consecutive columns per 32-lane half; the
+    //  gradient tile's 16-byte pixels sit 48 bytes apart so that the 9 consecutive pixels two neighbouring taps touch differ in bank)
+    static constexpr int PSX = 64 * 2 + 32, PSG = 8 * 2 + 32, TG = 18;
     static constexpr int X_BYTES = 256 * PSX, G_BYTES = TG * TG * PSG;
     static constexpr int ZERO = X_BYTES + G_BYTES;                  // 16 zero bytes: the missing tenth tap
     static constexpr int TILE_BYTES = ZERO + 64;
@@ -480,13 +493,13 @@ __global__ __launch_bounds__(256) void wgrad_in64_kernel(const WLeanArgs a) {
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
             const int blk = wave * 2 + bb;
-            const int row = blk * 2 + (lg >> 1), col = (lg & 1) * 8 + q;
+            const int row = blk * 2 + (lg >> 1), col = (lg & 1) * 4 + q;
             const unsigned char* xa = lds_x + (row * 16 + col) * PSX + 8 * p;
             bf16x8 afrag[4];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(xa + mt * 32));
-                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(xa + 4 * PSX + mt * 32));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(xa + 8 * PSX + mt * 32));
                 afrag[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
             const int pb0 = WIn64::X_BYTES + (row * TG + col) * PSG;
@@ -495,7 +508,7 @@ __global__ __launch_bounds__(256) void wgrad_in64_kernel(const WLeanArgs a) {
                 const int e = goff[nt];
                 const bool abs_ok = nt == 4;                           // only the last column tile holds the missing tenth tap
                 const int o0 = (abs_ok && (e & WL_ABS)) ? (e & ~WL_ABS) : pb0 + e;
-                const int o1 = (abs_ok && (e & WL_ABS)) ? (e & ~WL_ABS) : pb0 + 4 * PSG + e;
+                const int o1 = (abs_ok && (e & WL_ABS)) ? (e & ~WL_ABS) : pb0 + 8 * PSG + e;
                 bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o0));
                 bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(smem + o1));
                 bf16x8 bfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
