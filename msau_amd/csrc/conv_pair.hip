@@ -30,9 +30,21 @@ struct PairArgs {
     int tiles_x, tiles_y, ntiles;
     unsigned mag_tx, mag_ty;
     int per_xcd;
+#ifdef MSAU_STAMPS
+    unsigned long long* stamps;                  // diagnostic build only: 16 words per workgroup (s_memrealtime at phase ends)
+#endif
 };
+#ifdef MSAU_STAMPS
+#define PSTAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PSTAMP(i) do {} while (0)
+#endif
 
-template <typename T, int C8, int TW, bool BWD>
+// RPW: lattice rows per wave.  4 = four waves per column tile (one per SIMD).  2 = eight: two waves per SIMD on the same tile,
+// each with half the accumulators, half the epilogue and half the staging -- the 32-channel launches (levels 2 / 3: one or two
+// tiles per workgroup, one workgroup per CU by LDS) ran every LDS read -> MFMA chain and every epilogue of a lone wave exposed:
+// phase stamps, 84 x 64 x 32 forward: MFMA phases 1.56 + 1.44 us for 0.48 + 0.48 us of MFMA time (profiles/HISTORY_r03_r04.md).
+template <typename T, int C8, int TW, bool BWD, int RPW = 4>
 struct PairCfg {
     static constexpr int ESZ = (int)sizeof(T);
     static constexpr int C = C8 * 8;
@@ -40,7 +52,8 @@ struct PairCfg {
     static constexpr int IW = 16 * TW;                        // intermediate lattice: 16 x IW
     static constexpr int OH = 14, OW = IW - 2;                // output tile
     static constexpr int XH = 18, XW = IW + 2;                // input tile; the intermediate tile is allocated alike
-    static constexpr int NT = 256 * TW;
+    static constexpr int NWR = 16 / RPW;                      // waves per column tile
+    static constexpr int NT = 64 * NWR * TW;
     static constexpr int PSRAW = C * ESZ;
     static constexpr int PS = lds_pixel_stride(PSRAW, ESZ, C8, 1);
     static constexpr int NPIX = XH * XW;
@@ -99,14 +112,16 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned of
 // BITS: the ReLU masks travel as bit planes ([B][H][W][C/8] bytes: one bit per element) -- the forward launch writes the
 // planes of its input (x > 0) and of its intermediate (mid > 0), the backward launch reads them instead of re-reading the
 // two bf16 tensors for one bit per element (110 -> 69 MB per backward launch at level 0).
-template <typename T, int C8, int TW, bool BWD, bool POOL = false, bool BITS = false>
-__global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
+template <typename T, int C8, int TW, bool BWD, bool POOL = false, bool BITS = false, int RPW = 4>
+__global__ __launch_bounds__((PairCfg<T, C8, TW, BWD, RPW>::NT)) void conv_pair_kernel(const PairArgs a) {
     static_assert(!(BWD && POOL), "the pooled output belongs to the forward launch");
-    using Cfg = PairCfg<T, C8, TW, BWD>;
+    static_assert(RPW == 4 || RPW == 2, "rows per wave");
+    using Cfg = PairCfg<T, C8, TW, BWD, RPW>;
     typedef typename Vec8<T>::type V8;
     typedef typename Vec4<T>::type V4;
     constexpr int ESZ = Cfg::ESZ, XW = Cfg::XW, IW = Cfg::IW, PS = Cfg::PS, NKS = Cfg::NKS, NG = Cfg::NG, CT = Cfg::CT, NT = Cfg::NT;
     extern __shared__ __align__(16) unsigned char smem[];
+    PSTAMP(0);
     unsigned char* xt = smem;
     unsigned char* rt = smem + Cfg::X_BYTES;
     unsigned char* mt = smem + Cfg::OFF_M;                          // [16][IW][C8] bits of mask_mid at the lattice
@@ -115,26 +130,43 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
     const msau_conv_pair_desc& d = a.d;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wave_all & 3, cwt = wave_all >> 2;
+    const int wave = wave_all & (Cfg::NWR - 1), cwt = wave_all / Cfg::NWR;
     const int lr = lane & 15, lg = lane >> 4;
     const int H = d.H, W = d.W;
     const unsigned img_bytes = (unsigned)H * (unsigned)a.row;
 
-    // ---- weights and biases of both convs: LDS, once per persistent workgroup
+    // ---- weights and biases of both convs: LDS, once per persistent workgroup.  All their loads are issued at one point, into
+    // registers, ahead of the first tile's loads; written as a loop of load -> LDS store the compiler kept it rolled with a
+    // vmcnt(0) per trip: nine serialised L2 round trips, 2.0 us of every launch (phase stamps).
+    constexpr int WG8 = NKS * 4, NWI = 2 * CT * 16 * WG8, NITW = (NWI + NT - 1) / NT;
+    static_assert(2 * Cfg::C <= NT, "one bias per thread");
+    V8 wreg[NITW];
+    float breg = 0.f;
     {
-        constexpr int WG8 = NKS * 4;
-        for (int idx = tid; idx < 2 * CT * 16 * WG8; idx += NT) {
+#pragma unroll
+        for (int it = 0; it < NITW; ++it) {
+            const int idx = min(tid + it * NT, NWI - 1);
             const int which = idx / (CT * 16 * WG8), rem = idx - which * (CT * 16 * WG8);
             const int r = rem / WG8, g8 = rem - r * WG8;
             const T* wp = static_cast<const T*>(which ? d.w2 : d.w1);
-            *reinterpret_cast<V8*>(smem + Cfg::OFF_W + which * Cfg::W_BYTES + r * Cfg::WS + g8 * 8 * ESZ) =
-                load8<T>(wp + (size_t)r * a.kchunk + g8 * 8);
+            wreg[it] = load8<T>(wp + (size_t)r * a.kchunk + g8 * 8);
         }
-        for (int c = tid; c < 2 * Cfg::C; c += NT) {
-            const float* src = c < Cfg::C ? d.b1 : d.b2;
-            lbias[c] = src ? src[c < Cfg::C ? c : c - Cfg::C] : 0.f;
+        if (tid < 2 * Cfg::C) {
+            const float* src = tid < Cfg::C ? d.b1 : d.b2;
+            if (src) breg = src[tid < Cfg::C ? tid : tid - Cfg::C];
         }
     }
+    auto write_weights = [&]() {
+#pragma unroll
+        for (int it = 0; it < NITW; ++it) {
+            const int idx = tid + it * NT;
+            const int which = idx / (CT * 16 * WG8), rem = idx - which * (CT * 16 * WG8);
+            const int r = rem / WG8, g8 = rem - r * WG8;
+            if ((it + 1) * NT <= NWI || idx < NWI)
+                *reinterpret_cast<V8*>(smem + Cfg::OFF_W + which * Cfg::W_BYTES + r * Cfg::WS + g8 * 8 * ESZ) = wreg[it];
+        }
+        if (tid < 2 * Cfg::C) lbias[tid] = breg;
+    };
 
     int koff[NKS];
 #pragma unroll
@@ -144,7 +176,7 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
         const int ky = tap / 3, kx = tap - ky * 3;
         koff[ks] = G < NG ? (ky * XW + kx) * PS + cg * 8 * ESZ : 0;
     }
-    const int pix_off = ((wave * 4) * XW + cwt * 16 + lr) * PS;      // lattice (wave*4 + pt, cwt*16 + lr), pt adds XW*PS
+    const int pix_off = ((wave * RPW) * XW + cwt * 16 + lr) * PS;      // lattice (wave*4 + pt, cwt*16 + lr), pt adds XW*PS
     const int ch0 = lg * (CT * 4);                                  // this lane's first channel (ct adds 4)
     const bool ch_ok = C8 > 1 || lg < 2;                            // 8-channel layers fill half of the 16 MFMA rows
     const int jcol = cwt * 16 + lr;                                 // this lane's lattice / tile column
@@ -243,9 +275,13 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
     }
     if (tile0 >= tend) return;                                 // workgroup-uniform
     issue_loads(tile0, true);
-    __syncthreads();                                           // weights / biases staged
+    PSTAMP(1);
+    write_weights();
+    PSTAMP(2);
     write_tiles();
     __syncthreads();
+    PSTAMP(3);
+    int nt_done = 0;
 
     for (int tile = tile0; tile < tend; tile += tstep) {
         int b, ty0, tx0;
@@ -258,17 +294,17 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
         const __amdgpu_buffer_rsrc_t ry = image_rsrc(static_cast<char*>(d.y) + img, img_bytes);
         // ================= phase 1: intermediate on the 16 x IW lattice, image position (ty0-1+i, tx0-1+j) ===========
         {
-            f32x4 acc[CT][4];
+            f32x4 acc[CT][RPW];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int pt = 0; pt < RPW; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const unsigned char* p = xt + pix_off + koff[ks];
-                V8 bfrag[4];
+                V8 bfrag[RPW];
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt) {
+                for (int pt = 0; pt < RPW; ++pt) {
                     bfrag[pt] = *reinterpret_cast<const V8*>(p + pt * XW * PS);
                     if constexpr (!BWD) bfrag[pt] = relu8<T>(bfrag[pt]);         // MSAU_PAIR_RELU_IN
                 }
@@ -276,9 +312,10 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
                 for (int ct = 0; ct < CT; ++ct) {
                     const V8 af = *reinterpret_cast<const V8*>(smem + Cfg::OFF_W + (ct * 16 + lr) * Cfg::WS + (ks * 32 + lg * 8) * ESZ);
 #pragma unroll
-                    for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = mma8(af, bfrag[pt], acc[ct][pt]);
+                    for (int pt = 0; pt < RPW; ++pt) acc[ct][pt] = mma8(af, bfrag[pt], acc[ct][pt]);
                 }
             }
+            if (nt_done == 0) PSTAMP(4);
             const int xx = tx0 - 1 + jcol;
             const bool colin = (unsigned)xx < (unsigned)W;
             const bool colown = ch_ok && colin && jcol >= 1 && jcol <= Cfg::OW;
@@ -286,8 +323,8 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) bias[ct] = *reinterpret_cast<const f32x4*>(lbias + (ch_ok ? ch0 + ct * 4 : 0));
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) {
-                const int i = wave * 4 + pt;                     // wave-uniform
+            for (int pt = 0; pt < RPW; ++pt) {
+                const int i = wave * RPW + pt;                   // wave-uniform
                 const int yy = ty0 - 1 + i;
                 const bool rowin = (unsigned)yy < (unsigned)H;
                 const bool inimg = colin && rowin;
@@ -314,6 +351,7 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
             }
         }
         __syncthreads();
+        if (nt_done == 0) PSTAMP(5);
         if constexpr (!BWD && BITS) {
             // bit planes of the input (x > 0, raw tile) and of the intermediate (mid > 0) at this tile's own pixels
             const unsigned plane = (unsigned)H * (unsigned)W * C8;
@@ -335,24 +373,25 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
         }
         // ================= phase 2: output tile, image position (ty0+oy, tx0+ox), reads the intermediate from LDS ====
         {
-            f32x4 acc[CT][4];
+            f32x4 acc[CT][RPW];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int pt = 0; pt < RPW; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const unsigned char* p = rt + pix_off + koff[ks];
-                V8 bfrag[4];
+                V8 bfrag[RPW];
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt) bfrag[pt] = *reinterpret_cast<const V8*>(p + pt * XW * PS);
+                for (int pt = 0; pt < RPW; ++pt) bfrag[pt] = *reinterpret_cast<const V8*>(p + pt * XW * PS);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     const V8 af = *reinterpret_cast<const V8*>(smem + Cfg::OFF_W + Cfg::W_BYTES + (ct * 16 + lr) * Cfg::WS + (ks * 32 + lg * 8) * ESZ);
 #pragma unroll
-                    for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = mma8(af, bfrag[pt], acc[ct][pt]);
+                    for (int pt = 0; pt < RPW; ++pt) acc[ct][pt] = mma8(af, bfrag[pt], acc[ct][pt]);
                 }
             }
+            if (nt_done == 0) PSTAMP(6);
             const bool colok = ch_ok && jcol < Cfg::OW && tx0 + jcol < W;
             f32x4 bias[CT];
 #pragma unroll
@@ -360,10 +399,10 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
             // the residual (forward) / other-path gradient (backward) operand is the input tensor itself: read it back
             // from the raw LDS input tile, position (oy + 2, ox + 2); lanes without channels read slot 0
             const int xt_lane = ch_ok ? (2 * XW + jcol + 2) * PS + ch0 * ESZ : 0;
-            V4 keep[POOL ? CT : 1][4];                                     // MSAU_CONV_POOL: the rounded results, 0 where nothing is stored
+            V4 keep[POOL ? CT : 1][RPW];                                     // MSAU_CONV_POOL: the rounded results, 0 where nothing is stored
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) {
-                const int oy = wave * 4 + pt;                    // wave-uniform
+            for (int pt = 0; pt < RPW; ++pt) {
+                const int oy = wave * RPW + pt;                  // wave-uniform
                 const int yy = ty0 + oy;
                 const bool ok = colok && oy < Cfg::OH && yy < H;
                 const unsigned goff = (unsigned)(yy * a.row + tx0 * a.px + lane_c);
@@ -405,7 +444,7 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
-                        for (int pp = 0; pp < 2; ++pp) {
+                        for (int pp = 0; pp < RPW / 2; ++pp) {
                             V4 nb[2];
 #pragma unroll
                             for (int r = 0; r < 2; ++r) {
@@ -414,7 +453,7 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
                                 for (int w = 0; w < ND; ++w) dst[w] = __builtin_amdgcn_mov_dpp(src[w], 0xB1, 0xf, 0xf, true);
                                 nb[r] = __builtin_bit_cast(V4, dst);
                             }
-                            const int oy = wave * 4 + 2 * pp;
+                            const int oy = wave * RPW + 2 * pp;
                             const bool pok = colok && !(lr & 1) && oy < Cfg::OH && ty0 + oy < H;
                             V4 best;
                             unsigned idx = 0;
@@ -438,14 +477,21 @@ __global__ __launch_bounds__(256 * TW) void conv_pair_kernel(const PairArgs a) {
             }
         }
         __syncthreads();                                       // every read of the LDS tiles is done
+        if (nt_done == 0) PSTAMP(7);
         write_tiles();                                         // needs the prefetch only: vmcnt(stores of this tile)
         __syncthreads();
+        if (nt_done == 0) PSTAMP(8);
+        ++nt_done;
     }
+    PSTAMP(9);
+#ifdef MSAU_STAMPS
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + 10] = nt_done;
+#endif
 }
 
-template <typename T, int C8, int TW, bool BWD, bool POOL = false, bool BITS = false>
+template <typename T, int C8, int TW, bool BWD, bool POOL = false, bool BITS = false, int RPW = 4>
 int launch_pair(hipStream_t s, const PairArgs& a0) {
-    using Cfg = PairCfg<T, C8, TW, BWD>;
+    using Cfg = PairCfg<T, C8, TW, BWD, RPW>;
     static_assert(Cfg::LDS + Cfg::LDS_PAD + 256 <= MSAU_LDS_LIMIT, "conv_pair instance does not fit the LDS");
     PairArgs a = a0;
     a.tiles_x = cdiv(a.d.W, Cfg::OW);
@@ -455,7 +501,7 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
     a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS + Cfg::LDS_PAD > 60 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD, POOL, BITS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD, POOL, BITS, RPW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_pair: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -466,12 +512,12 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
     if (!per_cu) {
         // (hipOccupancyMaxActiveBlocksPerMultiprocessor budgets 64 KB of LDS per CU, not gfx950's 160 KB: compute it here)
         hipFuncAttributes fa;
-        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD, POOL, BITS>));
+        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD, POOL, BITS, RPW>));
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_pair: hipFuncGetAttributes: %s", hipGetErrorString(e));
         const int vgprs = ((fa.numRegs > 0 ? fa.numRegs : 64) + 7) & ~7;
         int waves_per_simd = 512 / vgprs;                      // 512 VGPRs per SIMD lane, 8 waves at most
         waves_per_simd = waves_per_simd > 8 ? 8 : waves_per_simd;
-        const int by_regs = waves_per_simd / TW;               // a workgroup puts TW waves on every SIMD
+        const int by_regs = waves_per_simd / (Cfg::NT / 256);  // a workgroup puts NT / 256 waves on every SIMD
         const int by_lds = MSAU_LDS_LIMIT / (Cfg::LDS + Cfg::LDS_PAD + 256);
         int n = by_regs < by_lds ? by_regs : by_lds;
         static const int percu_max = std::getenv("MSAU_PAIR_PERCU") ? atoi(std::getenv("MSAU_PAIR_PERCU")) : 8;
@@ -486,7 +532,7 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
         grid &= ~7;
         a.per_xcd = cdiv(a.ntiles, 8);
     }
-    hipLaunchKernelGGL((conv_pair_kernel<T, C8, TW, BWD, POOL, BITS>), dim3(grid), dim3(256 * TW), Cfg::LDS + Cfg::LDS_PAD, s, a);
+    hipLaunchKernelGGL((conv_pair_kernel<T, C8, TW, BWD, POOL, BITS, RPW>), dim3(grid), dim3(Cfg::NT), Cfg::LDS + Cfg::LDS_PAD, s, a);
     MSAU_CHECK_LAUNCH("conv_pair_kernel");
     return 0;
 }
@@ -501,6 +547,9 @@ int pair_tw(int dtype, const msau_conv_pair_desc* d) {
 }
 
 // the two flag combinations the kernel is compiled for: the residual block's forward, and its data gradient
+#ifndef MSAU_PAIR_RPW32
+#define MSAU_PAIR_RPW32 2                      // rows per wave of the 32-channel bf16 instances (PairCfg)
+#endif
 constexpr int kFwd1 = MSAU_PAIR_RELU_IN | MSAU_PAIR_RELU_MID, kFwd2 = MSAU_CONV_ADD | MSAU_CONV_RELU_OUT;
 constexpr int kBwd1 = MSAU_PAIR_MASK_MID, kBwd2 = MSAU_CONV_MASK_A | MSAU_CONV_ADD;
 
@@ -568,20 +617,23 @@ extern "C" int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc
     const int esz = dtype == MSAU_F32 ? 4 : 2;
     PairArgs a;
     a.d = *d;
+#ifdef MSAU_STAMPS
+    a.stamps = std::getenv("MSAU_STAMP_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(std::getenv("MSAU_STAMP_PTR"), nullptr, 0)) : nullptr;
+#endif
     a.kchunk = roundup(9 * d->C, 32);
     a.px = d->C * esz;
     a.row = d->W * a.px;
     const int c8 = d->C / 8, tw = pair_tw(dtype, d);
     const bool pool = !bwd && (d->flags2 & MSAU_CONV_POOL);
     const bool bits = d->bits_mid && d->bits_a;
-#define PAIR_CASE(T, C8V, TWV) if (c8 == C8V && tw == TWV) { \
-        if (bwd) return bits ? launch_pair<T, C8V, TWV, true, false, true>(s, a) : launch_pair<T, C8V, TWV, true>(s, a); \
-        if (pool) return bits ? launch_pair<T, C8V, TWV, false, true, true>(s, a) : launch_pair<T, C8V, TWV, false, true>(s, a); \
-        return bits ? launch_pair<T, C8V, TWV, false, false, true>(s, a) : launch_pair<T, C8V, TWV, false>(s, a); }
+#define PAIR_CASE(T, C8V, TWV, RPWV) if (c8 == C8V && tw == TWV) { \
+        if (bwd) return bits ? launch_pair<T, C8V, TWV, true, false, true, RPWV>(s, a) : launch_pair<T, C8V, TWV, true, false, false, RPWV>(s, a); \
+        if (pool) return bits ? launch_pair<T, C8V, TWV, false, true, true, RPWV>(s, a) : launch_pair<T, C8V, TWV, false, true, false, RPWV>(s, a); \
+        return bits ? launch_pair<T, C8V, TWV, false, false, true, RPWV>(s, a) : launch_pair<T, C8V, TWV, false, false, false, RPWV>(s, a); }
     if (dtype == MSAU_BF16) {
-        PAIR_CASE(bf16_t, 1, 1) PAIR_CASE(bf16_t, 1, 2) PAIR_CASE(bf16_t, 2, 1) PAIR_CASE(bf16_t, 2, 2) PAIR_CASE(bf16_t, 4, 1)
+        PAIR_CASE(bf16_t, 1, 1, 4) PAIR_CASE(bf16_t, 1, 2, 4) PAIR_CASE(bf16_t, 2, 1, 4) PAIR_CASE(bf16_t, 2, 2, 4) PAIR_CASE(bf16_t, 4, 1, MSAU_PAIR_RPW32)
     } else {
-        PAIR_CASE(float, 1, 1) PAIR_CASE(float, 1, 2) PAIR_CASE(float, 2, 1)
+        PAIR_CASE(float, 1, 1, 4) PAIR_CASE(float, 1, 2, 4) PAIR_CASE(float, 2, 1, 4)
     }
 #undef PAIR_CASE
     return msau_set_error(MSAU_ERR_ARG, "conv_pair: no instance for C %d tile width %d", d->C, tw);
