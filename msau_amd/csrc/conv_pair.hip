@@ -70,6 +70,14 @@ struct PairCfg {
     static constexpr int LDS_PAD = 1024;
     static constexpr int NITX = (NPIX * C8 + NT - 1) / NT;    // prefetch registers (16 B each): input tile
     static constexpr int NITM = BWD ? (16 * IW * C8) / NT : 0;                 //                 each mask tile
+    // ALLFRAG: all fragment reads of a phase (NKS x (RPW + CT) ds_read_b128) are issued before its first MFMA and waited for with
+    // counted lgkmcnt: the compiler's own schedule kept them one k-step ahead, and with eight waves reading, an LDS round trip
+    // (~350 cycles under that load) per k-step was the phase: 1.4 us for 0.5 us of MFMA / 0.5 us of LDS-array time (phase stamps,
+    // 84 x 64 x 32).  Needs NKS * (RPW + CT) * 4 registers: the bf16 instances.
+#ifndef MSAU_PAIR_ALLFRAG
+#define MSAU_PAIR_ALLFRAG 1
+#endif
+    static constexpr bool ALLFRAG = MSAU_PAIR_ALLFRAG && ESZ == 2 && NKS * (RPW + CT) * 4 <= 160;
 };
 
 template <typename T> __device__ __forceinline__ unsigned positive_bits(typename Vec8<T>::type v) {
@@ -299,6 +307,30 @@ __global__ __launch_bounds__((PairCfg<T, C8, TW, BWD, RPW>::NT)) void conv_pair_
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int pt = 0; pt < RPW; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (Cfg::ALLFRAG) {
+                // every fragment read of the phase is issued before its first MFMA (see PairCfg::ALLFRAG)
+                V8 bfr[NKS][RPW], afr[NKS][CT];
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const unsigned char* p = xt + pix_off + koff[ks];
+#pragma unroll
+                    for (int pt = 0; pt < RPW; ++pt) bfr[ks][pt] = *reinterpret_cast<const V8*>(p + pt * XW * PS);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        afr[ks][ct] = *reinterpret_cast<const V8*>(smem + Cfg::OFF_W + (ct * 16 + lr) * Cfg::WS + (ks * 32 + lg * 8) * ESZ);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+                    for (int pt = 0; pt < RPW; ++pt)
+                        if constexpr (!BWD) bfr[ks][pt] = relu8<T>(bfr[ks][pt]);     // MSAU_PAIR_RELU_IN
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int pt = 0; pt < RPW; ++pt) acc[ct][pt] = mma8(afr[ks][ct], bfr[ks][pt], acc[ct][pt]);
+                }
+            } else {
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const unsigned char* p = xt + pix_off + koff[ks];
@@ -314,6 +346,7 @@ __global__ __launch_bounds__((PairCfg<T, C8, TW, BWD, RPW>::NT)) void conv_pair_
 #pragma unroll
                     for (int pt = 0; pt < RPW; ++pt) acc[ct][pt] = mma8(af, bfrag[pt], acc[ct][pt]);
                 }
+            }
             }
             if (nt_done == 0) PSTAMP(4);
             const int xx = tx0 - 1 + jcol;
@@ -378,6 +411,25 @@ __global__ __launch_bounds__((PairCfg<T, C8, TW, BWD, RPW>::NT)) void conv_pair_
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int pt = 0; pt < RPW; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (Cfg::ALLFRAG) {
+                V8 bfr[NKS][RPW], afr[NKS][CT];
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const unsigned char* p = rt + pix_off + koff[ks];
+#pragma unroll
+                    for (int pt = 0; pt < RPW; ++pt) bfr[ks][pt] = *reinterpret_cast<const V8*>(p + pt * XW * PS);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        afr[ks][ct] = *reinterpret_cast<const V8*>(smem + Cfg::OFF_W + Cfg::W_BYTES + (ct * 16 + lr) * Cfg::WS + (ks * 32 + lg * 8) * ESZ);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int pt = 0; pt < RPW; ++pt) acc[ct][pt] = mma8(afr[ks][ct], bfr[ks][pt], acc[ct][pt]);
+            } else {
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const unsigned char* p = rt + pix_off + koff[ks];
@@ -390,6 +442,7 @@ __global__ __launch_bounds__((PairCfg<T, C8, TW, BWD, RPW>::NT)) void conv_pair_
 #pragma unroll
                     for (int pt = 0; pt < RPW; ++pt) acc[ct][pt] = mma8(af, bfrag[pt], acc[ct][pt]);
                 }
+            }
             }
             if (nt_done == 0) PSTAMP(6);
             const bool colok = ch_ok && jcol < Cfg::OW && tx0 + jcol < W;
