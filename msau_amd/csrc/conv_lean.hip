@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256 * WGW) void conv_lean_kernel(const LeanArgs a) 
         } else {
         // MSAU_CONV_POOL keeps the rounded results (0 where nothing is stored: the zero padding of the pool)
         constexpr bool POOL_OK = EPI == EPI_POOL;
-        static_assert(EPI == EPI_NONE || ((CT <= 2 || EPI == EPI_LRN) && !DOUT && STRIDE == 1 && UPS == 1), "fused epilogues: <= 2 channel tiles (LRN: 4), one output");
+        static_assert(EPI == EPI_NONE || (CT <= 2 && !DOUT && STRIDE == 1 && UPS == 1), "fused epilogues: <= 2 channel tiles, one output");
         V4 keep[POOL_OK ? CT : 1][4];
         if constexpr (POOL_OK) {
 #pragma unroll
@@ -853,10 +853,8 @@ static int lean_epi_case(int dtype, const msau_conv_desc* d, int CT, int epi) {
         if (c8 == 2 && CT == 2 && d->dil == 4 && d->Cout == 32) return 4;
         if (c8 == 2 && CT == 1 && d->dil == 1 && d->Cout == 16) return 5;
         if (c8 == 2 && CT == 2 && d->dil == 2 && d->Cout == 32) return 6;
-        if (c8 == 4 && CT == 4 && d->dil == 8 && d->Cout == 64 && dtype == MSAU_BF16) {             // the level-3 entry conv (round 4)
-            const char* v = std::getenv("MSAU_LRN64");
-            if (!(v && v[0] == '0')) return 8;
-        }
+        // (the level-3 entry conv, 32 -> 64 channels at dilation 8 with four channel tiles, had an instance in round 4: 15.1 us against
+        //  7.8 us for the conv + 1.7 us for the 64-channel LRN launch, 3.086 -> 3.077 ms without it -- removed, profiles/HISTORY_r03_r04.md)
         // (the net's first conv, 64 one-hot channels -> featRoot 8, had an instance too: 9 us SLOWER per step than the conv + the 8.4 us
         //  stand-alone LRN launch -- removed in round 4, profiles/HISTORY_r03_r04.md)
     }
@@ -879,7 +877,6 @@ int lean_epi(hipStream_t s, const LeanArgs& a, int which) {
         case 4: return launch_lean<T, 2, 2, 3, false, 4, 1, false, false, 1, 1, EPI_LRN>(s, a);
         case 5: return launch_lean<T, 2, 1, 3, false, 1, 1, false, false, 1, 1, EPI_LRN>(s, a);
         case 6: return launch_lean<T, 2, 2, 3, false, 2, 1, false, false, 1, 1, EPI_LRN>(s, a);
-        case 8: if constexpr (sizeof(T) == 2) return launch_lean<T, 4, 4, 3, false, 8, 1, false, false, 1, 1, EPI_LRN>(s, a); else return 0;
         case 10: return launch_lean<T, 2, 1, 1, true, 1, 1, false, false, 1, 1, EPI_POOL>(s, a);
         case 11: return launch_lean<T, 4, 1, 1, true, 1, 1, false, false, 1, 1, EPI_POOL>(s, a);
         case 12: return launch_lean<T, 8, 2, 1, true, 1, 1, false, false, 1, 1, EPI_POOL>(s, a);

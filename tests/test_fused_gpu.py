@@ -251,7 +251,7 @@ def test_lrn_in_the_conv_epilogue_matches_the_standalone_pass(monkeypatch, dtype
     for mode in ("1", "0"):
         monkeypatch.setenv("MSAU_FUSE_LRN", mode)
         out[mode] = run_graph(build, p, x, gy, dtype)
-    fits = not (cout == 64 and dtype == L.F32)              # (the dilation-8 instance with four channel tiles exists in bf16 only: LDS)
+    fits = cout != 64                                       # (the 64-channel LRN stays its own launch: the fused instance measured slower)
     assert (took[0].fused_into is not None) == fits and took[1].fused_into is None
     bf = dtype == L.BF16
     # same inputs (the storage-rounded conv result), same formula, different order of the window sums: one bf16 ulp at most
