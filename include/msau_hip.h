@@ -95,6 +95,12 @@ enum {
                                    and tap.  3x3, stride 1, C1 -> 8; other flags: RELU_OUT only; also on msau_wgrad_desc.flags (x1 =
                                    the same context; the first msau_owner_slabs(d) slabs are written -- the slab reduction must be told).
                                    msau_conv2d_launch_info: info[7] & 32 when the launch can take it. */
+    MSAU_CONV_NCHW     = 4096,  /* the net's first conv fed with the API's input tensor itself (csrc/conv_first.hip): x1 is fp32 NCHW
+                                   [B][C][Hin][Win] with C = head_classes real channels (<= C1 = 64 stored; the missing ones are zero), and
+                                   y2, if not NULL, receives its NHWC copy in the storage dtype -- what msau_nchw_to_nhwc would have
+                                   written, for the weight gradient of the backward.  bf16, 3x3 SAME stride 1, 64 -> 8, Win % 4 == 0,
+                                   Win <= 288; other flags: RELU_OUT only; results equal msau_nchw_to_nhwc + the dense launch bit for bit.
+                                   msau_conv2d_launch_info: info[7] & 64 when the launch can take it. */
     MSAU_CONV_HEAD     = 64     /* inference head (kv_model.py:305-313): besides y, write softmax over the Cout real
                                    channels of the (storage-rounded) result to head_probs (fp32 [B][Hout][Wout][Cout],
                                    dense) and the index of its first maximum to head_argmax (uint8 [B][Hout][Wout]).
@@ -152,7 +158,7 @@ int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d);
  * info[6] = 1 if a compile-time-specialised "lean" instance (conv_lean.hip) takes the launch, 2 if the chunked-K instance does,
  *           3 if a row-streaming instance (conv_rows.hip) does,
  * info[7] = bit 0: that instance implements MSAU_CONV_HEAD for this descriptor, bit 1: MSAU_CONV_DOUT,
- *           bit 2: MSAU_CONV_LRN, bit 3: MSAU_CONV_POOL, bit 4: MSAU_CONV_IDS, bit 5: MSAU_CONV_OWNER */
+ *           bit 2: MSAU_CONV_LRN, bit 3: MSAU_CONV_POOL, bit 4: MSAU_CONV_IDS, bit 5: MSAU_CONV_OWNER, bit 6: MSAU_CONV_NCHW */
 int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info8);
 
 /* ------------------------------------------------------------------------------------------

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmsau_hip.so")
-SOURCES = ["pack.hip", "conv.hip", "conv_lean.hip", "conv_pair.hip", "conv_rows.hip", "conv_wgrad.hip", "wgrad_lean.hip", "elementwise.hip", "attention.hip", "attention_mfma.hip", "raster.hip", "boxconv.hip", "sequence.hip", "comm.hip", "ownerconv.hip"]
+SOURCES = ["pack.hip", "conv.hip", "conv_lean.hip", "conv_first.hip", "conv_pair.hip", "conv_rows.hip", "conv_wgrad.hip", "wgrad_lean.hip", "elementwise.hip", "attention.hip", "attention_mfma.hip", "raster.hip", "boxconv.hip", "sequence.hip", "comm.hip", "ownerconv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"] + os.environ.get("MSAU_EXTRA_HIPCC_FLAGS", "").split() + [
          "-ffp-contract=fast"]
 

@@ -345,6 +345,8 @@ int msau_conv_lean_pool_capable(int dtype, const msau_conv_desc* d, int nchunks,
 int msau_conv_lean_ids_capable(int dtype, const msau_conv_desc* d, int nchunks, int CT);
 int msau_conv_chunked_try(hipStream_t s, int dtype, const msau_conv_desc* d, int cch, int kchunk, int nchunks, int CT);
 int msau_conv_chunked_capable(int dtype, const msau_conv_desc* d, int cch, int nchunks, int CT);
+int msau_firstconv_takes(int dtype, const msau_conv_desc* d);
+int msau_firstconv_launch(hipStream_t s, int dtype, const msau_conv_desc* d, int real_channels);
 
 extern "C" int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32_t* info) {
     MSAU_CHECK_ARG(d && info, "conv2d_launch_info: null pointer");
@@ -364,6 +366,11 @@ extern "C" int msau_conv2d_launch_info(int dtype, const msau_conv_desc* d, int32
         msau_conv_desc p = *d;
         p.flags |= MSAU_CONV_OWNER;
         if (msau_ownerconv_takes(dtype, &p)) info[7] |= 32;
+    }
+    {
+        msau_conv_desc p = *d;
+        p.flags |= MSAU_CONV_NCHW;
+        if (msau_firstconv_takes(dtype, &p)) info[7] |= 64;
     }
     if (g.nslices == 1 && !(info[7] & 4)) {              // would a row-streaming instance take this launch with MSAU_CONV_LRN added?
         msau_conv_desc p = *d;
@@ -401,6 +408,11 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
     if (d->flags & MSAU_CONV_OWNER) {                                          // ownerconv.hip: box lists instead of a painted input tensor
         MSAU_CHECK_ARG(msau_ownerconv_takes(dtype, d), "conv2d: MSAU_CONV_OWNER is the 3x3 stride-1 C -> 8 conv, no other flag but RELU_OUT");
         return msau_ownerconv_fwd(static_cast<hipStream_t>(stream), dtype, d);
+    }
+    if (d->flags & MSAU_CONV_NCHW) {                                           // conv_first.hip: the fp32 NCHW input tensor itself
+        MSAU_CHECK_ARG(msau_firstconv_takes(dtype, d) && d->head_classes > 0 && d->head_classes <= d->C1,
+                       "conv2d: MSAU_CONV_NCHW is the bf16 3x3 64 -> 8 conv (W %% 4 == 0, W <= 288), head_classes = real input channels");
+        return msau_firstconv_launch(static_cast<hipStream_t>(stream), dtype, d, d->head_classes);
     }
     ConvGeom g; TileGeom t; int PT; int64_t nb;
     int rc = conv_plan(dtype, d, &g, &t, &PT, &nb);

@@ -1299,7 +1299,17 @@ class Plan:
         esz = 4 if self.dtype == L.F32 else 2
         a = self.x_in
         self.in_bytes = self.B * a.C * a.H * a.W * 4 + a.npix * a.Cs * esz
-        self.note_launch("msau_nchw_to_nhwc", self.in_bytes, 0.0)
+        c = self._nchw_first_conv()
+        if c is None:
+            self.note_launch("msau_nchw_to_nhwc", self.in_bytes, 0.0)
+        else:
+            # the first conv reads the API tensor itself (MSAU_CONV_NCHW, csrc/conv_first.hip): the conversion launch and the conv's
+            # read of the converted copy disappear; the copy is still written for the backward's weight gradient (training plans)
+            self.unnote_launch(c.fkey, c.fbytes, c.flops)
+            T = "f32" if self.dtype == L.F32 else "bf16"
+            c.fkey = f"first_conv_nchw<{T},CIN{a.Cs},CO{c.out.Cs}>"
+            c.fbytes = self.B * a.C * a.H * a.W * 4 + (a.npix * a.Cs * esz if self.training else 0) + c.out.npix * c.out.Cs * esz
+            self.note_launch(c.fkey, c.fbytes, c.flops)
         nparam = sum(int(math.prod(shp)) for shp in self.pshape.values())
         self.note_launch("msau_pack_params", nparam * 4 + self._pack_bytes, 0.0)
         if self.training:
@@ -1408,11 +1418,54 @@ class Plan:
         a = self.x_in
         L.call("msau_nchw_to_nhwc", self._stream(), self.dtype, x_nchw.data_ptr(), a.data.data_ptr(), self.B, a.C, a.Cs, self.H, self.W)
 
+    def _nchw_first_conv(self):
+        """the net's first conv if msau_conv2d takes it with MSAU_CONV_NCHW (the API's fp32 NCHW tensor as its input), else None"""
+        if not hasattr(self, "_nchw_conv"):
+            c = next((op for op in self.ops if isinstance(op, ConvOp) and op.x1 is self.x_in and op.x2 is None), None)
+            ok = c is not None and os.environ.get("MSAU_FIRST_NCHW", "1") != "0" and not (c.pair is not None and c.pair.active) \
+                and not (c.fdesc.flags & ~L.CONV_RELU_OUT)
+            if ok:
+                info = (L.i32 * 8)()
+                L.call("msau_conv2d_launch_info", self.dtype, C.byref(c.fdesc), info)
+                ok = bool(info[7] & 64)
+            self._nchw_conv = c if ok else None
+            self._nchw_on = False
+        return self._nchw_conv
+
+    def _feed_nchw(self, x_nchw: Optional[torch.Tensor]) -> bool:
+        """Switch the net's first conv between the plan's NHWC input buffer and the API's fp32 NCHW tensor `x_nchw` (MSAU_CONV_NCHW:
+        the conv converts while it loads and writes the NHWC copy the backward's weight gradient reads; same bits as
+        msau_nchw_to_nhwc + the dense launch).  Returns True when the conv takes the tensor: no conversion launch then.  Call it
+        after _feed_ids / _feed_owner (they reset the descriptor's input).  The descriptor is launched by value."""
+        c = self._nchw_first_conv()
+        if c is None:
+            return False
+        if x_nchw is not None:
+            assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and tuple(x_nchw.shape) == \
+                (self.B, self.cfg["channels"], self.H, self.W), (x_nchw.shape, x_nchw.dtype)
+            if x_nchw.data_ptr() % 16:
+                x_nchw = None                                   # (a view at an odd offset: the plain conversion takes any alignment)
+        if x_nchw is not None:
+            c.fdesc.flags |= L.CONV_NCHW
+            c.fdesc.x1 = x_nchw.data_ptr()
+            c.fdesc.y2 = _ptr(self.x_in.data) if self.training else None
+            c.fdesc.head_classes = self.x_in.C
+            self._nchw_on = True
+            return True
+        if self._nchw_on:
+            c.fdesc.flags &= ~L.CONV_NCHW
+            c.fdesc.x1 = _ptr(self.x_in.data)
+            c.fdesc.y2 = None
+            c.fdesc.head_classes = 0
+            self._nchw_on = False
+        return False
+
     def _feed_ids(self, ids: Optional[torch.Tensor]) -> bool:
         """Switch the net's first conv (and its weight gradient) between the dense input tensor and an id mask
         (MSAU_CONV_IDS: the one-hot tile is synthesised in LDS, nothing is painted or read; same bits as the dense launch).
         Returns True when the id mask feeds the conv directly; False = paint the dense one-hot input (`load_ids`).  The
         descriptors are launched by value, so flipping them between sweeps is safe."""
+        self._feed_nchw(None)
         if not hasattr(self, "_ids_conv"):
             c = next((op for op in self.ops if isinstance(op, ConvOp) and op.x1 is self.x_in and op.x2 is None), None)
             ok = c is not None and os.environ.get("MSAU_IDS_DIRECT", "1") != "0" and not (c.pair is not None and c.pair.active)
@@ -1449,6 +1502,7 @@ class Plan:
         """Switch the net's first conv (and its weight gradient) between the painted input tensor and BOX LISTS
         (MSAU_CONV_OWNER, csrc/ownerconv.hip): `src` = (owner int32 [B,H,W], boxes int32 [n,6] device tensor or None, n, feats
         fp32 [n_vec, C] device tensor) or None.  Returns False when no instance takes the conv (paint the tensor instead)."""
+        self._feed_nchw(None)
         if not hasattr(self, "_owner_conv"):
             c = next((op for op in self.ops if isinstance(op, ConvOp) and op.x1 is self.x_in and op.x2 is None), None)
             ok = c is not None and os.environ.get("MSAU_OWNER_CONV", "1") != "0" and not (c.pair is not None and c.pair.active) \
@@ -1527,7 +1581,8 @@ class Plan:
                 self.load_ids(ids)
         else:
             self._feed_ids(None)
-            self.load_input(x_nchw)
+            if not self._feed_nchw(x_nchw):
+                self.load_input(x_nchw)
         self._run_seq(self._fwd_seq, s)
         if not self.head_fused:
             lg = self.logits
@@ -1591,7 +1646,8 @@ class Plan:
                 self.load_ids(ids)
         else:
             self._feed_ids(None)
-            self.load_input(x_nchw)
+            if not self._feed_nchw(x_nchw):
+                self.load_input(x_nchw)
         if L._profiler is None:
             if self._fwd_side and not single_stream:
                 if self._side is None:

@@ -582,3 +582,69 @@ def test_row_streaming_two_output_data_gradients_match_the_tile_kernels_and_torc
     assert rows_have <= ("1" in out)
     if len(out) == 2:
         assert err(out["1"][0], out["0"][0], True) < 5e-3 and err(out["1"][1], out["0"][1], True) < 5e-3
+
+
+@pytest.mark.parametrize("B,Cr,hw,relu", [(2, 64, (24, 32), 0), (3, 61, (17, 100), 1), (1, 64, (9, 16), 0), (2, 64, (40, 256), 1),
+                                          (2, 5, (33, 288), 0), (1, 64, (8, 132), 0), (5, 64, (50, 60), 1), (16, 64, (336, 256), 0)])
+def test_first_conv_fed_with_the_nchw_tensor_is_bit_identical_to_conversion_plus_conv(B, Cr, hw, relu):
+    """MSAU_CONV_NCHW (csrc/conv_first.hip): the net's first conv reads the API's fp32 NCHW tensor itself and writes the NHWC bf16
+    copy the weight gradient needs -- same products, order and roundings as msau_nchw_to_nhwc followed by the dense launch.
+    Widths that are no multiple of 16 / 32 / 64, fewer real channels than the 64 stored, bands with a ragged last one, the
+    bench's own size; with and without the copy."""
+    H, W = hw
+    dev = torch.device("cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    lib = L.load()
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + H + W)
+    x = (torch.randn(B, Cr, H, W, generator=g) * (torch.rand(B, 1, H, W, generator=g) > 0.5)).to(dev)
+    w = (torch.randn(16 * 576, generator=g) * 0.1).to(dev).to(torch.bfloat16)
+    w.view(16, 576)[8:] = 0                                         # rows beyond the 8 output channels, as msau_pack_params writes them
+    bias = torch.randn(16, generator=g).to(dev)
+    xn = torch.zeros(B, H, W, 64, device=dev, dtype=torch.bfloat16)
+    y_ref = torch.zeros(B, H, W, 8, device=dev, dtype=torch.bfloat16)
+    L.call("msau_nchw_to_nhwc", s, L.BF16, x.data_ptr(), xn.data_ptr(), B, Cr, 64, H, W)
+    d = L.ConvDesc()
+    d.B, d.Hin, d.Win, d.Hout, d.Wout = B, H, W, H, W
+    d.C1, d.C2, d.Cout = 64, 0, 8
+    d.KH = d.KW = 3
+    d.dil, d.pad_t, d.pad_l, d.stride, d.ups = 1, 1, 1, 1, 1
+    d.flags = L.CONV_RELU_OUT if relu else 0
+    d.x1, d.wpack, d.bias, d.y = xn.data_ptr(), w.data_ptr(), bias.data_ptr(), y_ref.data_ptr()
+    L.check(lib.msau_conv2d(s, L.BF16, d), "conv")
+    info = (L.i32 * 8)()
+    L.call("msau_conv2d_launch_info", L.BF16, C.byref(d), info)
+    assert info[7] & 64, list(info)
+    xn2, y2 = torch.full_like(xn, 7.0), torch.full_like(y_ref, 7.0)
+    d.flags |= L.CONV_NCHW
+    d.x1, d.y, d.y2, d.head_classes = x.data_ptr(), y2.data_ptr(), xn2.data_ptr(), Cr
+    L.check(lib.msau_conv2d(s, L.BF16, d), "first conv, NCHW input")
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y_ref) and torch.equal(xn2, xn)
+    y3 = torch.full_like(y_ref, 7.0)
+    d.y, d.y2 = y3.data_ptr(), None                                  # forward-only plans: no copy
+    L.check(lib.msau_conv2d(s, L.BF16, d), "first conv, NCHW input, no copy")
+    torch.cuda.synchronize()
+    assert torch.equal(y3, y_ref)
+
+
+def test_first_conv_nchw_refuses_what_it_does_not_implement():
+    lib = L.load()
+    d = L.ConvDesc()
+    d.B, d.Hin, d.Win, d.Hout, d.Wout = 1, 16, 30, 16, 30                # width no multiple of 4
+    d.C1, d.C2, d.Cout, d.KH, d.KW = 64, 0, 8, 3, 3
+    d.dil, d.pad_t, d.pad_l, d.stride, d.ups = 1, 1, 1, 1, 1
+    info = (L.i32 * 8)()
+    L.call("msau_conv2d_launch_info", L.BF16, C.byref(d), info)
+    assert not info[7] & 64
+    d.Win = d.Wout = 32
+    L.call("msau_conv2d_launch_info", L.BF16, C.byref(d), info)
+    assert info[7] & 64
+    L.call("msau_conv2d_launch_info", L.F32, C.byref(d), info)       # bf16 storage only
+    assert not info[7] & 64
+    d.Win = d.Wout = 304                                             # the three-row ring would not fit the LDS
+    L.call("msau_conv2d_launch_info", L.BF16, C.byref(d), info)
+    assert not info[7] & 64
+    x = torch.zeros(8, device="cuda")
+    d.flags = L.CONV_NCHW
+    d.x1 = d.wpack = d.y = x.data_ptr()
+    assert lib.msau_conv2d(torch.cuda.current_stream().cuda_stream, L.BF16, d) != 0       # refused, not launched
