@@ -18,6 +18,10 @@
 #include "msau_common.h"
 #include <cstdlib>
 
+#ifndef MSAU_FIRST_DEPTH
+#define MSAU_FIRST_DEPTH 2                     // (3 measured the same 103 us: the walk is not bound by the loads in flight)
+#endif
+
 namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -94,7 +98,8 @@ __global__ __launch_bounds__(256) void first_conv_nchw_kernel(const FirstArgs a)
         st_off[it] = px0 < W ? (unsigned)px0 * 128u + (unsigned)cg * 16u : kOOB;
         lds_px[it] = px0 < W ? (px0 + 1) * PS : 0;
     }
-    f32x4 ra[NI][8], rb[NI][8];                                            // two rows of loads in flight
+    constexpr int DEPTH = MSAU_FIRST_DEPTH;                                // rows of loads in flight
+    f32x4 rr[DEPTH][NI][8];
     // Every load of a row is issued unconditionally, in straight-line code: a row outside the image gets a buffer of ZERO records
     // (a scalar select), a quad beyond W an offset beyond any buffer, channels beyond the real C fall behind the image's C planes --
     // all of them return 0 in hardware.  (With the conditions folded into the offsets the compiler branched around every load and
@@ -169,22 +174,21 @@ __global__ __launch_bounds__(256) void first_conv_nchw_kernel(const FirstArgs a)
     };
 
     // ---- the walk: rows y0 - 1 .. y1 go through the ring; output row r - 1 is computed when input row r has arrived
-    load_row(y0 - 1, ra);
-    load_row(y0, rb);
+#pragma unroll
+    for (int dd = 0; dd < DEPTH; ++dd) load_row(y0 - 1 + dd, rr[dd]);
     __syncthreads();                                                       // ring cleared, weights staged
-    for (int r = y0 - 1; r <= y1; r += 2) {
-        // even trip: row r from ra, then ra <- row r + 2; odd trip: row r + 1 from rb, then rb <- row r + 3
-        put_row(r, ra);
-        load_row(r + 2 <= y1 ? r + 2 : -1, ra);
-        __syncthreads();
-        if (r - 1 >= y0) compute_row(r - 1);
-        __syncthreads();
-        if (r + 1 > y1) break;
-        put_row(r + 1, rb);
-        load_row(r + 3 <= y1 ? r + 3 : -1, rb);
-        __syncthreads();
-        if (r >= y0) compute_row(r);
-        __syncthreads();
+    for (int r = y0 - 1; r <= y1; r += DEPTH) {
+#pragma unroll
+        for (int dd = 0; dd < DEPTH; ++dd) {
+            const int row = r + dd;                                        // workgroup-uniform, as is everything tested below
+            if (row <= y1) {
+                put_row(row, rr[dd]);
+                load_row(row + DEPTH <= y1 ? row + DEPTH : -1, rr[dd]);
+                __syncthreads();
+                if (row - 1 >= y0) compute_row(row - 1);
+                __syncthreads();
+            }
+        }
     }
 }
 
