@@ -43,6 +43,10 @@ int msau_version(void);
  * 10 msau_conv_pack_geom, 11 msau_wgrad_geom, 12 msau_conv_pair_desc, 13 msau_box_args, 14 msau_allreduce_args, 15 msau_owner_ctx;
  * -1 for anything else. */
 int msau_sizeof(int which);
+/* LDS strides (bytes) the tile kernels give a pixel of `raw_bytes` channels / a weight row of `nks` 32-deep k-steps (csrc/msau_common.h:
+ * lds_pixel_stride, lds_wrow_stride) -- exported so that a CPU test can check them against the bank model of MI355X_MICROARCH.md. */
+int msau_lds_pixel_stride(int raw_bytes, int esz, int c8_per_chunk, int read_stride);
+int msau_lds_wrow_stride(int nks, int esz);
 
 /* ------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution, used for: SAME conv 3x3 / dilated 3x3 / 1x1 / 4x4 forward

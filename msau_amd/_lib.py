@@ -124,6 +124,8 @@ _SIGNATURES = {
     "msau_last_error": (C.c_char_p, []),
     "msau_version": (C.c_int, []),
     "msau_sizeof": (C.c_int, [C.c_int]),
+    "msau_lds_pixel_stride": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "msau_lds_wrow_stride": (C.c_int, [C.c_int, C.c_int]),
     "msau_conv_pack_geometry": (C.c_int, [C.c_int] * 9 + [C.POINTER(ConvPackGeom)]),
     "msau_conv2d": (C.c_int, [vp, C.c_int, C.POINTER(ConvDesc)]),
     "msau_conv2d_launch_info": (C.c_int, [C.c_int, C.POINTER(ConvDesc), C.POINTER(i32)]),
