@@ -374,16 +374,20 @@ int msau_selfattn_bwd(void* stream, int dtype, const void* f, const void* g, con
  * per-block partials then one ordered pass).  ws: >= msau_ce_ws_floats(npix) floats.
  * ------------------------------------------------------------------------------------------ */
 int msau_label_counts(void* stream, const int64_t* labels, int32_t* counts, int B, int64_t hw);
+/* the same count with every sample spread over K workgroups: partial[b * K + k] (K <= 64) is written; msau_masked_ce_multi adds the
+ * K integers of a sample up itself (counts_k = K) -- no atomics, no follow-up launch */
+int msau_label_counts_split(void* stream, const int64_t* labels, int32_t* partial, int B, int64_t hw, int K);
 int64_t msau_ce_ws_floats(int64_t npix_total);
 int msau_masked_ce(void* stream, int dtype, const void* logits, const int64_t* labels, const int32_t* counts,
                    void* dlogits, float* loss_accum, float* ws, int B, int64_t hw, int C, int Cs, float scale);
 /* final + auxiliary logits in one launch (model/model.py:455-458): loss[0] = CE(logits) + CE(aux) (aux may be NULL),
  * written, not accumulated; ws: msau_ce_multi_ws_floats(B*hw) floats of scratch.  Same arithmetic per pixel as
- * msau_masked_ce; the block sums are added in index order by a one-wave follow-up kernel. */
+ * msau_masked_ce; the block sums are added in index order by a one-wave follow-up kernel.  counts_k = 1: counts is [B] as
+ * msau_label_counts writes it; counts_k = K > 1: [B][K] partial counts of msau_label_counts_split (B <= 1024). */
 int64_t msau_ce_multi_ws_floats(int64_t npix_total);
 int msau_masked_ce_multi(void* stream, int dtype, const void* logits, const void* aux, const int64_t* labels,
                          const int32_t* counts, void* dlogits, void* daux, float* loss, float* ws,
-                         int B, int64_t hw, int C, int Cs, float scale);
+                         int B, int64_t hw, int C, int Cs, float scale, int counts_k);
 
 /* plain cross entropy over EVERY pixel (label 0 is a class), as model/training/cost.py:35-65 `UNetLoss`:
  *   loss += scale * sum_p -log softmax(logits_p)[label_p] ; dlogits = scale * (softmax - onehot)           */

@@ -159,9 +159,10 @@ _SIGNATURES = {
     "msau_selfattn_fwd": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp] + [C.c_int] * 4),
     "msau_selfattn_bwd": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 4),
     "msau_label_counts": (C.c_int, [vp, vp, vp, C.c_int, i64]),
+    "msau_label_counts_split": (C.c_int, [vp, vp, vp, C.c_int, i64, C.c_int]),
     "msau_ce_ws_floats": (i64, [i64]),
     "msau_ce_multi_ws_floats": (i64, [i64]),
-    "msau_masked_ce_multi": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, C.c_int, f32]),
+    "msau_masked_ce_multi": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, C.c_int, f32, C.c_int]),
     "msau_masked_ce": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, C.c_int, f32]),
     "msau_softmax_ce": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, C.c_int, f32]),
     "msau_adam_ws_floats": (i64, [i64]),

@@ -1249,7 +1249,9 @@ class Plan:
         self.out_aux = torch.zeros((self.B, self.aux.C, self.aux.H, self.aux.W), dtype=torch.float32,
                                    device=self.device) if self.aux is not None else None
         if self.training:
-            self.counts = torch.zeros((self.B,), dtype=torch.int32, device=self.device)
+            # label counts: a sample spread over K workgroups (msau_label_counts_split), the K integers added up by the CE launch
+            self.counts_k = max(1, min(16, 256 // self.B)) if self.B <= 1024 and os.environ.get("MSAU_LABEL_SPLIT", "1") != "0" else 1
+            self.counts = torch.zeros((self.B * self.counts_k,), dtype=torch.int32, device=self.device)
             self.ce_ws = torch.zeros((int(L.load().msau_ce_ws_floats(self.B * HW)),), dtype=torch.float32, device=self.device)
             self.ce_multi_ws = torch.zeros((int(L.load().msau_ce_multi_ws_floats(self.B * HW)),), dtype=torch.float32, device=self.device)
             self.loss_buf = torch.zeros((1,), dtype=torch.float32, device=self.device)
@@ -1691,14 +1693,19 @@ class Plan:
         assert labels.dtype == torch.int64 and labels.is_contiguous() and tuple(labels.shape) == (self.B, self.H, self.W)
         s = self._stream()
         HW = self.H * self.W
-        L.call("msau_label_counts", s, labels.data_ptr(), self.counts.data_ptr(), self.B, HW)
         lg, ax = self.logits, self.aux
         if lg.Cs <= 16 and self.B * HW < (1 << 31) and (ax is None or (ax.C, ax.Cs) == (lg.C, lg.Cs)) \
                 and os.environ.get("MSAU_CE_MULTI", "1") != "0":
+            K = self.counts_k
+            if K > 1:
+                L.call("msau_label_counts_split", s, labels.data_ptr(), self.counts.data_ptr(), self.B, HW, K, key="msau_label_counts")
+            else:
+                L.call("msau_label_counts", s, labels.data_ptr(), self.counts.data_ptr(), self.B, HW)
             L.call("msau_masked_ce_multi", s, self.dtype, lg.data.data_ptr(), _ptr(ax.data) if ax is not None else None,
                    labels.data_ptr(), self.counts.data_ptr(), lg.grad.data_ptr(), _ptr(ax.grad) if ax is not None else None,
-                   self.loss_buf.data_ptr(), self.ce_multi_ws.data_ptr(), self.B, HW, lg.C, lg.Cs, 1.0 / self.B)
+                   self.loss_buf.data_ptr(), self.ce_multi_ws.data_ptr(), self.B, HW, lg.C, lg.Cs, 1.0 / self.B, K)
             return self.loss_buf
+        L.call("msau_label_counts", s, labels.data_ptr(), self.counts.data_ptr(), self.B, HW)
         self.loss_buf.zero_()
         for act in (self.logits, self.aux):
             if act is None:

@@ -345,7 +345,19 @@ def test_masked_ce_multi_equals_two_single_launches(dtype, C, with_aux):
     for _ in range(2):                                           # the scratch needs no re-initialisation between calls
         L.call("msau_masked_ce_multi", s, dt, lg.data_ptr(), ax.data_ptr() if with_aux else None, labels.data_ptr(),
                counts.data_ptr(), d0.data_ptr(), d1.data_ptr() if with_aux else None, loss.data_ptr(), ws2.data_ptr(),
-               B, H * W, C, Cs, 1.0 / B)
+               B, H * W, C, Cs, 1.0 / B, 1)
+    # the label counts as K partial counts per sample (msau_label_counts_split), added up by the CE launch: the same bits
+    for K in (2, 7, 16):
+        part = torch.full((B * K,), -5, dtype=torch.int32, device="cuda")
+        L.call("msau_label_counts_split", s, labels.data_ptr(), part.data_ptr(), B, H * W, K)
+        assert torch.equal(part.view(B, K).sum(1).to(torch.int32), counts)
+        loss_k = torch.full((1,), 321.0, device="cuda")
+        dk0, dk1 = torch.empty_like(lg), torch.empty_like(ax)
+        L.call("msau_masked_ce_multi", s, dt, lg.data_ptr(), ax.data_ptr() if with_aux else None, labels.data_ptr(),
+               part.data_ptr(), dk0.data_ptr(), dk1.data_ptr() if with_aux else None, loss_k.data_ptr(), ws2.data_ptr(),
+               B, H * W, C, Cs, 1.0 / B, K)
+        torch.cuda.synchronize()
+        assert torch.equal(dk0, d0) and torch.equal(loss_k, loss) and (not with_aux or torch.equal(dk1, d1))
     assert torch.equal(d0, d_ref[0])
     if with_aux:
         assert torch.equal(d1, d_ref[1])
