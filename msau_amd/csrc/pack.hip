@@ -67,30 +67,45 @@ __global__ void pack_kernel(const float* __restrict__ params, unsigned char* __r
     const int srows = e.rows_pad > 128 ? 128 : e.rows_pad;
     const int CT = srows >> 4;
     const int64_t total = (int64_t)e.nchunks * e.rows_pad * e.kchunk;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int k = (int)(i % e.kchunk);
-        int64_t r = i / e.kchunk;
-        int slot = (int)(r % srows);
-        int chunk = (int)((r / srows) % e.nchunks);
-        int slice = (int)(r / ((int64_t)srows * e.nchunks));
+    // a thread writes 8 consecutive k of one row (kchunk is a multiple of 32): one 16-byte (bf16) / two 16-byte (fp32) stores.  With
+    // one element per thread the launch was 18.5 k workgroups for 2.5 M elements -- 16 us of workgroup dispatch at the head of every step.
+    for (int64_t i8 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i8 < total; i8 += (int64_t)gridDim.x * blockDim.x * 8) {
+        const int k0 = (int)(i8 % e.kchunk);
+        const int64_t r = i8 / e.kchunk;
+        const int slot = (int)(r % srows);
+        const int chunk = (int)((r / srows) % e.nchunks);
+        const int slice = (int)(r / ((int64_t)srows * e.nchunks));
         // row slot (ct*16 + 4q + j)  <->  output channel q*CT*4 + ct*4 + j   (epilogue layout of conv.hip)
-        int ct = slot >> 4, q = (slot >> 2) & 3, j = slot & 3;
-        int row = slice * 128 + q * (CT * 4) + ct * 4 + j;
-        float v = 0.f;
-        if (row < e.rows_real && k < taps * e.cch) {
-            int tap = k / e.cch, c = k - tap * e.cch;
-            int kc = real_channel(chunk * e.cch + c, e.k1_real, e.k1_store, e.k2_real, e.k2_store);
-            if (kc >= 0) {
-                int ky = tap / e.KW, kx = tap - ky * e.KW;
-                if (e.flip) { ky = e.KH - 1 - ky; kx = e.KW - 1 - kx; }
-                int prow = e.row_off + row;
-                int i0 = e.row_is_dim0 ? prow : kc;
-                int i1 = e.row_is_dim0 ? kc : prow;
-                v = src[(((int64_t)i0 * e.dim1 + i1) * e.KH + ky) * e.KW + kx];
+        const int ct = slot >> 4, q = (slot >> 2) & 3, j = slot & 3;
+        const int row = slice * 128 + q * (CT * 4) + ct * 4 + j;
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u;
+            v[u] = 0.f;
+            if (row < e.rows_real && k < taps * e.cch) {
+                int tap = k / e.cch, c = k - tap * e.cch;
+                int kc = real_channel(chunk * e.cch + c, e.k1_real, e.k1_store, e.k2_real, e.k2_store);
+                if (kc >= 0) {
+                    int ky = tap / e.KW, kx = tap - ky * e.KW;
+                    if (e.flip) { ky = e.KH - 1 - ky; kx = e.KW - 1 - kx; }
+                    int prow = e.row_off + row;
+                    int i0 = e.row_is_dim0 ? prow : kc;
+                    int i1 = e.row_is_dim0 ? kc : prow;
+                    v[u] = src[(((int64_t)i0 * e.dim1 + i1) * e.KH + ky) * e.KW + kx];
+                }
             }
         }
-        if (e.dtype == MSAU_F32) reinterpret_cast<float*>(arena + e.dst_off)[i] = v;
-        else reinterpret_cast<bf16_t*>(arena + e.dst_off)[i] = (bf16_t)v;
+        if (e.dtype == MSAU_F32) {
+            float* dst = reinterpret_cast<float*>(arena + e.dst_off) + i8;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+            bf16x8 o;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[u] = (bf16_t)v[u];
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(arena + e.dst_off) + i8) = o;
+        }
     }
 }
 
@@ -188,7 +203,7 @@ __global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ s
 extern "C" int msau_pack_params(void* stream, const float* flat_params, void* pack_arena,
                                 const msau_pack_entry* table_dev, int n_entries, int max_elems_per_entry) {
     MSAU_CHECK_ARG(flat_params && pack_arena && table_dev && n_entries > 0, "pack_params: bad args");
-    int bx = cdiv(max_elems_per_entry, 256);
+    int bx = cdiv(max_elems_per_entry, 256 * 8);             // (8 elements per thread)
     if (bx > 64) bx = 64;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(pack_kernel, dim3(bx, n_entries), dim3(256), 0, static_cast<hipStream_t>(stream),
