@@ -611,3 +611,25 @@ def test_box_list_fed_step_at_the_size_of_baseline_config_4_vs_oracle(dtype):
         if float(ref.norm()) > 1e-4 * gn:
             assert err(got, ref, True) < tol, (k, err(got, ref, True))
     assert abs(float(eng.grad_norm) - gn) < (2e-3 if dtype == "fp32" else 3e-2) * gn
+
+
+@pytest.mark.gpu
+def test_fork_events_without_the_system_fence_give_the_same_bits(tmp_path):
+    """csrc/sequence.hip creates the main <-> side stream events with hipEventDisableSystemFence.  One cold
+    training step of the cfg-2 golden net per FRESH process (tools/det_check.py: exact fingerprints of every activation and
+    gradient): two processes with the flag, one with HIP's default events (MSAU_EVENT_FENCE=1) -- one bit pattern."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for i, fence in enumerate(("0", "1", "0")):
+        out = str(tmp_path / f"r{i}.pt")
+        env = dict(os.environ, MSAU_EVENT_FENCE=fence)
+        subprocess.run([sys.executable, os.path.join(root, "tools", "det_check.py"), "run", out], env=env, check=True, cwd=root,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+        outs.append(torch.load(out))
+    keys = list(outs[0])
+    assert len(keys) > 100 and set(keys) == set(outs[1]) == set(outs[2])
+    for d in outs[1:]:
+        bad = [k for k in keys if not torch.equal(outs[0][k], d[k])]
+        assert not bad, bad[:5]
