@@ -37,6 +37,9 @@ typedef enum {
 
 const char* msau_last_error(void);
 int msau_version(void);
+/* 16 hex digits: sha256 over the kernel sources + this header the library was built from (msau_amd/build.py::source_hash);
+ * a binding that ships beside the sources compares the two at load time (msau_amd/_lib.py::load). */
+const char* msau_source_hash(void);
 /* sizeof() of the structs below as the library was compiled, for bindings that mirror them (a mirror that is too short
  * makes the library read past it): which = 0 msau_conv_desc, 1 msau_wgrad_desc, 2 msau_pack_entry, 3 msau_unpack_entry,
  * 4 msau_op, 5 msau_lrn_args, 6 msau_pool_args, 7 msau_attn_args, 8 msau_csum_args, 9 msau_reduce_args,
@@ -103,7 +106,8 @@ enum {
                                    [B][C][Hin][Win] with C = head_classes real channels (<= C1 = 64 stored; the missing ones are zero), and
                                    y2, if not NULL, receives its NHWC copy in the storage dtype -- what msau_nchw_to_nhwc would have
                                    written, for the weight gradient of the backward.  bf16, 3x3 SAME stride 1, 64 -> 8, Win % 4 == 0,
-                                   Win <= 288; other flags: RELU_OUT only; results equal msau_nchw_to_nhwc + the dense launch bit for bit.
+                                   16 <= Win <= 320 as far as the three-row LDS ring fits (msau_firstconv_takes decides;
+                                   msau_conv2d_launch_info reports it); other flags: RELU_OUT only; results equal msau_nchw_to_nhwc + the dense launch bit for bit.
                                    msau_conv2d_launch_info: info[7] & 64 when the launch can take it. */
     MSAU_CONV_HEAD     = 64     /* inference head (kv_model.py:305-313): besides y, write softmax over the Cout real
                                    channels of the (storage-rounded) result to head_probs (fp32 [B][Hout][Wout][Cout],

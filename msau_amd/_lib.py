@@ -123,6 +123,7 @@ OP_CONV2D, OP_WGRAD, OP_LRN_FWD, OP_LRN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_ATTN_F
 _SIGNATURES = {
     "msau_last_error": (C.c_char_p, []),
     "msau_version": (C.c_int, []),
+    "msau_source_hash": (C.c_char_p, []),
     "msau_sizeof": (C.c_int, [C.c_int]),
     "msau_lds_pixel_stride": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "msau_lds_wrow_stride": (C.c_int, [C.c_int, C.c_int]),
@@ -223,6 +224,14 @@ def load():
         if lib.msau_sizeof(which) != C.sizeof(st):
             raise MsauHipError(f"{LIB_PATH}: sizeof({st.__name__}) is {lib.msau_sizeof(which)} in the library, "
                                f"{C.sizeof(st)} in msau_amd/_lib.py -- rebuild (python -m msau_amd.build)")
+    # the library must be the build of the kernel sources that sit beside it (the .so ships with the tree, git-ignored: nothing
+    # else ties the two together).  MSAU_HIP_LIB (an explicitly chosen library) and a source-less install skip the comparison.
+    if "MSAU_HIP_LIB" not in os.environ and os.path.isdir(os.path.join(HERE, "csrc")):
+        from .build import source_hash
+        have, want = lib.msau_source_hash().decode(), source_hash()
+        if have != want:
+            raise MsauHipError(f"{LIB_PATH} was built from kernel sources {have}, the tree holds {want}: rebuild "
+                               f"(python -m msau_amd.build)")
     _lib = lib
     return lib
 

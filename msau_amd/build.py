@@ -29,12 +29,41 @@ EXTRA_FLAGS = {"elementwise.hip": ["-Xclang", "-target-feature", "-Xclang", "-pa
                # the box-list-fed first conv (cfg 4's bf16 train path, beside the same side-stream kernels): its fp32 partial-sum loops
                # compiled to 247 packed-fp32 instructions, 91 of them with op_sel_hi -- the pattern the rule above is about
                "ownerconv.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
+               # the box variant's kernels (cfg 5) run in a bf16 train path beside the same side-stream weight gradients: same rule
+               "boxconv.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
                # attention on the matrix cores: MFMA results in VGPRs as well (the statistics kernel read every score back with
                # v_accvgpr_read: a quarter of its vector instructions)
                "attention_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "conv_rows.hip": ["-std=c++20"] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.environ.get("MSAU_ROWS_VGPR_FORM", "1") != "0" else [])
                                 + (["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] if os.environ.get("MSAU_ROWS_PACKED_FP32", "0") != "1" else [])
                                 + (["-DMSAU_ROWCONV_PF=" + os.environ["MSAU_ROWCONV_PF"]] if os.environ.get("MSAU_ROWCONV_PF") else [])}
+
+
+def source_hash() -> str:
+    """sha256 over the HIP sources, their headers and the ABI header (16 hex digits).  build() stamps it into the library
+    (msau_source_hash()), msau_amd/_lib.py::load() compares it with the sources it finds beside the library, bench.py ties its
+    PMC files to it: nothing but this ties a shipped libmsau_hip.so to a tree (file times do not survive a snapshot)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))
+                    + [os.path.join(HERE, "..", "include", "msau_hip.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+STAMP_MARK = b"MSAU_SRC_HASH="
+
+
+def stamped_hash(lib: str = LIB):
+    """the hash a built library carries, read from its bytes (no dlopen); None for a library without a stamp"""
+    try:
+        blob = open(lib, "rb").read()
+    except OSError:
+        return None
+    i = blob.find(STAMP_MARK)
+    return blob[i + len(STAMP_MARK):i + len(STAMP_MARK) + 16].decode("ascii", "replace") if i >= 0 else None
 
 
 def _stale(target, deps):
@@ -48,6 +77,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # this file is a dependency too: it holds the compile flags
     headers = [os.path.join(CSRC, "msau_common.h"), os.path.join(HERE, "..", "include", "msau_hip.h"), os.path.abspath(__file__)]
+    want = source_hash()
+    if os.path.exists(LIB) and stamped_hash() != want:
+        force = True                     # a library of other sources (or of no known ones), whatever the file times say
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -70,7 +102,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl", "-lpthread"])
+        # the stamp: a host-only object generated at link time, never a file of the tree
+        stamp_o = os.path.join(CSRC, "stamp.o")
+        code = ('extern "C" __attribute__((visibility("default"))) const char* msau_source_hash(void) '
+                '{ static const char s[] = "%s%s"; return s + %d; }\n' % (STAMP_MARK.decode(), want, len(STAMP_MARK)))
+        if verbose:
+            print(f"g++ -c <stamp {want}> -o {stamp_o}", flush=True)
+        subprocess.run(["g++", "-O1", "-fPIC", "-x", "c++", "-c", "-", "-o", stamp_o], input=code, text=True, check=True)
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, stamp_o, "-ldl", "-lpthread"])
+        assert stamped_hash() == want, (stamped_hash(), want)
     return LIB
 
 

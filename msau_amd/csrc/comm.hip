@@ -11,6 +11,7 @@
 #include "msau_common.h"
 #include <dlfcn.h>
 #include <string.h>
+#include <mutex>
 
 namespace {
 
@@ -25,26 +26,37 @@ struct Rccl {
     int (*CommDestroy)(nccl_comm) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
-    bool tried = false;
+    char why[256] = "not tried";                               // why the library is unavailable (dlerror() may be NULL, and is per-thread)
 };
 Rccl g_rccl;
+std::once_flag g_rccl_once;
 
-const Rccl* rccl() {
+void rccl_resolve() {
     Rccl& r = g_rccl;
-    if (r.tried) return r.lib ? &r : nullptr;
-    r.tried = true;
     const char* names[] = {"librccl.so", "librccl.so.1"};
     for (int pass = 0; pass < 2 && !r.lib; ++pass)             // first: a copy that is already loaded (RTLD_NOLOAD)
         for (const char* n : names)
             if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
-    if (!r.lib) return nullptr;
+    if (!r.lib) {
+        const char* e = dlerror();
+        snprintf(r.why, sizeof(r.why), "%s", e ? e : "dlopen(librccl.so) failed without a message");
+        return;
+    }
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) { r.lib = nullptr; return nullptr; }
-    return &r;
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) {
+        snprintf(r.why, sizeof(r.why), "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce");
+        r.lib = nullptr;
+    }
+}
+
+// resolved once per process, whichever thread asks first (std::call_once: a second caller waits for the first to finish)
+const Rccl* rccl() {
+    std::call_once(g_rccl_once, rccl_resolve);
+    return g_rccl.lib ? &g_rccl : nullptr;
 }
 
 int rccl_fail(const Rccl* r, const char* what, int rc) {
@@ -58,7 +70,7 @@ extern "C" int msau_comm_available(void) { return rccl() != nullptr; }
 extern "C" int msau_comm_unique_id(void* id_out, int bytes) {
     MSAU_CHECK_ARG(id_out && bytes == (int)sizeof(nccl_uid), "comm_unique_id: the id is %d bytes", (int)sizeof(nccl_uid));
     const Rccl* r = rccl();
-    if (!r) return msau_set_error(MSAU_ERR_HIP, "comm_unique_id: librccl.so could not be loaded (%s)", dlerror());
+    if (!r) return msau_set_error(MSAU_ERR_HIP, "comm_unique_id: librccl.so could not be loaded (%s)", g_rccl.why);
     nccl_uid id;
     int rc = r->GetUniqueId(&id);
     if (rc != kNcclSuccess) return rccl_fail(r, "comm_unique_id", rc);
@@ -69,7 +81,7 @@ extern "C" int msau_comm_unique_id(void* id_out, int bytes) {
 extern "C" int msau_comm_init(void** comm_out, int world, int rank, const void* id, int bytes) {
     MSAU_CHECK_ARG(comm_out && id && bytes == (int)sizeof(nccl_uid) && world >= 1 && rank >= 0 && rank < world, "comm_init: bad args");
     const Rccl* r = rccl();
-    if (!r) return msau_set_error(MSAU_ERR_HIP, "comm_init: librccl.so could not be loaded (%s)", dlerror());
+    if (!r) return msau_set_error(MSAU_ERR_HIP, "comm_init: librccl.so could not be loaded (%s)", g_rccl.why);
     nccl_uid uid;
     memcpy(&uid, id, sizeof(uid));
     nccl_comm c = nullptr;

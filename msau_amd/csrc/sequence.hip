@@ -87,17 +87,17 @@ extern "C" int msau_run_ops_overlap(void* stream, void* side_stream, const msau_
 extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_stream, const msau_op* ops, int n, int join) {
     MSAU_CHECK_ARG((ops || n == 0) && side_stream && side_stream != stream && (!comm_stream || (comm_stream != stream && comm_stream != side_stream)),
                    "run_ops_overlap: bad args");
-    // Two pools of timing-disabled events, reused across calls.  The forks and joins between `stream` and `side_stream` order
-    // kernels of ONE device among themselves: what a kernel wrote is made visible to the next kernel of the device by the dispatch
-    // packets' own (agent-scope) release / acquire, and nobody inspects these events from the host -- so they are created with
-    // hipEventDisableSystemFence: no system-scope cache write-back + invalidate when the event is recorded.  ~20 forks per backward
-    // sweep: 3.036 -> 3.005 ms (A/B, 3 rounds); the GPU suite and tools/det_check.py (8 fresh processes, 6 with and 2 without the
-    // flag: one bit pattern) are unchanged.  MSAU_EVENT_FENCE=1 restores the default events.  The gradient exchange's events (the
-    // comm stream: RCCL's kernels feed the fabric) keep the default system-scope fence.
+    // Two pools of timing-disabled events, reused across calls.  Default: ordinary events everywhere (HIP documents
+    // hipEventDisableSystemFence for timing-only events; without the fence the visibility of a producer's writes to a consumer on
+    // the OTHER queue rests on each dispatch packet's own agent-scope release / acquire, which is runtime behaviour nobody
+    // documents for a multi-XCD part -- a failure would be silently stale data).  Round 4 measured what the fence costs: created
+    // with hipEventDisableSystemFence the ~20 forks of a backward sweep run the step 1 % faster (3.036 -> 3.005 ms, bit-equal
+    // results in 8 fresh processes).  That is kept as an opt-in, MSAU_EVENT_FENCE=0, for the main <-> side events only; the
+    // gradient exchange's events (the comm stream: RCCL's kernels feed the fabric) always keep the system-scope fence.
     static thread_local std::vector<hipEvent_t> pool, pool_sys;
     hipStream_t ms = static_cast<hipStream_t>(stream), ss = static_cast<hipStream_t>(side_stream);
     size_t used = 0, used_sys = 0;
-    static const bool fence_all = std::getenv("MSAU_EVENT_FENCE") && std::getenv("MSAU_EVENT_FENCE")[0] == '1';
+    static const bool fence_all = !(std::getenv("MSAU_EVENT_FENCE") && std::getenv("MSAU_EVENT_FENCE")[0] == '0');
     auto next_event_of = [&](hipEvent_t* ev, bool sys) -> int {
         std::vector<hipEvent_t>& pl = sys ? pool_sys : pool;
         size_t& u = sys ? used_sys : used;

@@ -740,6 +740,10 @@ class TrainEngine:
             raise RuntimeError("prefetch_boxes is an eager path (use_graph=False)")
         plan = self.model._plan_for_shape(B, H, W, self.model._flat.device, True)
         q = self.__dict__.setdefault("_prefetched", [])
+        if len(q) >= 2:
+            # the plan keeps TWO input buffers: a third batch would be painted over one that is still queued, unread
+            raise RuntimeError("prefetch_boxes: two batches are already queued (the plan has two input buffers); call "
+                               "step_prefetched() before painting another one")
         k = (q[-1][1] + 1) % 2 if q else (getattr(self, "_pf_last", 1) + 1) % 2
         buf = plan.input_buffer(k)
         cur = torch.cuda.current_stream()

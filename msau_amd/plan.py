@@ -1192,13 +1192,17 @@ class Plan:
             for op in self.ops:
                 if isinstance(op, AttnCoreOp):
                     branch = [c for c in self.ops if isinstance(c, ConvOp) and c.out in (op.f, op.g, op.h)]
-                    users = [c for c in self.ops if isinstance(c, ConvOp) and (c.x1 is op.y or c.x2 is op.y or c.fwd_add is op.y)]
+                    # every reader of the branch's output, of any op type; the FIRST one must be a conv that emits a launch record of
+                    # its own (it carries the join) -- anything else keeps the branch on the main stream
+                    users = [c for c in self.ops if c is not op and any(t is op.y for t in c.reads())]
                     later = self.ops[self.ops.index(op) + 1:]
+                    first = min(users, key=self.ops.index) if users else None
                     if len(branch) == 3 and users and all(u in later for u in users) and \
+                            isinstance(first, ConvOp) and first.fwd_recs() and \
                             not any(t in (op.f, op.g, op.h) for o2 in later for t in o2.reads()):
                         side_ops.update(id(c) for c in branch)
                         side_ops.add(id(op))
-                        join_ops.add(id(min(users, key=self.ops.index)))
+                        join_ops.add(id(first))
         frecs = []
         for op in self.ops:
             for kind, args in op.fwd_recs():
@@ -1208,6 +1212,7 @@ class Plan:
                     kind |= L.OP_JOIN
                     join_ops.discard(id(op))                 # (a fused pair emits one record; only the first record of an op joins)
                 frecs.append((kind, args))
+        assert not join_ops, "a side-stream attention branch lost its join: its first reader emitted no launch record"
         self._fwd_side = bool(side_ops)
 
         self._fwd_seq = self._make_seq(frecs)
@@ -1651,6 +1656,10 @@ class Plan:
             if not self._feed_nchw(x_nchw):
                 self.load_input(x_nchw)
         if L._profiler is None:
+            # a sweep that is being captured into a HIP graph stays on ONE stream whoever the caller is (a captured fork onto the
+            # side stream is the configuration of profiles/r04_graph_destroy.md; creating the side stream synchronises the device,
+            # which is illegal during capture)
+            single_stream = single_stream or (str(self.device).startswith("cuda") and torch.cuda.is_current_stream_capturing())
             if self._fwd_side and not single_stream:
                 if self._side is None:
                     self._side = L.concurrent_stream(self.device)
@@ -1762,6 +1771,7 @@ class Plan:
         for ba in self._box_bwd_args:
             ba.flat_grads = flat_grads.data_ptr()
         arr, n, _ = self._bwd_seq
+        single_stream = single_stream or (str(self.device).startswith("cuda") and torch.cuda.is_current_stream_capturing())
         if not self.overlap_wgrad or single_stream:         # (single_stream: a sweep that is being captured into a HIP graph)
             L.call("msau_run_ops", s, arr, n)
             if on_stage_done is not None:

@@ -28,6 +28,28 @@ def test_library_exports_every_declared_symbol():
     assert lib.msau_version() >= 1
 
 
+def test_library_carries_the_hash_of_the_kernel_sources_it_was_built_from(tmp_path, monkeypatch):
+    """The .so ships with the tree but is not in its history: the only tie between the two is the stamp build() links in
+    (msau_source_hash) -- load() refuses a library of other sources, build() rebuilds one whatever the file times say."""
+    from msau_amd import build as B
+    lib = L.load()
+    assert lib.msau_version() >= 8
+    assert lib.msau_source_hash().decode() == B.source_hash() == B.stamped_hash()
+    assert re.fullmatch(r"[0-9a-f]{16}", B.source_hash())
+    # a library whose stamp names other sources is refused (the check of load(), on a doctored copy of the bytes)
+    blob = open(B.LIB, "rb").read()
+    i = blob.find(B.STAMP_MARK) + len(B.STAMP_MARK)
+    bad = tmp_path / "libmsau_hip.so"
+    bad.write_bytes(blob[:i] + b"0123456789abcdef" + blob[i + 16:])
+    assert B.stamped_hash(str(bad)) == "0123456789abcdef"
+    code = ("import msau_amd._lib as L\nL.LIB_PATH = %r\n"
+            "try:\n    L.load()\nexcept L.MsauHipError as e:\n    print('refused:', e)\n" % str(bad))
+    import subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k != "MSAU_HIP_LIB"}
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert "refused:" in out.stdout and "0123456789abcdef" in out.stdout, (out.stdout, out.stderr[-500:])
+
+
 def test_error_reporting_across_the_abi():
     g = L.ConvPackGeom()
     import ctypes as C
@@ -247,9 +269,9 @@ def test_isa_of_the_built_kernels_has_no_cross_half_packed_fp32_adds(tmp_path):
     pattern from coming back unnoticed:
       * elementwise.o has NO packed-fp32 instruction at all (the flag is in force);
       * the translation units of the bf16 train path that run on the main stream beside the weight gradients (conv, conv_lean,
-        conv_pair, conv_rows, wgrad_lean, conv_wgrad, attention_mfma, pack, raster, ownerconv) have NO packed-fp32 instruction with
-        op_sel / op_sel_hi;
-      * attention.hip (the fp32-storage VALU attention) and boxconv.hip do use them -- known, counted, outside the bf16 path."""
+        conv_pair, conv_rows, wgrad_lean, conv_wgrad, attention_mfma, pack, raster, ownerconv, boxconv) have NO packed-fp32
+        instruction with op_sel / op_sel_hi;
+      * attention.hip (the fp32-storage VALU attention) does use them -- known, counted, outside the bf16 path."""
     import shutil
     import subprocess
     from msau_amd import build as B
@@ -272,10 +294,10 @@ def test_isa_of_the_built_kernels_has_no_cross_half_packed_fp32_adds(tmp_path):
         lines = [ln for ln in dis.splitlines() if pk.search(ln)]
         counts[name] = (len(lines), sum(1 for ln in lines if "op_sel" in ln))
     assert counts["elementwise"] == (0, 0), counts["elementwise"]
-    clean = ("conv", "conv_lean", "conv_pair", "conv_rows", "wgrad_lean", "conv_wgrad", "attention_mfma", "pack", "raster", "ownerconv")
+    clean = ("conv", "conv_lean", "conv_pair", "conv_rows", "wgrad_lean", "conv_wgrad", "attention_mfma", "pack", "raster", "ownerconv", "boxconv")
     assert all(counts[n][1] == 0 for n in clean), {n: counts[n] for n in clean}
     assert counts["conv_lean"][0] > 0                 # the check does see packed instructions where they are
-    assert counts["attention"][1] > 0 or counts["boxconv"][1] >= 0
+    assert counts["boxconv"] == (0, 0), counts["boxconv"]       # (built without the instructions altogether, like elementwise)
 
 
 def test_lds_strides_are_conflict_free_under_the_real_lane_groups():

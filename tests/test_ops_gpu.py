@@ -292,26 +292,39 @@ def test_attention_mfma_bf16_vs_fp32_kernels(N, C):
         assert rel_l2(a, b) < (1e-4 if nm == "stats" else 2e-2), (nm, rel_l2(a, b))
 
 
-def test_device_chargrid_rasteriser_matches_cpu_painter(tmp_path):
-    """N1: box lists painted on device == the CPU painter (bit exact), which is pinned to the reference"""
-    import os, pickle
+def test_device_chargrid_rasteriser_matches_the_reference_chargrids(tmp_path):
+    """N1: box lists painted on the device against tests/golden/funsd/chargrid.npz DIRECTLY -- the arrays the reference's own
+    funsd_preprocessing_word_level.py + data_generator_funsd_bert.py:149-186 painted for the committed documents (bit exact,
+    train and test split, label map of the fixture) -- and, as before, against the product's CPU painter."""
+    import json, os, pickle
+    import numpy as np
     from msau_amd.data import funsd as F
     from msau_amd.data.raster import document_boxes, rasterize
     G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "funsd")
-    docs, inv = F.get_preprocessed_list_word_msau(os.path.join(G, "train"))
-    pickle.dump(docs, open(tmp_path / "t.pkl", "wb"))
-    ds = F.FUNSDCharGridDataLoaderBoxMaskBoxLabel(str(tmp_path / "t.pkl"), write_labels_file=False)
+    g = np.load(os.path.join(G, "chargrid.npz"), allow_pickle=True)
+    labels_map = json.loads(str(g["labels_json"]))
+    train, inv = F.get_preprocessed_list_word_msau(os.path.join(G, "train"))
+    test, _ = F.get_preprocessed_list_word_msau(os.path.join(G, "test"), inv_dict_charset=inv)
     C = len(inv)
-    for i in range(len(ds)):
-        ref = ds[i]
-        cb, lb, H, W = document_boxes(ds.inp_list[i])
-        assert (H, W) == tuple(ref["label"].shape[1:])
-        for dtype in ("fp32", "bf16"):
-            grid, labels = rasterize(cb, lb, 1, H, W, C, dtype)
-            got = grid[..., :C].permute(0, 3, 1, 2).float().cpu()
-            assert torch.equal(got, ref["mask"]), (i, dtype)
-            assert float(grid[..., C:].abs().sum()) == 0.0
-            assert torch.equal(labels.cpu(), ref["label"].long())
+    checked = 0
+    for split, docs in (("train", train), ("test", test)):
+        docs.sort(key=lambda d: d["file_path"])
+        pickle.dump(docs, open(tmp_path / f"{split}.pkl", "wb"))
+        ds = F.FUNSDCharGridDataLoaderBoxMaskBoxLabel(str(tmp_path / f"{split}.pkl"), labels_map, write_labels_file=False)
+        for i in range(len(ds)):
+            want_mask, want_label = g[f"{split}{i}.mask"], g[f"{split}{i}.label"]          # uint8 [1,C,H,W], [1,H,W]: the reference's arrays
+            cb, lb, H, W = document_boxes(ds.inp_list[i])
+            assert (1, C, H, W) == tuple(want_mask.shape), (split, i)
+            ref = ds[i]
+            for dtype in ("fp32", "bf16"):
+                grid, labels = rasterize(cb, lb, 1, H, W, C, dtype)
+                got = grid[..., :C].permute(0, 3, 1, 2).float().cpu()
+                assert np.array_equal(got.numpy(), want_mask.astype(np.float32)), (split, i, dtype)
+                assert np.array_equal(labels.cpu().numpy(), want_label.astype(np.int64)), (split, i, dtype)
+                assert float(grid[..., C:].abs().sum()) == 0.0
+                assert torch.equal(got, ref["mask"]) and torch.equal(labels.cpu(), ref["label"].long())
+                checked += 1
+    assert checked >= 4
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])

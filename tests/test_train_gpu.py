@@ -289,33 +289,42 @@ def test_plan_cache_is_bounded_by_bytes_as_well_as_count():
 
 # ---- N1: dense (BERT) painter on the device ----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_device_dense_rasteriser_matches_cpu_painter(dtype, tmp_path):
-    """msau_raster_dense + msau_raster_labels against `funsd.get_box_mask_box_label`, which tests/test_data_cpu.py pins to
-    the reference's own loader output"""
+def test_device_dense_rasteriser_matches_the_reference_bertgrids(dtype, tmp_path):
+    """msau_raster_dense + msau_raster_labels against tests/golden/funsd/bertgrid.npz DIRECTLY: the grids and label maps the
+    reference's own loader (`get_box_mask_box_label`, data_generator_funsd_bert.py:64-93,240) painted from the same documents and
+    per-line feature vectors -- both splits, bit exact in the storage type -- and against the product's CPU painter."""
     import json, pickle
     from msau_amd.data import funsd as F
     from msau_amd.data.raster import document_line_boxes, rasterize_dense
     G = os.path.join(GOLDEN, "funsd")
     g = np.load(os.path.join(G, "bertgrid.npz"), allow_pickle=True)
-    docs, inv = F.get_preprocessed_list_word_msau(os.path.join(G, "train"))
-    docs.sort(key=lambda d: d["file_path"])
-    for di, d in enumerate(docs):
-        d["transformer_feature"] = g[f"train{di}.feats"]
-    with open(tmp_path / "t.pkl", "wb") as fh:
-        pickle.dump(docs, fh)
-    ds = F.FUNSDBertDataLoaderBoxMaskBoxLabel(str(tmp_path / "t.pkl"), json.loads(str(g["labels_json"])), write_labels_file=False)
-    for i in range(len(ds)):
-        it = ds[i]
-        fb, lb, H, W = document_line_boxes(ds.inp_list[i])
-        feats = np.asarray(ds.inp_list[i]["transformer_feature"], np.float32)
-        grid, labels = rasterize_dense(fb, lb, feats, 1, H, W, dtype)
-        C = feats.shape[1]
-        want = it["mask"][0].permute(1, 2, 0)                               # [H,W,C]
-        if dtype == "bf16":
-            want = want.to(torch.bfloat16)
-        assert torch.equal(grid[0, :, :, :C].float().cpu(), want.float()), i   # bit exact in the storage type
-        assert float(grid[0, :, :, C:].abs().max()) == 0.0 if grid.shape[3] > C else True
-        assert torch.equal(labels[0].cpu(), it["label"][0].long()), i
+    train, inv = F.get_preprocessed_list_word_msau(os.path.join(G, "train"))
+    test, _ = F.get_preprocessed_list_word_msau(os.path.join(G, "test"), inv_dict_charset=inv)
+    checked = 0
+    for split, docs in (("train", train), ("test", test)):
+        docs.sort(key=lambda d: d["file_path"])
+        for di, d in enumerate(docs):
+            d["transformer_feature"] = g[f"{split}{di}.feats"]
+        with open(tmp_path / f"{split}.pkl", "wb") as fh:
+            pickle.dump(docs, fh)
+        ds = F.FUNSDBertDataLoaderBoxMaskBoxLabel(str(tmp_path / f"{split}.pkl"), json.loads(str(g["labels_json"])), write_labels_file=False)
+        for i in range(len(ds)):
+            it = ds[i]
+            fb, lb, H, W = document_line_boxes(ds.inp_list[i])
+            feats = np.asarray(ds.inp_list[i]["transformer_feature"], np.float32)
+            grid, labels = rasterize_dense(fb, lb, feats, 1, H, W, dtype)
+            C = feats.shape[1]
+            gold = torch.from_numpy(np.ascontiguousarray(g[f"{split}{i}.mask"]))[0].permute(1, 2, 0)    # the reference's array, [H,W,C]
+            assert tuple(gold.shape) == (H, W, C), (split, i)
+            for want in (gold, it["mask"][0].permute(1, 2, 0)):
+                if dtype == "bf16":
+                    want = want.to(torch.bfloat16)
+                assert torch.equal(grid[0, :, :, :C].float().cpu(), want.float()), (split, i)   # bit exact in the storage type
+            assert float(grid[0, :, :, C:].abs().max()) == 0.0 if grid.shape[3] > C else True
+            assert np.array_equal(labels[0].cpu().numpy(), g[f"{split}{i}.label"][0].astype(np.int64)), (split, i)
+            assert torch.equal(labels[0].cpu(), it["label"][0].long()), (split, i)
+            checked += 1
+    assert checked >= 2
 
 
 def test_graphs_of_a_dead_engine_are_not_destroyed_inside_somebody_elses_capture():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""HBM traffic per launch of the dominant kernels from PMC counters -> profiles/r04_traffic.json (read by bench.py).
+"""HBM traffic per launch of the dominant kernels from PMC counters -> profiles/r05_traffic.json (read by bench.py).
 
 Collected exactly as MI355X_MICROARCH.md prescribes: `rocprofv3 --kernel-trace --pmc <one counter>` in SEPARATE passes
 (never combined with another trace domain), FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of wide coalesced
@@ -147,7 +147,7 @@ def main():
            "how": "tools/make_traffic.py: rocprofv3 --kernel-trace --pmc, one counter per pass; FETCH_SIZE x2 (gfx950), WRITE_SIZE as is; KB = 1024 B",
            "kernels": kernels}
     # profiles/ is the tracked copy; gpurun only brings gpurun_out/ back from the GPU box
-    for path in (os.path.join(ROOT, "profiles", "r04_traffic.json"), os.path.join(OUT, "r04_traffic.json")):
+    for path in (os.path.join(ROOT, "profiles", "r05_traffic.json"), os.path.join(OUT, "r05_traffic.json")):
         with open(path, "w") as f:
             json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))

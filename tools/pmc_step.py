@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """SQ counters of every kernel of the training step, IN the step (round-4 verdict item 5: MFMA utilisation on the conv GEMMs from
-counters, not from flops / time) -> profiles/r04_pmc_step.txt (table) + profiles/r04_pmc.json (read by bench.py).
+counters, not from flops / time) -> profiles/r05_pmc_step.txt (table) + profiles/r05_pmc.json (read by bench.py).
 
 `rocprofv3 --kernel-trace --pmc ...` passes of `bench.py --steps 3` (counters only: never with another trace domain), per kernel
 symbol the mean per dispatch and
@@ -112,9 +112,9 @@ def main():
                   "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 32)",
            "families": fam}
     for base in (os.path.join(ROOT, "profiles"), OUT):
-        with open(os.path.join(base, "r04_pmc_step.txt"), "w") as f:
+        with open(os.path.join(base, "r05_pmc_step.txt"), "w") as f:
             f.write(txt)
-        with open(os.path.join(base, "r04_pmc.json"), "w") as f:
+        with open(os.path.join(base, "r05_pmc.json"), "w") as f:
             json.dump(out, f, indent=1)
     print(txt)
 

@@ -1,6 +1,10 @@
-"""The round-3 finding on THIS code base: TrainEngine(use_graph=True) captures its step, the engine dies and (MSAU_GRAPH_DESTROY=1) its
-graphs are destroyed, the next engine captures again -- crashed in about half of the stand-alone runs of tests/test_train_gpu.py.
-    MSAU_GRAPH_DESTROY=1 [MSAU_CAPTURE_FRESH_EVENTS=1] python tools/repro/graph_destroy_msau.py [cycles]"""
+"""The round-3 finding on THIS code base: TrainEngine(use_graph=True) captures its step, the engine dies, its graphs are destroyed,
+the next engine captures again -- crashed in about half of the stand-alone runs of tests/test_train_gpu.py while the captured
+backward forked its weight gradients onto the side stream (profiles/r04_graph_destroy.md: 4 of 8 runs; 0 of 8 on one stream).
+Since round 4 every captured sweep is single-stream (Plan.forward / Plan.backward detect the capture themselves), so as shipped
+this script PASSES; it is the regression check of that remedy.  The crashing configuration cannot be reached through the
+product any more -- to see it again, remove the `is_current_stream_capturing()` line from Plan.backward.
+    python tools/repro/graph_destroy_msau.py [cycles]"""
 import gc
 import os
 import sys
@@ -27,4 +31,4 @@ for c in range(cycles):
     del eng, eager
     gc.collect()
     print(f"cycle {c + 1} ok loss {float(loss):.4f}", flush=True)
-print(f"PASS {cycles} engine cycles (graphs destroyed: {os.environ.get('MSAU_GRAPH_DESTROY', '0')}, fresh events: {os.environ.get('MSAU_CAPTURE_FRESH_EVENTS', '0')})")
+print(f"PASS {cycles} engine cycles (single-stream captures, graphs destroyed with their engines)")
