@@ -131,3 +131,31 @@ def test_gradient_exchange_through_the_c_abi_equals_the_torch_distributed_path()
     import numpy as np
     assert np.array_equal(out["1"][1], out["0"][1]) and np.array_equal(out["1"][1], ref)
     assert out["1"][0] == out["0"][0] == float(loss)
+
+
+def test_bench_py_scale_command_path_with_two_ranks():
+    """The exact command path of the driver's SCALE run, which no 8-GPU node has exercised yet: `bench.py --gpus 2` relaunches
+    itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 ...` as a CHILD process
+    (before its own first GPU call), every rank builds the engine with a process group, the timed region is bracketed by
+    barrier + synchronize, the MAX over ranks is taken and rank 0 prints ONE JSON line.  Here both ranks share cuda:0
+    (MSAU_BENCH_DEVICE=0) over gloo (RCCL refuses two ranks on one device); a smaller image keeps it to seconds."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MSAU_BENCH_DEVICE="0", MSAU_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MSAU_FORCE_DIST", "MSAU_DP_NATIVE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4",
+           "--height", "168", "--width", "128", "--no-secondary", "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                                           # ONE JSON line on stdout, whatever the libraries print
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
+    assert out["unit"] == "tiles/s" and out["value"] > 0 and out["higher_is_better"] is True
+    assert abs(out["value"] - 8 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-2 * out["value"]     # whole-job tiles over the MAX-over-ranks time
+    loss = out["config"]["loss"]
+    assert loss == loss and 0.0 < loss < 50.0, loss                         # finite

@@ -31,7 +31,9 @@ pytestmark = pytest.mark.gpu
 ACC = 3e-5                 # fp32 accumulation slack, relative to the sum of |terms| of an output element
 
 
-def nchw(t, C):
+def nchw(t, C, samples=None):
+    if samples is not None:
+        t = t[list(samples)]
     return t[..., :C].permute(0, 3, 1, 2).double().cpu().contiguous()
 
 
@@ -79,17 +81,26 @@ def lrn_bwd_ref(a, dy):
 
 
 class Checker:
-    def __init__(self, m, eng, plan, sd0, labels, max_h):
-        self.m, self.eng, self.plan, self.labels, self.max_h = m, eng, plan, labels, max_h
+    def __init__(self, m, eng, plan, sd0, labels, max_h, min_h=0, samples=None):
+        """`samples`: check the forward outputs and stored gradients of these batch elements only (every op is per sample;
+        the float64 references of all 16 bench-size images would take minutes) -- weight gradients always sum the whole batch.
+        `min_h` < H <= `max_h`: the levels whose tensors are checked."""
+        self.m, self.eng, self.plan, self.labels, self.max_h, self.min_h = m, eng, plan, labels, max_h, min_h
+        self.samples = None if samples is None else sorted(set(samples))
+        self.nb = plan.B if samples is None else len(self.samples)
         # the packed images hold bf16(fp32 master weight); biases stay fp32
         self.sd = {k: (v.bfloat16().double() if k.endswith("weight") else v.double()) for k, v in sd0.items()}
         self.nchecked = 0
 
     def small(self, act):
-        return act.H <= self.max_h
+        return self.min_h < act.H <= self.max_h
 
-    def source(self, op):
-        xs = [nchw(op.x1.data, op.x1.C)] + ([nchw(op.x2.data, op.x2.C)] if op.x2 is not None else [])
+    def n(self, t, C):
+        return nchw(t, C, self.samples)
+
+    def source(self, op, whole_batch=False):
+        n = nchw if whole_batch else self.n
+        xs = [n(op.x1.data, op.x1.C)] + ([n(op.x2.data, op.x2.C)] if op.x2 is not None else [])
         inp = torch.cat(xs, 1)
         return torch.relu(inp) if op.relu_in else inp
 
@@ -102,30 +113,30 @@ class Checker:
                 y = conv_ref(op, self.sd, inp)
                 S = conv_ref(op, self.sd, inp.abs(), self.sd[op.wname].abs(), self.sd[op.bname].abs())
                 if op.fwd_add is not None:
-                    add = nchw(op.fwd_add.data, op.fwd_add.C)
+                    add = self.n(op.fwd_add.data, op.fwd_add.C)
                     y, S = y + add, S + add.abs()
                 if op.relu_out:
                     y = torch.relu(y)
-                assert_rounded(nchw(op.out.data, op.out.C), y, ACC * S, f"forward {op.name}")
+                assert_rounded(self.n(op.out.data, op.out.C), y, ACC * S, f"forward {op.name}")
                 self.nchecked += 1
             elif isinstance(op, LrnOp) and self.small(op.y):
-                a = nchw(op.a.data, op.a.C)
+                a = self.n(op.a.data, op.a.C)
                 y = O.lrn(a, op.a.C)
-                assert_rounded(nchw(op.y.data, op.y.C), y, 2e-6 * y.abs(), f"forward {op.name}")
+                assert_rounded(self.n(op.y.data, op.y.C), y, 2e-6 * y.abs(), f"forward {op.name}")
                 self.nchecked += 1
             elif isinstance(op, PoolOp) and self.small(op.x):
-                x = nchw(op.x.data, op.x.C)
+                x = self.n(op.x.data, op.x.C)
                 y = F.max_pool2d(F.pad(x, (0, op.x.W % 2, 0, op.x.H % 2)), 2, 2)
-                assert torch.equal(nchw(op.y.data, op.y.C), y), f"forward {op.name}"
+                assert torch.equal(self.n(op.y.data, op.y.C), y), f"forward {op.name}"
                 self.nchecked += 1
             elif isinstance(op, AttnCoreOp) and self.small(op.y):
-                B, N = P.B, op.N
-                f, g, h, x = (nchw(t.data, t.C).reshape(B, t.C, N) for t in (op.f, op.g, op.h, op.x))
+                B, N = self.nb, op.N
+                f, g, h, x = (self.n(t.data, t.C).reshape(B, t.C, N) for t in (op.f, op.g, op.h, op.x))
                 beta = torch.softmax(torch.matmul(g.transpose(1, 2), f), dim=-1)
                 y = torch.matmul(h, beta) + x
                 # the probabilities enter the second product rounded to bf16: 2^-9 of every |term|
                 S = torch.matmul(h.abs(), beta)
-                assert_rounded(nchw(op.y.data, op.y.C).reshape(B, -1, N), y, 2.0 ** -8 * S + ACC * x.abs(), f"forward {op.name}")
+                assert_rounded(self.n(op.y.data, op.y.C).reshape(B, -1, N), y, 2.0 ** -8 * S + ACC * x.abs(), f"forward {op.name}")
                 self.nchecked += 1
 
     # ---- backward: the stored gradient of an activation = sum of its consumers' contributions ---------------------------
@@ -133,19 +144,19 @@ class Checker:
         """d(conv output)/d(source src_index) applied to g: float64 autograd through conv_ref (a linear map)"""
         C1 = op.x1.C
         Cin = C1 + (op.x2.C if op.x2 is not None else 0)
-        z = torch.zeros((self.plan.B, Cin, op.x1.H, op.x1.W), dtype=torch.float64, requires_grad=True)
+        z = torch.zeros((self.nb, Cin, op.x1.H, op.x1.W), dtype=torch.float64, requires_grad=True)
         w = self.sd[op.wname]
         conv_ref(op, self.sd, z, w.abs() if absolute else w, torch.zeros_like(self.sd[op.bname])).backward(g.abs() if absolute else g)
         return z.grad[:, :C1] if src_index == 0 else z.grad[:, C1:]
 
     def ce_grad(self, act):
-        lg = nchw(act.data, act.C)
-        lab = self.labels.cpu()
+        lg = self.n(act.data, act.C)
+        lab = self.labels.cpu() if self.samples is None else self.labels[self.samples].cpu()
         B = lg.shape[0]
         p = torch.softmax(lg, 1)
         oh = F.one_hot(lab, act.C).permute(0, 3, 1, 2).double()
         cnt = (lab != 0).reshape(B, -1).sum(1).clamp_min(1).double().view(B, 1, 1, 1)
-        return (p - oh) * (lab != 0).unsqueeze(1).double() / cnt / B
+        return (p - oh) * (lab != 0).unsqueeze(1).double() / cnt / self.plan.B             # (mean over the WHOLE batch)
 
     def unwritten(self, act):
         """gradient buffers no launch writes: an LRN output whose backward rides on the pair launch (dy never stored) and the
@@ -163,11 +174,11 @@ class Checker:
         for t in P.acts:
             if t.grad is None or not self.small(t) or self.unwritten(t) or t.n_contrib == 0:
                 continue
-            tot = torch.zeros((P.B, t.C, t.H, t.W), dtype=torch.float64)
+            tot = torch.zeros((self.nb, t.C, t.H, t.W), dtype=torch.float64)
             S = torch.zeros_like(tot)
             mag = torch.zeros_like(tot)
             n, ok = 0, True
-            data = nchw(t.data, t.C)
+            data = self.n(t.data, t.C)
             for op in P.ops:
                 if isinstance(op, ConvOp):
                     for si, x in enumerate((op.x1, op.x2)):
@@ -175,25 +186,25 @@ class Checker:
                             if self.unwritten(op.out):
                                 ok = False
                                 continue
-                            g = nchw(op.out.grad, op.out.C)
+                            g = self.n(op.out.grad, op.out.C)
                             part, pabs = self.conv_dgrad(op, g, si), self.conv_dgrad(op, g, si, True)
                             if op.relu_in:
                                 part, pabs = part * (data > 0), pabs * (data > 0)
                             tot, S, n, mag = tot + part, S + pabs, n + 1, mag + part.abs()
                             if si == 0 and op.bwd_add is not None:
-                                ga = nchw(op.bwd_add.grad, op.bwd_add.C)
+                                ga = self.n(op.bwd_add.grad, op.bwd_add.C)
                                 tot, S, mag = tot + ga, S + ga.abs(), mag + ga.abs()
                 elif isinstance(op, LrnOp) and op.a is t:
                     if self.unwritten(op.y):
                         ok = False
                         continue
-                    dy = nchw(op.y.grad, op.y.C)
+                    dy = self.n(op.y.grad, op.y.C)
                     part, terms = lrn_bwd_ref(data, dy)
                     tot, S, n, mag = tot + part, S + 0.2 * terms, n + 1, mag + part.abs()
                 elif isinstance(op, PoolOp) and op.x is t and op.y.grad is not None:
-                    dy = nchw(op.y.grad, op.y.C)
-                    idx = op.idx[..., :t.C].permute(0, 3, 1, 2).cpu().long()
-                    part = torch.zeros((P.B, t.C, 2 * op.y.H, 2 * op.y.W), dtype=torch.float64)
+                    dy = self.n(op.y.grad, op.y.C)
+                    idx = (op.idx if self.samples is None else op.idx[self.samples])[..., :t.C].permute(0, 3, 1, 2).cpu().long()
+                    part = torch.zeros((self.nb, t.C, 2 * op.y.H, 2 * op.y.W), dtype=torch.float64)
                     for pos in range(4):
                         part[:, :, pos // 2::2, pos % 2::2] = dy * (idx == pos)
                     tot, n, mag = tot + part[:, :, :t.H, :t.W], n + 1, mag + part[:, :, :t.H, :t.W].abs()
@@ -207,19 +218,19 @@ class Checker:
                 continue
             if t.relu_out:
                 tot, S = tot * (data > 0), S * (data > 0)
-            assert_rounded(nchw(t.grad, t.C), tot, ACC * S, f"gradient of {t.name} ({n} contributions)", half_ulps=n, mag=mag)
+            assert_rounded(self.n(t.grad, t.C), tot, ACC * S, f"gradient of {t.name} ({n} contributions)", half_ulps=n, mag=mag)
             self.nchecked += 1
 
     def weight_grads(self, names=None, bound=2e-5):
         P, m = self.plan, self.m
         out = {}
         for op in P.ops:
-            if not isinstance(op, ConvOp) or op.wdesc is None or op.out.grad is None or not self.small(op.out) or not self.small(op.x1):
+            if not isinstance(op, ConvOp) or op.wdesc is None or op.out.grad is None or not self.small(op.out):
                 continue
             if self.unwritten(op.out) or (names is not None and op.name not in names):
                 continue
             g = nchw(op.out.grad, op.out.C)
-            inp = self.source(op)
+            inp = self.source(op, whole_batch=True)
             res = []
             for absolute in (False, True):
                 w = self.sd[op.wname].clone().requires_grad_(True)
@@ -238,7 +249,7 @@ class Checker:
         return out
 
 
-def _run(B, H, W, C, seed, env, max_h, monkeypatch):
+def _run(B, H, W, C, seed, env, max_h, monkeypatch, min_h=0, samples=None):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     L.load().msau_reload_env()
@@ -253,33 +264,46 @@ def _run(B, H, W, C, seed, env, max_h, monkeypatch):
     eng.step(x.cuda(), label.cuda())
     torch.cuda.synchronize()
     plan = m._plan_for_shape(B, H, W, torch.device("cuda", 0), True)
-    return Checker(m, eng, plan, sd0, label.cuda().reshape(B, H, W), max_h)
+    return Checker(m, eng, plan, sd0, label.cuda().reshape(B, H, W), max_h, min_h, samples)
 
 
-@pytest.mark.parametrize("B,H,W,max_h", [(3, 176, 144, 10 ** 6), (16, 336, 256, 84)])
-def test_every_launch_is_correctly_rounded(monkeypatch, B, H, W, max_h):
+# (B, H, W, min_h, max_h, samples)
+CASES = [pytest.param(3, 176, 144, 0, 10 ** 6, None, id="3x176x144-all-levels"),
+         pytest.param(16, 336, 256, 0, 84, None, id="bench-shape-levels-2-3"),
+         pytest.param(16, 336, 256, 84, 10 ** 6, (0, 15), id="bench-shape-levels-0-1-samples-0-15")]
+
+
+@pytest.mark.parametrize("B,H,W,min_h,max_h,samples", CASES)
+def test_every_launch_is_correctly_rounded(monkeypatch, B, H, W, min_h, max_h, samples):
     """(3, 176x144): the row-streaming kernels at levels 0-1, lean instances at level 1, generic kernels below -- every op checked.
-    (16, 336x256): the BENCH shape; the float64 references are computed for levels 2-3 only (84x64 and 42x32: the lean / split /
-    tile-pair / strided instances the headline runs there, which no smaller image reaches)."""
+    (16, 336x256), levels 2-3: the BENCH shape; the float64 references are computed for 84x64 and 42x32 (the lean / split /
+    tile-pair / strided instances the headline runs there, which no smaller image reaches), all 16 samples.
+    (16, 336x256), levels 0-1: the launches that carry 60 % of the headline's bytes (row pairs, row convs incl. LRN output, dual
+    3x3 / 1x1, 4x4, the 16-channel pairs with the pooled output, the first conv fed with the NCHW tensor) AT the bench shape --
+    segment heights, strip counts and XCD task runs differ from the small image's; forward outputs and stored gradients of the
+    first and the last sample of the batch element by element, weight gradients (they sum the batch) over all 16."""
+    rows = max_h > 84                                  # the case reaches the levels the row-streaming kernels take
     try:
         # riders off: every intermediate gradient is stored, every launch can be checked on its own operands
-        ck = _run(B, H, W, 64, 51, {"MSAU_FUSE_LRN_BWD": "0", "MSAU_PAIR_WGRAD": "0", "MSAU_ROWS_MIN_TASKS": "1"}, max_h, monkeypatch)
+        ck = _run(B, H, W, 64, 51, {"MSAU_FUSE_LRN_BWD": "0", "MSAU_PAIR_WGRAD": "0", "MSAU_ROWS_MIN_TASKS": "1"}, max_h, monkeypatch,
+                  min_h, samples)
         assert not any(pr.c1.wg_fused for pr in ck.plan.pairs)
         ck.forward()
         ck.backward()
         wg_off = ck.weight_grads()
-        assert ck.nchecked > (250 if max_h > 84 else 120), ck.nchecked
+        assert ck.nchecked > (250 if min_h == 0 and rows else 120), ck.nchecked
         inst = {ck.plan.rec_meta[a][0] for a in ck.plan.rec_meta}
-        if max_h > 84:
+        if rows:
             assert any(k.startswith("rowpair_kernel<bf16,C8>") for k in inst) and any(k.startswith("rowconv_kernel") for k in inst), inst
         else:
             assert any(k.startswith("conv_pair_kernel<bf16,C32>") for k in inst) and any("CIN64,CT4,K3" in k for k in inst), inst
-        if max_h <= 84:
+        if not rows:
             return
         grads_off = {t.name: t.grad.clone() for t in ck.plan.acts if t.grad is not None and not ck.unwritten(t)}
         # riders on (the shipped default): the data gradients do not change by a bit, the LRN backward in the pair's epilogue
         # stays within its rounding of the stand-alone pass, the riding weight gradient within the fp32 bound
-        ck2 = _run(B, H, W, 64, 51, {"MSAU_FUSE_LRN_BWD": "1", "MSAU_PAIR_WGRAD": "1", "MSAU_ROWS_MIN_TASKS": "1"}, max_h, monkeypatch)
+        ck2 = _run(B, H, W, 64, 51, {"MSAU_FUSE_LRN_BWD": "1", "MSAU_PAIR_WGRAD": "1", "MSAU_ROWS_MIN_TASKS": "1"}, max_h, monkeypatch,
+                   min_h, samples)
         fused = [pr for pr in ck2.plan.pairs if pr.active and pr.c1.wg_fused]
         riders = [op for op in ck2.plan.ops if isinstance(op, LrnOp) and op.bwd_fused_into is not None]
         assert fused and riders
@@ -290,10 +314,10 @@ def test_every_launch_is_correctly_rounded(monkeypatch, B, H, W, max_h):
             if rider is not None:
                 # float64 LRN backward of the gradient the riders-off run STORED for the LRN's output (the rider's launch computes the
                 # same values and rounds them the same way before its epilogue: DESIGN section 5)
-                ref, terms = lrn_bwd_ref(nchw(t.data, t.C), nchw(grads_off[rider.y.name], rider.y.C))
-                assert_rounded(nchw(t.grad, t.C), ref, ACC * 0.2 * terms, f"LRN-backward rider {t.name}")
+                ref, terms = lrn_bwd_ref(ck2.n(t.data, t.C), ck2.n(grads_off[rider.y.name], rider.y.C))
+                assert_rounded(ck2.n(t.grad, t.C), ref, ACC * 0.2 * terms, f"LRN-backward rider {t.name}")
             else:
-                assert torch.equal(t.grad, grads_off[t.name]), t.name
+                assert torch.equal(t.grad, grads_off[t.name]), t.name           # (whole batch, on the device)
         ck2.weight_grads(names={pr.c1.name for pr in fused} | {pr.c2.name for pr in fused})
     finally:
         monkeypatch.undo()
