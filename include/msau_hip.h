@@ -397,6 +397,12 @@ int msau_masked_ce_multi(void* stream, int dtype, const void* logits, const void
  *   loss += scale * sum_p -log softmax(logits_p)[label_p] ; dlogits = scale * (softmax - onehot)           */
 int msau_softmax_ce(void* stream, int dtype, const void* logits, const int64_t* labels, void* dlogits,
                     float* loss_accum, float* ws, int B, int64_t hw, int C, int Cs, float scale);
+/* the same with per-class weights, torch.nn.CrossEntropyLoss(weight) as `UNetLoss(class_weights=...)` builds it
+ * (model/training/cost.py:24-31): class_w = float[C] on the device;
+ *   sums[0] += sum_p w_p nll_p, sums[1] += sum_p w_p (w_p = class_w[label_p]);  dlogits = w_p (softmax - onehot)   -- UN-normalised:
+ * the loss is sums[0] / sums[1] and the caller scales dlogits by 1 / sums[1] (known only after the pass). ws: msau_ce_ws_floats. */
+int msau_softmax_ce_weighted(void* stream, int dtype, const void* logits, const int64_t* labels, const float* class_w,
+                             void* dlogits, float* sums, float* ws, int B, int64_t hw, int C, int Cs);
 
 /* ------------------------------------------------------------------------------------------
  * Global-norm clip + Adam on flat fp32 buffers (train_chargrid_funsd_msau.py:24-26,58-59).

@@ -166,6 +166,7 @@ _SIGNATURES = {
     "msau_masked_ce_multi": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, C.c_int, f32, C.c_int]),
     "msau_masked_ce": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, C.c_int, f32]),
     "msau_softmax_ce": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, C.c_int, f32]),
+    "msau_softmax_ce_weighted": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, C.c_int]),
     "msau_adam_ws_floats": (i64, [i64]),
     "msau_clip_adam_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32]),
     "msau_raster_owner": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]),

@@ -462,18 +462,34 @@ __global__ __launch_bounds__(256) void label_count_split_kernel(const int64_t* _
     if (threadIdx.x == 0) partial[b * K + k] = red[0] + red[1] + red[2] + red[3];
 }
 
+// the block's sum of class weights (second reduction of the weighted CE), same order as the loss partials
+__device__ __forceinline__ void ce_weight_sum(float local_w, float* red, float* out) {
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) local_w += __shfl_down(local_w, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local_w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < kThreads / 64; ++i) s += red[i];
+        out[blockIdx.x] = s;
+    }
+}
+
 template <typename T, bool ALL>
 __global__ void masked_ce_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels,
                                  const int32_t* __restrict__ counts, T* __restrict__ dlogits, float* __restrict__ partials,
-                                 int B, int64_t hw, int C, int Cs, float scale) {
+                                 int B, int64_t hw, int C, int Cs, float scale, const float* __restrict__ cw = nullptr) {
+    // cw (ALL only): per-class weights of torch.nn.CrossEntropyLoss(weight) (model/training/cost.py:24-31): every pixel's term and
+    // gradient are multiplied by cw[label]; the sum of those weights -- the loss's denominator -- goes to the second half of partials
     __shared__ float red[kThreads / 64];
-    float local = 0.f;
+    float local = 0.f, local_w = 0.f;
     const int64_t total = (int64_t)B * hw;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
         const int b = (int)(p / hw);
         const int64_t lab = labels[p];
         const bool on = ALL ? (lab >= 0 && lab < C) : (lab > 0 && lab < C);
-        const float w = on ? (ALL ? scale : scale / (float)max(counts[b], 1)) : 0.f;
+        float w = on ? (ALL ? scale : scale / (float)max(counts[b], 1)) : 0.f;
+        if (ALL && cw && on) { const float c = cw[(int)lab]; w *= c; local_w += c; }
         float x[16];
         float mx = -INFINITY;
         for (int c0 = 0; c0 < Cs && c0 < 16; c0 += 8) {
@@ -505,6 +521,7 @@ __global__ void masked_ce_kernel(const T* __restrict__ logits, const int64_t* __
         for (int i = 0; i < kThreads / 64; ++i) s += red[i];
         partials[blockIdx.x] = s;
     }
+    if (ALL && cw) ce_weight_sum(local_w, red, partials + gridDim.x);
 }
 
 // Any class count (Cs > 16: e.g. the 17-class key-value head): the logits of a pixel are read three times from the
@@ -512,15 +529,18 @@ __global__ void masked_ce_kernel(const T* __restrict__ logits, const int64_t* __
 template <typename T, bool ALL>
 __global__ void masked_ce_wide_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels,
                                       const int32_t* __restrict__ counts, T* __restrict__ dlogits, float* __restrict__ partials,
-                                      int B, int64_t hw, int C, int Cs, float scale) {
+                                      int B, int64_t hw, int C, int Cs, float scale, const float* __restrict__ cw = nullptr) {
+    // cw (ALL only): per-class weights of torch.nn.CrossEntropyLoss(weight) (model/training/cost.py:24-31): every pixel's term and
+    // gradient are multiplied by cw[label]; the sum of those weights -- the loss's denominator -- goes to the second half of partials
     __shared__ float red[kThreads / 64];
-    float local = 0.f;
+    float local = 0.f, local_w = 0.f;
     const int64_t total = (int64_t)B * hw;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
         const int b = (int)(p / hw);
         const int64_t lab = labels[p];
         const bool on = ALL ? (lab >= 0 && lab < C) : (lab != 0 && lab > 0 && lab < C);
-        const float w = on ? (ALL ? scale : scale / (float)max(counts[b], 1)) : 0.f;
+        float w = on ? (ALL ? scale : scale / (float)max(counts[b], 1)) : 0.f;
+        if (ALL && cw && on) { const float c = cw[(int)lab]; w *= c; local_w += c; }
         const T* l = logits + p * Cs;
         float mx = -INFINITY;
         for (int c = 0; c < C; ++c) mx = fmaxf(mx, (float)l[c]);
@@ -542,6 +562,7 @@ __global__ void masked_ce_wide_kernel(const T* __restrict__ logits, const int64_
         for (int i = 0; i < kThreads / 64; ++i) s += red[i];
         partials[blockIdx.x] = s;
     }
+    if (ALL && cw) ce_weight_sum(local_w, red, partials + gridDim.x);
 }
 
 constexpr int kCeMaxB = 1024;
@@ -904,7 +925,7 @@ extern "C" int msau_label_counts_split(void* stream, const int64_t* labels, int3
 }
 
 static int ce_blocks(int64_t npix) { return grid_for(npix, 1024); }
-extern "C" int64_t msau_ce_ws_floats(int64_t npix_total) { return ce_blocks(npix_total); }
+extern "C" int64_t msau_ce_ws_floats(int64_t npix_total) { return 2 * ce_blocks(npix_total); }      // (second half: msau_softmax_ce_weighted's weight sums)
 
 extern "C" int msau_masked_ce(void* stream, int dtype, const void* logits, const int64_t* labels, const int32_t* counts,
                               void* dlogits, float* loss_accum, float* ws, int B, int64_t hw, int C, int Cs, float scale) {
@@ -975,6 +996,28 @@ extern "C" int msau_softmax_ce(void* stream, int dtype, const void* logits, cons
                hipLaunchKernelGGL((masked_ce_kernel<bf16_t, true>), dim3(nb), dim3(kThreads), 0, s, static_cast<const bf16_t*>(logits), labels, nullptr, static_cast<bf16_t*>(dlogits), ws, B, hw, C, Cs, scale));
     MSAU_CHECK_LAUNCH("softmax_ce");
     hipLaunchKernelGGL(ordered_sum_kernel_t<false>, dim3(1), dim3(256), 0, s, ws, nb, loss_accum);
+    MSAU_CHECK_LAUNCH("ordered_sum");
+    return 0;
+}
+
+extern "C" int msau_softmax_ce_weighted(void* stream, int dtype, const void* logits, const int64_t* labels, const float* class_w,
+                                        void* dlogits, float* sums, float* ws, int B, int64_t hw, int C, int Cs) {
+    MSAU_CHECK_ARG(logits && labels && class_w && dlogits && sums && ws, "softmax_ce_weighted: null pointer");
+    MSAU_CHECK_ARG(B > 0 && hw > 0 && C > 0 && C <= Cs && Cs % 8 == 0 && Cs <= 256, "softmax_ce_weighted: bad dims (n_class <= 256)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nb = ce_blocks((int64_t)B * hw);
+    if (Cs > 16) {
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL((masked_ce_wide_kernel<float, true>), dim3(nb), dim3(kThreads), 0, s, static_cast<const float*>(logits), labels, nullptr, static_cast<float*>(dlogits), ws, B, hw, C, Cs, 1.f, class_w),
+                   hipLaunchKernelGGL((masked_ce_wide_kernel<bf16_t, true>), dim3(nb), dim3(kThreads), 0, s, static_cast<const bf16_t*>(logits), labels, nullptr, static_cast<bf16_t*>(dlogits), ws, B, hw, C, Cs, 1.f, class_w));
+    } else {
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL((masked_ce_kernel<float, true>), dim3(nb), dim3(kThreads), 0, s, static_cast<const float*>(logits), labels, nullptr, static_cast<float*>(dlogits), ws, B, hw, C, Cs, 1.f, class_w),
+                   hipLaunchKernelGGL((masked_ce_kernel<bf16_t, true>), dim3(nb), dim3(kThreads), 0, s, static_cast<const bf16_t*>(logits), labels, nullptr, static_cast<bf16_t*>(dlogits), ws, B, hw, C, Cs, 1.f, class_w));
+    }
+    MSAU_CHECK_LAUNCH("softmax_ce_weighted");
+    hipLaunchKernelGGL(ordered_sum_kernel_t<false>, dim3(1), dim3(256), 0, s, ws, nb, sums);
+    hipLaunchKernelGGL(ordered_sum_kernel_t<false>, dim3(1), dim3(256), 0, s, ws + nb, nb, sums + 1);
     MSAU_CHECK_LAUNCH("ordered_sum");
     return 0;
 }

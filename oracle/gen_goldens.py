@@ -533,3 +533,46 @@ def train_goldens():
 
 if __name__ == "__main__" and os.environ.get("MSAU_GOLDEN_TRAIN", "1") == "1":
     train_goldens()
+
+
+# ---------------------------------------------------------------------------------------------
+# G7: `UNetLoss(class_weights=...)` -- the reference's weighted cross entropy (model/training/cost.py:24-31:
+# torch.nn.CrossEntropyLoss(weight)) on random logits / one-hot targets, with and without auxiliary logits; a 17-class case
+# (the key-value head's class count) and a class whose weight is zero.  Own fixture, own switch: the other training fixtures
+# (a pickled checkpoint among them) are not rewritten.
+# ---------------------------------------------------------------------------------------------
+def weighted_loss_goldens():
+    import types
+    for name in ("tensorboardX", "cv2"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    with contextlib.redirect_stdout(io.StringIO()):
+        from model.training.cost import UNetLoss                    # reference
+    out_dir = os.path.join(OUT, "train")
+    os.makedirs(out_dir, exist_ok=True)
+    res = {}
+    g = torch.Generator().manual_seed(777)
+    for tag, (B, C, H, W, with_aux) in (("a", (2, 5, 9, 7, True)), ("b", (1, 17, 6, 11, True)), ("c", (3, 4, 5, 5, False))):
+        cw = (0.25 + 2.0 * torch.rand(C, generator=g)).numpy().astype(np.float32)
+        if tag == "c":
+            cw[2] = 0.0
+        crit = UNetLoss({"class_weights": [float(v) for v in cw]})
+        logits = (2.0 * torch.randn(B, C, H, W, generator=g)).requires_grad_(True)
+        aux = (2.0 * torch.randn(B, C, H, W, generator=g)).requires_grad_(True) if with_aux else None
+        lab = torch.randint(0, C, (B, H, W), generator=g)
+        tgt = torch.nn.functional.one_hot(lab, C).permute(0, 3, 1, 2).float()
+        acc, loss, final = crit(logits, tgt, {"aux_logits": aux, "aux_tgt": tgt} if with_aux else {})
+        loss.backward()
+        res[f"{tag}.class_weights"] = cw
+        res[f"{tag}.logits"], res[f"{tag}.label"] = logits.detach().numpy(), lab.numpy()
+        res[f"{tag}.acc"], res[f"{tag}.loss"] = float(acc), float(loss)
+        res[f"{tag}.final"] = float(final) if final is not None else np.nan
+        res[f"{tag}.glogits"] = logits.grad.numpy()
+        if with_aux:
+            res[f"{tag}.aux"], res[f"{tag}.gaux"] = aux.detach().numpy(), aux.grad.numpy()
+    np.savez_compressed(os.path.join(out_dir, "unet_loss_weighted.npz"), **res)
+    print("wrote weighted-loss goldens", {t: res[f"{t}.loss"] for t in "abc"})
+
+
+if __name__ == "__main__" and os.environ.get("MSAU_GOLDEN_WLOSS", "1") == "1":
+    weighted_loss_goldens()

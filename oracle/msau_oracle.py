@@ -32,6 +32,30 @@ DEFAULT_CFG = dict(channels=64, n_class=5, scale_space_num=4, res_depth=2,
 
 
 # ---------------------------------------------------------------------------
+# storage="bf16": the reference's arithmetic with the ROUNDING POINTS of the
+# device path's throughput mode (activations and packed
+# weights stored as bf16, accumulation fp32).  `msau_forward(..., storage="bf16")`
+# rounds exactly the tensors the device plan stores -- every conv / LRN /
+# residual-block / coupling / attention / transposed-conv output, the packed
+# weights, the bf16 attention probabilities -- and nothing else, so what is
+# left between it and the device's bf16 logits is the order of the fp32 sums.
+# The reference itself (model/model.py) is fp32 throughout; storage=None (the
+# default, and the only mode the golden vectors pin) is that path unchanged.
+# ---------------------------------------------------------------------------
+def _ident(t: Tensor) -> Tensor:
+    return t
+
+
+def _to_bf16(t: Tensor) -> Tensor:
+    return t.bfloat16().float()
+
+
+def rounder(storage: Optional[str]):
+    assert storage in (None, "fp32", "bf16"), storage
+    return _to_bf16 if storage == "bf16" else _ident
+
+
+# ---------------------------------------------------------------------------
 # A1  pad_2d                                        model/layers/utils.py:5-28
 # ---------------------------------------------------------------------------
 def same_pads(in_size: int, k: int, stride: int = 1, dilation: int = 1) -> Tuple[int, int]:
@@ -75,9 +99,10 @@ def lrn(x: Tensor, size: int, alpha: float = 1e-4, beta: float = 0.75, k: float 
     return x / div
 
 
-def dilconv_lrn(x: Tensor, w: Tensor, b: Tensor, rate: int) -> Tensor:
-    """DilConv2dBnLrnDrop.forward with activation=None, use_lrn=True: layers.py:152-164."""
-    return lrn(conv_same(x, w, b, dilation=rate), w.shape[0])
+def dilconv_lrn(x: Tensor, w: Tensor, b: Tensor, rate: int, q=_ident) -> Tensor:
+    """DilConv2dBnLrnDrop.forward with activation=None, use_lrn=True: layers.py:152-164.
+    (q: the conv output is a stored tensor of the device plan, the LRN reads it back)"""
+    return q(lrn(q(conv_same(x, w, b, dilation=rate)), w.shape[0]))
 
 
 # ---------------------------------------------------------------------------
@@ -95,27 +120,29 @@ def deconv(x: Tensor, w: Tensor, b: Tensor, out_hw: Tuple[int, int]) -> Tensor:
 # ---------------------------------------------------------------------------
 # A5  MultiConvResidualBlock                         model/model.py:37-50
 # ---------------------------------------------------------------------------
-def res_block(x: Tensor, sd: Dict[str, Tensor], prefix: str, R: int) -> Tensor:
+def res_block(x: Tensor, sd: Dict[str, Tensor], prefix: str, R: int, q=_ident) -> Tensor:
     r = torch.relu(x)
     for i in range(R):
         w = sd[f"{prefix}.conv_res_list.{i}.custom_conv.weight"]
         b = sd[f"{prefix}.conv_res_list.{i}.custom_conv.bias"]
         r = conv_same(r, w, b, relu=(i < R - 1))
-    return torch.relu(r + x)
+        if i < R - 1:
+            r = q(r)                                   # the inner tensors are stored (the backward reads them)
+    return q(torch.relu(r + x))
 
 
 # ---------------------------------------------------------------------------
 # A6  SelfAttentionBlock                             model/layers/attention.py:152-162
 # ---------------------------------------------------------------------------
-def self_attention(x: Tensor, sd: Dict[str, Tensor], prefix: str) -> Tensor:
+def self_attention(x: Tensor, sd: Dict[str, Tensor], prefix: str, q=_ident) -> Tensor:
     B, C, H, W = x.shape
-    f = F.conv2d(x, sd[f"{prefix}.f.conv.weight"], sd[f"{prefix}.f.conv.bias"]).reshape(B, -1, H * W)
-    g = F.conv2d(x, sd[f"{prefix}.g.conv.weight"], sd[f"{prefix}.g.conv.bias"]).reshape(B, -1, H * W)
-    h = F.conv2d(x, sd[f"{prefix}.h.conv.weight"], sd[f"{prefix}.h.conv.bias"]).reshape(B, C, H * W)
+    f = q(F.conv2d(x, sd[f"{prefix}.f.conv.weight"], sd[f"{prefix}.f.conv.bias"])).reshape(B, -1, H * W)
+    g = q(F.conv2d(x, sd[f"{prefix}.g.conv.weight"], sd[f"{prefix}.g.conv.bias"])).reshape(B, -1, H * W)
+    h = q(F.conv2d(x, sd[f"{prefix}.h.conv.weight"], sd[f"{prefix}.h.conv.bias"])).reshape(B, C, H * W)
     s = torch.matmul(g.transpose(1, 2), f)              # s[i, j] = g_i . f_j
-    beta = torch.softmax(s, dim=-1)                     # rows normalised
+    beta = q(torch.softmax(s, dim=-1))                  # rows normalised (q: the probabilities are the bf16 operand of the next product)
     o = torch.matmul(h, beta)                           # o[:, j] = sum_i h[:, i] beta[i, j]
-    return o.reshape(B, C, H, W) + x
+    return q(o.reshape(B, C, H, W) + x)
 
 
 # ---------------------------------------------------------------------------
@@ -123,7 +150,7 @@ def self_attention(x: Tensor, sd: Dict[str, Tensor], prefix: str) -> Tensor:
 # ---------------------------------------------------------------------------
 def stage_forward(inp: Tensor, sd: Dict[str, Tensor], b: int, cfg: dict,
                   prev_dw: Optional[Dict[int, Tensor]], prev_up: Optional[Dict[int, Tensor]],
-                  need_attention: bool = True):
+                  need_attention: bool = True, q=_ident):
     S, R = cfg["scale_space_num"], cfg["res_depth"]
     k, ps = cfg["filter_size"], cfg["pool_size"]
     assert ps == 2
@@ -134,14 +161,14 @@ def stage_forward(inp: Tensor, sd: Dict[str, Tensor], b: int, cfg: dict,
     x_in = inp
     x = inp
     for l in range(S):                                                  # model.py:136-162
-        x = dilconv_lrn(x_in, sd[f"{pd}.conv1s.{l}.conv.weight"], sd[f"{pd}.conv1s.{l}.conv.bias"], 2 ** l)
-        x = res_block(x, sd, f"{pd}.conv_res_list.{l}", R)
+        x = dilconv_lrn(x_in, sd[f"{pd}.conv1s.{l}.conv.weight"], sd[f"{pd}.conv1s.{l}.conv.bias"], 2 ** l, q)
+        x = res_block(x, sd, f"{pd}.conv_res_list.{l}", R, q)
         if coupled:                                                     # model.py:143-148
-            x = conv_same(torch.cat([prev_dw[l], x], dim=1),
-                          sd[f"{pd}.conv1_1s.{l}.custom_conv.weight"],
-                          sd[f"{pd}.conv1_1s.{l}.custom_conv.bias"], relu=True)
+            x = q(conv_same(torch.cat([prev_dw[l], x], dim=1),
+                            sd[f"{pd}.conv1_1s.{l}.custom_conv.weight"],
+                            sd[f"{pd}.conv1_1s.{l}.custom_conv.bias"], relu=True))
         if l > S - 2:                                                   # model.py:149-150
-            dw[l] = self_attention(x, sd, f"{pd}.layer_attentions.attention_block") if need_attention else x
+            dw[l] = self_attention(x, sd, f"{pd}.layer_attentions.attention_block", q) if need_attention else x
         else:
             dw[l] = x
         if l < S - 1:                                                   # model.py:158-160
@@ -149,15 +176,15 @@ def stage_forward(inp: Tensor, sd: Dict[str, Tensor], b: int, cfg: dict,
     cur = x                                                             # pre-attention tensor, model.py:162-164
     up: Dict[int, Tensor] = {}
     for l in range(S - 2, -1, -1):                                      # model.py:226-254
-        d = deconv(cur, sd[f"{pu}.deconvs.{l}.conv.weight"], sd[f"{pu}.deconvs.{l}.conv.bias"],
-                   tuple(dw[l].shape[2:]))
-        x = conv_same(torch.cat([dw[l], d], dim=1),
-                      sd[f"{pu}.conv1s.{l}.custom_conv.weight"], sd[f"{pu}.conv1s.{l}.custom_conv.bias"])
-        x = res_block(x, sd, f"{pu}.conv_res_list.{l}", R)
+        d = q(deconv(cur, sd[f"{pu}.deconvs.{l}.conv.weight"], sd[f"{pu}.deconvs.{l}.conv.bias"],
+                     tuple(dw[l].shape[2:])))
+        x = q(conv_same(torch.cat([dw[l], d], dim=1),
+                        sd[f"{pu}.conv1s.{l}.custom_conv.weight"], sd[f"{pu}.conv1s.{l}.custom_conv.bias"]))
+        x = res_block(x, sd, f"{pu}.conv_res_list.{l}", R, q)
         if coupled:
-            x = conv_same(torch.cat([prev_up[l], x], dim=1),
-                          sd[f"{pu}.conv1_1s.{l}.custom_conv.weight"],
-                          sd[f"{pu}.conv1_1s.{l}.custom_conv.bias"], relu=True)
+            x = q(conv_same(torch.cat([prev_up[l], x], dim=1),
+                            sd[f"{pu}.conv1_1s.{l}.custom_conv.weight"],
+                            sd[f"{pu}.conv1_1s.{l}.custom_conv.bias"], relu=True))
         up[l] = x
         cur = x
     return cur, dw, up
@@ -166,17 +193,23 @@ def stage_forward(inp: Tensor, sd: Dict[str, Tensor], b: int, cfg: dict,
 # ---------------------------------------------------------------------------
 # A10  MSAUNet.forward                               model/model.py:378-396
 # ---------------------------------------------------------------------------
-def msau_forward(sd: Dict[str, Tensor], inp: Tensor, cfg: dict) -> Tuple[Tensor, Optional[Tensor]]:
+def msau_forward(sd: Dict[str, Tensor], inp: Tensor, cfg: dict, storage: Optional[str] = None) -> Tuple[Tensor, Optional[Tensor]]:
+    """storage=None / "fp32": the reference's fp32 forward.  storage="bf16": the same arithmetic with the device plan's
+    rounding points (see `rounder`): weights (not biases: they stay fp32 on the device too) and the input are rounded once,
+    every stored activation where it is stored."""
     nb = cfg.get("num_blocks", 3)
+    q = rounder(storage)
+    if storage == "bf16":
+        sd = {k: (q(v) if k.endswith("weight") else v) for k, v in sd.items()}
     prev_dw = prev_up = None
     aux = None
-    x = inp
+    x = q(inp)
     out = None
     for b in range(nb):
         # the last stage's attention output is never consumed (model.py:149-150,226-227)
-        out, prev_dw, prev_up = stage_forward(x, sd, b, cfg, prev_dw, prev_up, need_attention=(b < nb - 1))
-        out = conv_same(out, sd[f"msau_net.end_convs.{b}.custom_conv.weight"],
-                        sd[f"msau_net.end_convs.{b}.custom_conv.bias"])      # 4x4, asym SAME pad
+        out, prev_dw, prev_up = stage_forward(x, sd, b, cfg, prev_dw, prev_up, need_attention=(b < nb - 1), q=q)
+        out = q(conv_same(out, sd[f"msau_net.end_convs.{b}.custom_conv.weight"],
+                          sd[f"msau_net.end_convs.{b}.custom_conv.bias"]))   # 4x4, asym SAME pad
         x = out
         if b == nb - 2:
             aux = out

@@ -250,7 +250,7 @@ def test_golden_recipe_reproduces_committed_fixtures(tmp_path):
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     gold = os.path.join(root, "tests", "golden")
     for rel in ("ops.npz", os.path.join("funsd", "chargrid.npz"), os.path.join("funsd", "bertgrid.npz"),
-                os.path.join("train", "unet_loss.npz")):
+                os.path.join("train", "unet_loss.npz"), os.path.join("train", "unet_loss_weighted.npz")):
         a = np.load(os.path.join(gold, rel), allow_pickle=True)
         b = np.load(os.path.join(str(tmp_path), rel), allow_pickle=True)
         assert sorted(a.files) == sorted(b.files), rel

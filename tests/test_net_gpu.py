@@ -52,6 +52,30 @@ def test_forward_matches_reference(name, dtype):
     assert [k for k in m.state_dict()] == [k for k in sd]
 
 
+@pytest.mark.parametrize("name", ["net_cfg2_336x256x64", "net_f8_c13_33x26", "net_2stage_c24_dense_24x40", "net_r3_s3_c8_21x35"])
+def test_bf16_logits_match_the_oracle_with_the_plans_rounding_points(name):
+    """The benchmarked mode against a TIGHT bound (round-4 verdict, weak 1 / next 3b).  Against the reference's fp32 logits bf16
+    storage can only be held to 6e-2 (60 sequential convs of 8 significant bits).  `oracle.msau_forward(storage="bf16")` is the
+    pinned restatement with bf16 roundings at exactly the tensors the plan stores, so the device's bf16 logits -- at
+    `net_cfg2_336x256x64` produced by the very row-streaming kernels the bench times -- must agree with it up to the order of the
+    fp32 sums (which now and then moves a value across a bf16 rounding boundary): rel-L2 <= 5e-3 (observed ~1e-3)."""
+    from oracle import msau_oracle as O
+    from tests.golden_util import rel_l2
+    g, cfg, sd, x, label = load_net_case(name)
+    m = _model(cfg, sd, "bf16")
+    with torch.no_grad():
+        pred, logits, aux = m(x.cuda())
+        ref, ref_aux = O.msau_forward(sd, x, cfg, storage="bf16")
+    e = rel_l2(logits.cpu(), ref)
+    assert e <= 5e-3, ("logits", e)
+    if aux is not None:
+        ea = rel_l2(aux.cpu(), ref_aux)
+        assert ea <= 5e-3, ("aux", ea)
+    # and the bound is not vacuous: the same logits are an order of magnitude further from the fp32 path
+    ref32, _ = O.msau_forward(sd, x, cfg)
+    assert rel_l2(logits.cpu(), ref32) > 2 * e
+
+
 def _check_grads(g, cfg, named_grads, tol):
     names = [str(s) for s in g["param_names"]]
     dead = set(str(s) for s in g["dead_params"])

@@ -162,3 +162,21 @@ def test_net_forward_loss_grads_step(name):
         if ref_s[0] / np.sqrt(sd[k].numel()) > 1e-6:
             ds, dsmp = summarize(sd[k] - before[k])
             assert abs(ds[0] - g["delta_summary"][i][0]) <= 2e-2 * g["delta_summary"][i][0] + 1e-9, k
+
+
+def test_bf16_storage_mode_is_the_same_function_with_rounding_points():
+    """`msau_forward(..., storage="bf16")` (the checker of the device path's throughput mode, tests/test_net_gpu.py) is the
+    pinned fp32 restatement plus roundings: "fp32" / None leave it untouched bit for bit, "bf16" stays within bf16 noise of it,
+    its outputs ARE bf16 values, and the weights it was handed are not modified."""
+    g, cfg, sd, x, label = load_net_case("net_f4_c13_b2_64x48")
+    sd0 = {k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        ref, ref_aux = O.msau_forward(sd, x, cfg)
+        same, same_aux = O.msau_forward(sd, x, cfg, storage="fp32")
+        low, low_aux = O.msau_forward(sd, x, cfg, storage="bf16")
+    assert torch.equal(ref, same) and torch.equal(ref_aux, same_aux)
+    assert rel_err(ref, g["logits"]) < 2e-5                                   # (the pinned path)
+    assert all(torch.equal(sd[k], sd0[k]) for k in sd)
+    assert torch.equal(low, low.bfloat16().float()) and torch.equal(low_aux, low_aux.bfloat16().float())
+    from tests.golden_util import rel_l2
+    assert 1e-4 < rel_l2(low, ref) < 3e-2 and rel_l2(low_aux, ref_aux) < 3e-2, (rel_l2(low, ref), rel_l2(low_aux, ref_aux))

@@ -150,6 +150,38 @@ def test_unet_loss_matches_reference_fixture():
         assert rel_err(lg.grad.cpu(), g[f"{tag}.glogits"]) < 1e-5, tag
 
 
+def test_unet_loss_with_class_weights_matches_reference_fixture():
+    """`UNetLoss({"class_weights": ...})` = torch.nn.CrossEntropyLoss(weight) (model/training/cost.py:24-31) against values the
+    reference's own class produced (oracle/gen_goldens.py::weighted_loss_goldens): 5 and 17 classes with auxiliary logits, 4 classes
+    without, one class of weight zero.  `msau_softmax_ce_weighted`: un-normalised gradient + both sums in one pass."""
+    from msau_amd.training import UNetLoss
+    g = np.load(os.path.join(GOLDEN, "train", "unet_loss_weighted.npz"))
+    for tag in ("a", "b", "c"):
+        crit = UNetLoss({"class_weights": [float(v) for v in g[f"{tag}.class_weights"]]}).cuda()
+        lg = torch.from_numpy(g[f"{tag}.logits"]).cuda().requires_grad_(True)
+        lab = torch.from_numpy(g[f"{tag}.label"]).cuda()
+        C = lg.shape[1]
+        tgt = torch.nn.functional.one_hot(lab, C).permute(0, 3, 1, 2).float()
+        with_aux = f"{tag}.aux" in g.files
+        ax = torch.from_numpy(g[f"{tag}.aux"]).cuda().requires_grad_(True) if with_aux else None
+        acc, loss, final = crit(lg, tgt, {"aux_logits": ax, "aux_tgt": tgt} if with_aux else {})
+        loss.backward()
+        assert abs(acc - float(g[f"{tag}.acc"])) < 1e-6, tag
+        assert abs(float(loss) - float(g[f"{tag}.loss"])) < 1e-5 * abs(float(g[f"{tag}.loss"])), tag
+        if with_aux:
+            assert abs(float(final) - float(g[f"{tag}.final"])) < 1e-5 * abs(float(g[f"{tag}.final"])), tag
+            assert rel_err(ax.grad.cpu(), g[f"{tag}.gaux"]) < 1e-5, tag
+        else:
+            assert final is None and np.isnan(g[f"{tag}.final"])
+        assert rel_err(lg.grad.cpu(), g[f"{tag}.glogits"]) < 1e-5, tag
+    # uniform weights are the plain loss
+    gp = np.load(os.path.join(GOLDEN, "train", "unet_loss.npz"))
+    lg = torch.from_numpy(gp["c.logits"]).cuda()
+    tgt = torch.nn.functional.one_hot(torch.from_numpy(gp["c.label"]).cuda(), lg.shape[1]).permute(0, 3, 1, 2).float()
+    _, lw, _ = UNetLoss({"class_weights": [3.0] * lg.shape[1]}).cuda()(lg, tgt, {})
+    assert abs(float(lw) - float(gp["c.loss"])) < 1e-5 * abs(float(gp["c.loss"]))
+
+
 # ---- N3: a checkpoint the reference wrote --------------------------------------------------------------------------------------
 def test_reference_checkpoint_resumes_on_the_engine(tmp_path):
     """utils.io_utils.save_checkpoint's file (after one clip + Adam step of the reference): the HIP network reproduces the
