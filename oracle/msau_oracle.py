@@ -47,7 +47,7 @@ def _ident(t: Tensor) -> Tensor:
 
 
 def _to_bf16(t: Tensor) -> Tensor:
-    return t.bfloat16().float()
+    return t.bfloat16().to(t.dtype)                    # (float64 tensors stay float64: exact sums between the same rounding points)
 
 
 def rounder(storage: Optional[str]):
@@ -201,6 +201,8 @@ def msau_forward(sd: Dict[str, Tensor], inp: Tensor, cfg: dict, storage: Optiona
     q = rounder(storage)
     if storage == "bf16":
         sd = {k: (q(v) if k.endswith("weight") else v) for k, v in sd.items()}
+    if inp.dtype != torch.float32:                     # float64 input: the sums between the rounding points in float64 too
+        sd = {k: v.to(inp.dtype) for k, v in sd.items()}
     prev_dw = prev_up = None
     aux = None
     x = q(inp)

@@ -74,7 +74,10 @@ def lrn_bwd_ref(a, dy):
     n, alpha, beta = a.shape[1], 1e-4, 0.75
     ar = a.clone().requires_grad_(True)
     O.lrn(ar, n).backward(dy)
-    d = (a / O.lrn(a, n).clamp_min(1e-300).where(a != 0, torch.ones_like(a))).abs().where(a != 0, torch.ones_like(a)) ** (1.0 / beta)   # d = (a / y)^(1/beta)
+    # d = |a / y|^(1/beta)   (|.| BEFORE the clamp: a negative y used to be clamped to 1e-300, which made d huge and the bound of
+    # every element with a < 0 -- half of an LRN input -- collapse to the bare half ulp; the bench-shape case then tripped over two
+    # exact ties among 1.4 M elements)
+    d = (a.abs() / O.lrn(a, n).abs().clamp_min(1e-300)).where(a != 0, torch.ones_like(a)) ** (1.0 / beta)
     t1 = dy.abs() * d ** -beta
     t2 = a.abs() * (2 * alpha * beta / n) * (dy.abs() * a.abs() * d ** (-beta - 1)).sum(1, keepdim=True)
     return ar.grad, t1 + t2

@@ -180,3 +180,17 @@ def test_bf16_storage_mode_is_the_same_function_with_rounding_points():
     assert torch.equal(low, low.bfloat16().float()) and torch.equal(low_aux, low_aux.bfloat16().float())
     from tests.golden_util import rel_l2
     assert 1e-4 < rel_l2(low, ref) < 3e-2 and rel_l2(low_aux, ref_aux) < 3e-2, (rel_l2(low, ref), rel_l2(low_aux, ref_aux))
+
+
+def test_bf16_oracle_rounding_noise_envelope():
+    """the premise of tests/test_net_gpu.py::test_bf16_logits_cost_no_more_than_bf16_storage_itself, kept honest: two evaluations
+    with the SAME rounding points (fp32 against float64 sums in between) decorrelate -- they end up as far from each other as
+    either is from the fp32 reference, so a network-level bf16 bound is a radius around the reference, not a few ulps"""
+    from tests.golden_util import rel_l2
+    g, cfg, sd, x, label = load_net_case("net_r3_s3_c8_21x35")
+    with torch.no_grad():
+        a32, _ = O.msau_forward(sd, x, cfg, storage="bf16")
+        a64, _ = O.msau_forward(sd, x.double(), cfg, storage="bf16")
+        r32, _ = O.msau_forward(sd, x, cfg)
+    assert a64.dtype == torch.float64
+    assert 0.3 * rel_l2(a32, r32) < rel_l2(a32, a64.float()) < 1.5 * rel_l2(a32, r32)
