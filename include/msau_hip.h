@@ -193,6 +193,15 @@ enum { MSAU_PAIR_RELU_IN = 1, MSAU_PAIR_RELU_MID = 2, MSAU_PAIR_MASK_MID = 4,
                                    (`mid` is left untouched) nor re-read; wg1_x = the block's forward input x0 (ReLU applied on load),
                                    wg1_slabs = msau_conv_pair_wgrad_slabs() slabs of [8][80] fp32 in the layout msau_wgrad_reduce expects
                                    (kext 80, ones column 72).  Row-streaming 8-channel instance only. */
+       MSAU_PAIR_COUPLE = 64,   /* forward flag set only: the coupling conv that follows the block in a coupled stage
+                                   (model/model.py:143-148,246-252) rides on this launch --
+                                       z = max(Wc * concat(cpl_prev, y) + bc, 0)           ([B][H][W][C], written to cpl_y)
+                                   computed from the storage-rounded y exactly as the stand-alone 1x1 launch reads it; y itself is still
+                                   written (the backward reads it).  cpl_w / cpl_b = the packed image / bias msau_pack_params writes
+                                   for a 1x1 conv over concat(C, C) -> C.  With cpl_pool_y != NULL also the zero-padded MaxPool2d(2,2)
+                                   of z (cpl_pool_idx: the 1-byte positions, may be NULL), as MSAU_CONV_POOL does for y.  Row-streaming
+                                   8- and 16-channel instances only (msau_conv_pair_applicable says so); not together with
+                                   MSAU_CONV_POOL in flags2. */
        MSAU_PAIR_TILES = 8 };   /* take the tile kernels (conv_pair.hip) even where the row-streaming kernel has an instance: the
                                    forward and the backward launch of one block must agree on the layout of the mask planes, so a
                                    caller whose forward carries a flag only the tile kernels implement (MSAU_CONV_POOL) sets this on
@@ -224,6 +233,12 @@ typedef struct {
     float* wg1_slabs;           /* [msau_conv_pair_wgrad_slabs()][C][80] partial sums, one slab per workgroup             */
     int32_t wg1_nslabs;         /* the slab count the caller allocated: the launch refuses to write another number        */
     int32_t reserved1;
+    const void* cpl_prev;       /* MSAU_PAIR_COUPLE: the coupling conv's first source (the previous stage's tensor)      */
+    const void* cpl_w;          /* ... its packed weight image (1x1, concat(C, C) -> C) and bias                          */
+    const float* cpl_b;
+    void* cpl_y;                /* ... its output z                                                                       */
+    void* cpl_pool_y;           /* ... NULL, or the pooled z [B][ceil(H/2)][ceil(W/2)][C]                                 */
+    uint8_t* cpl_pool_idx;      /* ... and its 1-byte positions (may be NULL)                                             */
 } msau_conv_pair_desc;
 int msau_conv_pair_applicable(int dtype, const msau_conv_pair_desc* d);
 int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc* d);

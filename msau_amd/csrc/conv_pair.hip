@@ -616,13 +616,13 @@ extern "C" int msau_conv_pair_applicable(int dtype, const msau_conv_pair_desc* d
     if ((d->C != 8 && d->C != 16 && d->C != 32) || (d->C > maxc && !(tiny && d->C == 32))) return 0;
     if (dtype == MSAU_F32 && d->C == 32) return 0;                 // two fp32 tiles + two weight sets exceed the LDS
     if (d->B <= 0 || d->H <= 0 || d->W <= 0) return 0;
-    const int f1 = d->flags1 & ~(MSAU_PAIR_TILES | MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1);
+    const int f1 = d->flags1 & ~(MSAU_PAIR_TILES | MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1 | MSAU_PAIR_COUPLE);
     const bool fwd = f1 == kFwd1 && (d->flags2 & ~MSAU_CONV_POOL) == kFwd2, bwd = f1 == kBwd1 && d->flags2 == kBwd2;
     if (fwd && (d->flags2 & MSAU_CONV_POOL) && !d->pool_y) return 0;
     if (!fwd && !bwd) return 0;
     if (d->add != d->x) return 0;                                  // the ADD operand is read back from the input tile
     if (msau_rowpair_takes(dtype, d)) return 1;                    // 8 channels, bf16: the row-streaming kernel (conv_rows.hip)
-    if (d->flags1 & (MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1)) return 0;  // riders of the row-streaming instance only
+    if (d->flags1 & (MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1 | MSAU_PAIR_COUPLE)) return 0;  // riders of the row-streaming instances only
     const int esz = dtype == MSAU_F32 ? 4 : 2;
     if ((int64_t)d->H * d->W * d->C * esz >= (1ll << 31)) return 0;             // 32-bit lane offsets inside an image
     const int tw = pair_tw(dtype, d);

@@ -85,11 +85,23 @@ constexpr int SKEW = MSAU_ROWS_SKEW;
 // exactly as in rowwgrad8_kernel.  A wave owns the lattice columns 1..30 of its own rows m; the other lattice columns
 // (neighbour strips' pixels) are cleared in the fragment.  The four waves of a workgroup add up in LDS in a fixed order and
 // the workgroup writes ONE slab (layout of msau_wgrad_reduce: [co][tap * 8 + ci], ones column 72).
-template <bool BWD, bool BITS, bool LRNB = false, bool WG1 = false>
+//
+// CPL (MSAU_PAIR_COUPLE, forward flag set): the coupling conv of a coupled stage (model/model.py:143-148,246-252) in the same launch:
+// z = ReLU(Wc * concat(prev, y) + bc), a 1x1 conv, i.e. pixel-local on the output row this walk has just finished.  The row goes
+// through LDS once more (8-byte write in the result layout, 16-byte read in the fragment layout) and ONE more MFMA per row yields the
+// 32 pixels x 8 channels of z, with rowconv8_kernel<2, 1, 1>'s k order -- lane group lg = (source lg >> 1, pixel parity lg & 1): the
+// lanes of groups 0, 1 carry `prev` (one 16-byte load per lane and row, three rows ahead), groups 2, 3 the row of y -- so the result is
+// bit-identical to the stand-alone launch, whose read of y (22 MB at the bench size) and whose launch disappear.  CPL = 2 also writes
+// the zero-padded 2x2 max pool of z (model/model.py:158-160): a window is this row and the previous one (kept in registers) of this
+// lane and of lane ^ 32 (the odd column of the pair); same comparison order and rounded values as msau_maxpool2x2_fwd.
+constexpr int CPL_ROW = 32 * 16;                  // a finished output row in LDS: 32 pixels x 8 bf16
+
+template <bool BWD, bool BITS, bool LRNB = false, bool WG1 = false, int CPL = 0>
 __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
     static_assert(!LRNB || (BWD && !SKEW), "the LRN backward rides on the data-gradient launch");
     static_assert(!WG1 || (BWD && !SKEW), "the weight gradient rides on the data-gradient launch");
-    __shared__ __align__(16) unsigned char smem[4 * WAVE_LDS + (WG1 ? 4 * WG_ROW + 8 * 80 * 4 : 0)];
+    static_assert(!CPL || (!BWD && !SKEW), "the coupling conv rides on the forward launch");
+    __shared__ __align__(16) unsigned char smem[4 * WAVE_LDS + (WG1 ? 4 * WG_ROW + 8 * 80 * 4 : 0) + (CPL ? 4 * CPL_ROW : 0)];
     const msau_conv_pair_desc& d = a.d;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -227,6 +239,33 @@ __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
         return (cu64p)(base + (unsigned long long)(rc * plane_pitch));
     };
 
+    // ---- CPL: A fragment and bias of the coupling conv, the finished row's LDS slot, `prev` rows three ahead
+    bf16x8 AC = zero8<bf16_t>();
+    f32x4 cbias = {0.f, 0.f, 0.f, 0.f};
+    unsigned char* ywr = smem + 4 * WAVE_LDS + wave * CPL_ROW + j * 16 + c0 * 2;                    // result layout
+    const unsigned char* yrd = smem + 4 * WAVE_LDS + wave * CPL_ROW + (2 * lr + (lg & 1)) * 16;     // fragment layout: pixel 2 lr + parity
+    const __amdgpu_buffer_rsrc_t rcp = rsrc_of(CPL ? static_cast<const char*>(d.cpl_prev) + img : nullptr, CPL ? a.img_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rcz = rsrc_of(CPL ? static_cast<char*>(d.cpl_y) + img : nullptr, CPL ? a.img_bytes : 0u);
+    const int pcx = x0 + 2 * lr + (lg & 1);
+    const unsigned pcol = lg < 2 && pcx < W ? (unsigned)(pcx * 16) : kOOB;                          // (groups 2, 3 carry y: no load)
+    auto load_prev = [&](int r) -> u32x4 {
+        return __builtin_amdgcn_raw_buffer_load_b128(rcp, r >= y0 && r < y1 ? (unsigned)(r * a.row_bytes) + pcol : kOOB, 0, 0);
+    };
+    u32x4 PV[3] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    u32x2 zprev = {0u, 0u};                                               // CPL = 2: the even row of the current pooling window
+    const int Wo = (W + 1) >> 1, Ho = (H + 1) >> 1;
+    const unsigned pimg = CPL == 2 ? (unsigned)Ho * (unsigned)Wo * 16u : 0u;
+    const __amdgpu_buffer_rsrc_t rpz = rsrc_of(CPL == 2 ? static_cast<char*>(d.cpl_pool_y) + (long long)b * pimg : nullptr, pimg);
+    const __amdgpu_buffer_rsrc_t rpi = rsrc_of(CPL == 2 && d.cpl_pool_idx ? d.cpl_pool_idx + (long long)b * (pimg / 2) : nullptr,
+                                               CPL == 2 && d.cpl_pool_idx ? pimg / 2 : 0u);
+    if constexpr (CPL != 0) {
+        const int co = lr & 7, pp = lr >> 3;
+        if ((lg & 1) == pp) AC = load8<bf16_t>(static_cast<const bf16_t*>(d.cpl_w) + (lg >> 1) * (16 * 32) + co * 32);
+        if (d.cpl_b) cbias = *reinterpret_cast<const f32x4*>(d.cpl_b + c0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) PV[k] = load_prev(y0 - 2 + k);
+    }
+
     // X[k]: input rows in fragment layout (raw until first used, ReLU'd after that in the forward); at iteration I row t + k
     // lives in X[(I + k) % 6].  RS[k % 3]: the half of the RAW pixel this lane offers as residual operand.  M[k % 3]:
     // intermediate rows in fragment layout.
@@ -244,7 +283,7 @@ __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
     // stores the hardware drops: with them the loop is entered in the state its back edge leaves behind (rows t+2..t+4 in
     // flight, each followed by a row's stores), and the compiler's merged wait before the first rows is the steady-state
     // vmcnt(9), not vmcnt(1) -- which would wait for ALL rows in flight once per trip
-    constexpr int kStoresPerRow = (WG1 ? 1 : 2) + (!BWD && BITS ? 2 : 0);
+    constexpr int kStoresPerRow = (WG1 ? 1 : 2) + (!BWD && BITS ? 2 : 0) + (CPL ? 1 : 0);
 #pragma unroll
     for (int k = 0; k < 3 * kStoresPerRow; ++k) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rmid, kOOB + 8u * k, 0, 0);   // (distinct: equal ones are merged)
     M[0] = M[1] = M[2] = zero8<bf16_t>();
@@ -345,6 +384,61 @@ __global__ __launch_bounds__(256) void rowpair_c8_kernel(const RowArgs a) {
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) bal[jj] = __builtin_amdgcn_ballot_w64((float)r[jj] > 0.f);      // (x > 0): MASK_A of the backward
                 __builtin_amdgcn_raw_buffer_store_b32(lane_word(bal), rba, ownrow ? (unsigned)(to * plane_pitch) + bal_off : kOOB, 0, 0);
+            }
+            if constexpr (CPL != 0) {
+                // ---- the coupling conv on the finished row: fragment = [prev px 2lr | prev px 2lr+1 | y px 2lr | y px 2lr+1]
+                *reinterpret_cast<bf16x4*>(ywr) = o;
+                __builtin_amdgcn_wave_barrier();
+                const u32x4 yb = *reinterpret_cast<const u32x4*>(yrd);
+                __builtin_amdgcn_wave_barrier();
+                u32x4 bf;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) bf[w] = lg < 2 ? PV[I % 3][w] : yb[w];
+                PV[I % 3] = load_prev(to + 3);
+                const f32x4 zacc = mma8(AC, __builtin_bit_cast(bf16x8, bf), cbias);
+                bf16x4 zo;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) zo[jj] = (bf16_t)fmaxf(zacc[jj], 0.f);               // MSAU_CONV_RELU_OUT
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, zo), rcz, ownrow ? (unsigned)(to * a.row_bytes) + out_col : kOOB, 0, 0);
+                if constexpr (CPL == 2) {
+                    // rows to - 1 (even, in zprev) and to (odd); columns x0 + j (even: lanes of groups 0, 1) and x0 + j + 1 (lane ^ 32).
+                    // The window of the image's last row / column, when H / W is odd, sees zeros there (zero padding).
+                    const bool zok = ownrow && out_col != kOOB;
+                    const u32x2 cur = zok ? __builtin_bit_cast(u32x2, zo) : u32x2{0u, 0u};
+                    const bool odd = (to & 1) != 0;                       // wave-uniform (y0 is even)
+                    const bool last_even = !odd && to == H - 1;           // a window with no second row
+                    if (odd || last_even) {
+                        const u32x2 top = odd ? zprev : cur, bot = odd ? cur : u32x2{0u, 0u};
+                        const int nb = (lane ^ 32) * 4;
+                        u32x2 ntop, nbot;
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) {
+                            ntop[w] = (unsigned)__builtin_amdgcn_ds_bpermute(nb, (int)top[w]);
+                            nbot[w] = (unsigned)__builtin_amdgcn_ds_bpermute(nb, (int)bot[w]);
+                        }
+                        const bf16x4 vt = __builtin_bit_cast(bf16x4, top), vnt = __builtin_bit_cast(bf16x4, ntop),
+                                     vb = __builtin_bit_cast(bf16x4, bot), vnb = __builtin_bit_cast(bf16x4, nbot);
+                        bf16x4 best;
+                        unsigned idx = 0;
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            float bv = (float)vt[jj];
+                            unsigned bi = 0;
+                            const float c1 = (float)vnt[jj], c2 = (float)vb[jj], c3 = (float)vnb[jj];
+                            if (c1 > bv) { bv = c1; bi = 1; }
+                            if (c2 > bv) { bv = c2; bi = 2; }
+                            if (c3 > bv) { bv = c3; bi = 3; }
+                            best[jj] = (bf16_t)bv;
+                            idx |= bi << (8 * jj);
+                        }
+                        const int ty = odd ? to - 1 : to;
+                        const bool pok = lg < 2 && j < OW && x0 + j < W && ty >= y0 && ty < y1;
+                        const unsigned e = (unsigned)(((ty >> 1) * Wo + ((x0 + j) >> 1)) * 8 + c0);      // elements
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, best), rpz, pok ? e * 2 : kOOB, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(idx, rpi, pok ? e : kOOB, 0, 0);
+                    }
+                    zprev = cur;
+                }
             }
         };
         if constexpr (SKEW) {
@@ -470,10 +564,15 @@ constexpr int OW16 = 14, XW16 = 18;
 constexpr int MP16 = XW16 * 32;
 constexpr int WAVE_LDS16 = 2 * MP16;
 
-template <bool BWD, bool BITS, bool POOL>
+// CPL (MSAU_PAIR_COUPLE): as in rowpair_c8_kernel; here K = 32 is concat(prev, y) of ONE pixel -- lane group lg = (source lg >> 1,
+// 8-channel group lg & 1) -- and the pooled z takes the place of POOL's pooled y (same code, other operands).
+constexpr int CPL_ROW16 = 16 * 32;                // a finished output row in LDS: 16 pixels x 16 bf16
+
+template <bool BWD, bool BITS, bool POOL, int CPL = 0>
 __global__ __launch_bounds__(256) void rowpair_c16_kernel(const RowArgs a) {
     static_assert(!(BWD && POOL), "the pooled output belongs to the forward launch");
-    __shared__ __align__(16) unsigned char smem[4 * WAVE_LDS16];
+    static_assert(!CPL || (!BWD && !POOL), "the coupling conv rides on the forward launch; its pooled output replaces POOL's");
+    __shared__ __align__(16) unsigned char smem[4 * WAVE_LDS16 + (CPL ? 4 * CPL_ROW16 : 0)];
     const msau_conv_pair_desc& d = a.d;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -581,7 +680,7 @@ __global__ __launch_bounds__(256) void rowpair_c16_kernel(const RowArgs a) {
     };
     first_use(XA[0], XB[0], RS[0]);
     first_use(XA[1], XB[1], RS[1]);
-    constexpr int kStoresPerRow = 2 + (!BWD && BITS ? 2 : 0);            // see rowpair_c8_kernel
+    constexpr int kStoresPerRow = 2 + (!BWD && BITS ? 2 : 0) + (CPL ? 1 : 0);            // see rowpair_c8_kernel
 #pragma unroll
     for (int k = 0; k < 3 * kStoresPerRow; ++k)
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rmid, kOOB + 8u * k, 0, 0);
@@ -595,11 +694,32 @@ __global__ __launch_bounds__(256) void rowpair_c16_kernel(const RowArgs a) {
             for (int jj = 0; jj < 4; ++jj) { mm[k][jj] = pm[jj]; ma[k][jj] = pa[jj]; }
         }
     }
-    bf16x4 prev_out = {};                                                 // POOL: the even row of the current window
+    bf16x4 prev_out = {};                                                 // POOL / CPL = 2: the even row of the current window
+    constexpr bool PL = POOL || CPL == 2;
     const int Wo = (W + 1) >> 1, Ho = (H + 1) >> 1;
-    const unsigned pimg = POOL ? (unsigned)Ho * (unsigned)Wo * 32u : 0u;
-    const __amdgpu_buffer_rsrc_t rp = rsrc_of(POOL ? static_cast<char*>(d.pool_y) + (long long)b * pimg : nullptr, pimg);
-    const __amdgpu_buffer_rsrc_t ri = rsrc_of(POOL && d.pool_idx ? d.pool_idx + (long long)b * (pimg / 2) : nullptr, POOL && d.pool_idx ? pimg / 2 : 0u);
+    const unsigned pimg = PL ? (unsigned)Ho * (unsigned)Wo * 32u : 0u;
+    void* const pool_y = CPL == 2 ? d.cpl_pool_y : d.pool_y;
+    uint8_t* const pool_idx = CPL == 2 ? d.cpl_pool_idx : d.pool_idx;
+    const __amdgpu_buffer_rsrc_t rp = rsrc_of(PL ? static_cast<char*>(pool_y) + (long long)b * pimg : nullptr, pimg);
+    const __amdgpu_buffer_rsrc_t ri = rsrc_of(PL && pool_idx ? pool_idx + (long long)b * (pimg / 2) : nullptr, PL && pool_idx ? pimg / 2 : 0u);
+    // ---- CPL: A fragment and bias of the coupling conv, the finished row's LDS slot, `prev` rows three ahead
+    bf16x8 AC = zero8<bf16_t>();
+    f32x4 cbias = {0.f, 0.f, 0.f, 0.f};
+    unsigned char* ywr = smem + 4 * WAVE_LDS16 + wave * CPL_ROW16 + lr * 32 + c0 * 2;               // result layout
+    const unsigned char* yrd = smem + 4 * WAVE_LDS16 + wave * CPL_ROW16 + lr * 32 + (lg & 1) * 16;  // fragment layout: pixel lr, group lg & 1
+    const __amdgpu_buffer_rsrc_t rcp = rsrc_of(CPL ? static_cast<const char*>(d.cpl_prev) + img : nullptr, CPL ? a.img_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rcz = rsrc_of(CPL ? static_cast<char*>(d.cpl_y) + img : nullptr, CPL ? a.img_bytes : 0u);
+    const unsigned pcol = lg < 2 && x0 + lr < W ? (unsigned)((x0 + lr) * 32 + (lg & 1) * 16) : kOOB;     // (groups 2, 3 carry y: no load)
+    auto load_prev = [&](int r) -> u32x4 {
+        return __builtin_amdgcn_raw_buffer_load_b128(rcp, r >= y0 && r < y1 ? (unsigned)(r * a.row_bytes) + pcol : kOOB, 0, 0);
+    };
+    u32x4 PV[3] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    if constexpr (CPL != 0) {
+        AC = load8<bf16_t>(static_cast<const bf16_t*>(d.cpl_w) + (lg >> 1) * (16 * 32) + lr * 32 + (lg & 1) * 8);
+        if (d.cpl_b) cbias = *reinterpret_cast<const f32x4*>(d.cpl_b + c0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) PV[k] = load_prev(y0 - 2 + k);
+    }
 
     auto step = [&](auto ic, const int tg) {
         constexpr int I = decltype(ic)::value, P = I & 1;
@@ -672,12 +792,28 @@ __global__ __launch_bounds__(256) void rowpair_c16_kernel(const RowArgs a) {
                 for (int jj = 0; jj < 4; ++jj) bal[jj] = __builtin_amdgcn_ballot_w64((float)r[jj] > 0.f);
                 __builtin_amdgcn_raw_buffer_store_b32(lane_word(bal), rba, ownrow ? (unsigned)(t * plane_pitch) + bal_off : kOOB, 0, 0);
             }
-            if constexpr (POOL) {
+            bf16x4 po = o;                                                // what is pooled: y, or (CPL = 2) z
+            if constexpr (CPL != 0) {
+                // ---- the coupling conv on the finished row: fragment = [prev ch 0-7 | prev ch 8-15 | y ch 0-7 | y ch 8-15] of pixel lr
+                *reinterpret_cast<bf16x4*>(ywr) = o;
+                __builtin_amdgcn_wave_barrier();
+                const u32x4 yb = *reinterpret_cast<const u32x4*>(yrd);
+                __builtin_amdgcn_wave_barrier();
+                u32x4 bf;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) bf[w] = lg < 2 ? PV[I % 3][w] : yb[w];
+                PV[I % 3] = load_prev(t + 3);
+                const f32x4 zacc = mma8(AC, __builtin_bit_cast(bf16x8, bf), cbias);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) po[jj] = (bf16_t)fmaxf(zacc[jj], 0.f);               // MSAU_CONV_RELU_OUT
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, po), rcz, ownrow ? (unsigned)(t * a.row_bytes) + out_col : kOOB, 0, 0);
+            }
+            if constexpr (PL) {
                 // rows t - 1 (even, in prev_out) and t (odd), columns lr and lr ^ 1; the window of the image's last row, when H
                 // is odd, sees zeros below (model/model.py:158-160: zero padding).  Values 0 where nothing is stored.
                 bf16x4 cur;
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) cur[jj] = ownrow && out_ok ? o[jj] : (bf16_t)0.f;
+                for (int jj = 0; jj < 4; ++jj) cur[jj] = ownrow && out_ok ? po[jj] : (bf16_t)0.f;
                 const bool odd = (t & 1) != 0;                            // wave-uniform (y0 is even)
                 const bool last_even = !odd && t == H - 1;                // a window with no second row
                 if (odd || last_even) {
@@ -1125,7 +1261,7 @@ constexpr int kFwd1 = MSAU_PAIR_RELU_IN | MSAU_PAIR_RELU_MID, kFwd2 = MSAU_CONV_
 constexpr int kBwd1 = MSAU_PAIR_MASK_MID, kBwd2 = MSAU_CONV_MASK_A | MSAU_CONV_ADD;
 
 // environment switches of this file, read once; msau_reload_env() makes the next call read them again (tests, A/B tools)
-struct RowsEnv { int on, sh, sh16, waves, min_tasks, maxc, conv, wgrad, wgrad4, dout, pairwg; };
+struct RowsEnv { int on, sh, sh16, waves, min_tasks, maxc, conv, wgrad, wgrad4, dout, pairwg, couple; };
 RowsEnv g_env;
 bool g_env_ok = false;
 const RowsEnv& rows_env() {
@@ -1140,6 +1276,7 @@ const RowsEnv& rows_env() {
         g_env.wgrad4 = geti("MSAU_WGRAD_ROWS4", 0);              // ... and the 4x4 end conv's: correct (tests), but 13 us per step SLOWER than the tile kernel beside the main stream: off
         g_env.conv = geti("MSAU_CONV_ROWS", 1);                  // single convolutions of the 8-channel level on the row kernels
         g_env.pairwg = geti("MSAU_PAIR_WGRAD", 1);               // the first conv's weight gradient inside the pair's data-gradient launch
+        g_env.couple = geti("MSAU_PAIR_COUPLE", 1);              // the coupling 1x1 conv inside the pair's forward launch
         g_env.dout = geti("MSAU_DOUT_ROWS", 1);                  // the two-output data gradients (8 -> 8 + 8, 3x3 and 1x1) on the row kernels
         g_env.maxc = geti("MSAU_ROWS_MAXC", 16);                 // widest layer the row kernels take (8: the 16-channel pairs stay on the tile kernels)
         g_env_ok = true;
@@ -1168,12 +1305,20 @@ int msau_rowpair_takes(int dtype, const msau_conv_pair_desc* d) {
     const RowsEnv& e = rows_env();
     if (!e.on || dtype != MSAU_BF16 || (d->C != 8 && d->C != 16) || d->C > e.maxc || (d->flags1 & MSAU_PAIR_TILES)) return 0;
     const int pool_ok = d->C == 16 ? MSAU_CONV_POOL : 0;
-    const bool lrnb = d->flags1 & MSAU_PAIR_LRN_BWD, wg1 = d->flags1 & MSAU_PAIR_WGRAD1;
-    const bool fwd = d->flags1 == kFwd1 && (d->flags2 & ~pool_ok) == kFwd2,
+    const bool lrnb = d->flags1 & MSAU_PAIR_LRN_BWD, wg1 = d->flags1 & MSAU_PAIR_WGRAD1, cpl = d->flags1 & MSAU_PAIR_COUPLE;
+    const bool fwd = (d->flags1 & ~MSAU_PAIR_COUPLE) == kFwd1 && (d->flags2 & ~pool_ok) == kFwd2,
                bwd = (d->flags1 & ~(MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1)) == kBwd1 && d->flags2 == kBwd2;
     if (!fwd && !bwd) return 0;
     if (lrnb && !(bwd && d->C == 8 && d->lrn_a && d->lrn_da && d->lrn_k > 0.f)) return 0;
     if (wg1 && !(bwd && d->C == 8 && d->wg1_x && d->wg1_slabs && e.pairwg)) return 0;
+    if (cpl) {
+        // the coupling conv rides on the forward launch: its packed image must be the one the kernels index (1x1 over
+        // concat(C, C) -> C: one chunk per source, 16 rows of 32)
+        if (!fwd || !e.couple || (d->flags2 & MSAU_CONV_POOL) || !d->cpl_prev || !d->cpl_w || !d->cpl_y) return 0;
+        msau_conv_pack_geom g;
+        if (msau_conv_pack_geometry(dtype, d->C, d->C, d->C, 1, 1, 1, 1, 1, &g) != 0 || g.cch != d->C || g.nchunks != 2 || g.kchunk != 32 || g.rows != 16) return 0;
+        if (d->cpl_pool_y && ((d->H | d->W) < 2)) return 0;
+    }
     if (fwd && (d->flags2 & MSAU_CONV_POOL) && !d->pool_y) return 0;
     if (bwd && !(d->bits_mid && d->bits_a)) return 0;
     if (d->add != d->x) return 0;
@@ -1204,9 +1349,10 @@ int msau_rowpair_launch(hipStream_t s, const msau_conv_pair_desc* d) {
     a.d = *d;
     const bool c8 = d->C == 8;
     const bool bwd = (d->flags1 & ~(MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1)) == kBwd1, bits = d->bits_mid && d->bits_a, pool = !bwd && (d->flags2 & MSAU_CONV_POOL);
+    const int cpl = !bwd && (d->flags1 & MSAU_PAIR_COUPLE) ? (d->cpl_pool_y ? 2 : 1) : 0;
     a.nstrips = cdiv(d->W, c8 ? OW : OW16);
     a.SH = segment_rows(d->B, d->H, a.nstrips, c8 ? 2 + SKEW : 2, !c8);
-    if (pool && (a.SH & 1) && a.SH < d->H) ++a.SH;                          // 2x2 windows do not straddle segments
+    if ((pool || cpl == 2) && (a.SH & 1) && a.SH < d->H) ++a.SH;            // 2x2 windows do not straddle segments
     a.nseg = cdiv(d->H, a.SH);
     a.ntasks = d->B * a.nstrips * a.nseg;
     a.tasks_per_xcd = roundup(cdiv(a.ntasks, 8), 4);
@@ -1223,10 +1369,18 @@ int msau_rowpair_launch(hipStream_t s, const msau_conv_pair_desc* d) {
         else if (bwd && wg1) hipLaunchKernelGGL((rowpair_c8_kernel<true, true, false, true>), grid, block, 0, s, a);
         else if (bwd && lrnb) hipLaunchKernelGGL((rowpair_c8_kernel<true, true, true>), grid, block, 0, s, a);
         else if (bwd) hipLaunchKernelGGL((rowpair_c8_kernel<true, true>), grid, block, 0, s, a);
+        else if (cpl == 2 && bits) hipLaunchKernelGGL((rowpair_c8_kernel<false, true, false, false, 2>), grid, block, 0, s, a);
+        else if (cpl == 2) hipLaunchKernelGGL((rowpair_c8_kernel<false, false, false, false, 2>), grid, block, 0, s, a);
+        else if (cpl && bits) hipLaunchKernelGGL((rowpair_c8_kernel<false, true, false, false, 1>), grid, block, 0, s, a);
+        else if (cpl) hipLaunchKernelGGL((rowpair_c8_kernel<false, false, false, false, 1>), grid, block, 0, s, a);
         else if (bits) hipLaunchKernelGGL((rowpair_c8_kernel<false, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((rowpair_c8_kernel<false, false>), grid, block, 0, s, a);
     } else {
         if (bwd) hipLaunchKernelGGL((rowpair_c16_kernel<true, true, false>), grid, block, 0, s, a);
+        else if (cpl == 2 && bits) hipLaunchKernelGGL((rowpair_c16_kernel<false, true, false, 2>), grid, block, 0, s, a);
+        else if (cpl == 2) hipLaunchKernelGGL((rowpair_c16_kernel<false, false, false, 2>), grid, block, 0, s, a);
+        else if (cpl && bits) hipLaunchKernelGGL((rowpair_c16_kernel<false, true, false, 1>), grid, block, 0, s, a);
+        else if (cpl) hipLaunchKernelGGL((rowpair_c16_kernel<false, false, false, 1>), grid, block, 0, s, a);
         else if (bits && pool) hipLaunchKernelGGL((rowpair_c16_kernel<false, true, true>), grid, block, 0, s, a);
         else if (bits) hipLaunchKernelGGL((rowpair_c16_kernel<false, true, false>), grid, block, 0, s, a);
         else if (pool) hipLaunchKernelGGL((rowpair_c16_kernel<false, false, true>), grid, block, 0, s, a);

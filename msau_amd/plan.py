@@ -108,6 +108,13 @@ class ConvOp(Op):
         self.relu_in, self.relu_out, self.fwd_add = relu_in, relu_out, fwd_add
         self.bwd_add: Optional[Act] = None
         self.pair: Optional["PairOp"] = None        # set when this conv runs as half of a fused two-conv launch
+        self.cpl: Optional["ConvOp"] = None         # on a pair's second conv: the coupling 1x1 conv that reads its output (may ride on the launch)
+        self.cpl_fused_into: Optional["PairOp"] = None   # on a coupling conv: the pair whose forward launch computes it (MSAU_PAIR_COUPLE)
+        if kind == "conv" and k == 1 and x2 is not None and relu_out and not relu_in and fwd_add is None and plan.ops:
+            prod = plan.ops[-1]
+            if isinstance(prod, ConvOp) and prod.out is x2 and prod.pair is not None and prod is prod.pair.c2 \
+                    and x1.Cs == x2.Cs == out.Cs == x2.C == out.C:
+                prod.cpl = self                      # (structure only: PairOp.bind decides whether an instance takes it)
         assert out.relu_out == relu_out
         if kind == "conv":
             assert out.H == x1.H and out.W == x1.W
@@ -139,7 +146,10 @@ class ConvOp(Op):
 
     def writes(self):
         lrn, pool = getattr(self, "lrn", None), getattr(self, "pool", None)     # fused outputs are written by this launch too
-        return [self.out] + ([lrn.y] if lrn is not None else []) + ([pool.y] if pool is not None else [])
+        w = [self.out] + ([lrn.y] if lrn is not None else []) + ([pool.y] if pool is not None else [])
+        if self.cpl is not None:         # a coupling conv that may ride on this launch: its outputs must not alias this launch's inputs
+            w += [t for t in self.cpl.writes() if t not in w]
+        return w
 
     # ---- helpers -------------------------------------------------------------------------
     def _geom(self, C1, C2, Cout, dil, stride, ups):
@@ -434,10 +444,14 @@ class ConvOp(Op):
             if self is self.pair.c2:
                 L.call("msau_conv_pair", s, self.plan.dtype, C.byref(self.pair.fdesc), key=self.pair.key)
             return
+        if self.cpl_fused_into is not None:
+            return
         L.call("msau_conv2d", s, self.plan.dtype, C.byref(self.fdesc), key=self.fkey)
 
     def fwd_recs(self):
         rm = self.plan.rec_meta
+        if self.cpl_fused_into is not None:             # computed by the residual pair's forward launch
+            return []
         if self.pair is not None and self.pair.active:
             if self is not self.pair.c2:
                 return []
@@ -617,6 +631,31 @@ class PairOp:
                     else:
                         b.flags1 &= ~L.PAIR_WGRAD1
                         b.wg1_x = b.wg1_slabs = None
+        # the coupling conv that reads this block's output (model/model.py:143-148,246-252) rides on the forward launch where an
+        # instance has it (row-streaming 8 / 16 channels): one launch and one read of the block's output less per coupled level
+        cp = c2.cpl
+        self.cpl = None
+        if cp is not None and not (f.flags2 & L.CONV_POOL) and cp.x2 is out and getattr(cp, "lrn", None) is None and not cp.head \
+                and os.environ.get("MSAU_PAIR_COUPLE", "1") != "0" and P.cfg.get("fuse_couple", True):
+            f.flags1 |= L.PAIR_COUPLE
+            f.cpl_prev, f.cpl_w, f.cpl_b, f.cpl_y = _ptr(cp.x1.data), P.pack_ptr(cp.w_off), P.pack_ptr(cp.b_off), _ptr(cp.out.data)
+            cpool = getattr(cp, "pool", None)                        # the pool behind the coupling conv (encoder levels): it moves along
+            if cpool is not None:
+                f.cpl_pool_y, f.cpl_pool_idx = _ptr(cpool.y.data), _ptr(cpool.idx)
+                if not L.load().msau_conv_pair_applicable(P.dtype, C.byref(f)):
+                    f.cpl_pool_y = f.cpl_pool_idx = None             # ... or stays where it was (the coupling launch's epilogue / a launch of its own)
+                    cpool = None
+            if L.load().msau_conv_pair_applicable(P.dtype, C.byref(f)):
+                self.cpl = cp
+                cp.cpl_fused_into = self
+                if cpool is not None:
+                    cpool.fused_into = self
+                elif getattr(cp, "pool", None) is not None and cp.pool.fused_into is cp:
+                    cp.pool.fused_into = None                        # (the coupling launch is gone: the pool runs on its own)
+                self.fbytes += 2 * n * esz + ((n // 4) * (esz + 1) if f.cpl_pool_y else 0)     # prev read, z written (+ pooled z, positions)
+            else:
+                f.flags1 &= ~L.PAIR_COUPLE
+                f.cpl_prev = f.cpl_w = f.cpl_b = f.cpl_y = f.cpl_pool_y = f.cpl_pool_idx = None
         # label by the instance that takes the launches (the backward descriptor, once it has its planes, decides for both)
         probe = self.bdesc if self.bdesc is not None else f
         if L.load().msau_conv_pair_instance(P.dtype, C.byref(probe)) == 2:
@@ -634,7 +673,11 @@ class PairOp:
             return
         for c in (c1, c2):
             P.unnote_launch(c.fkey, c.fbytes, c.flops)
-        P.note_launch(self.key, self.fbytes, c1.flops + c2.flops)
+        cflops = 0.0
+        if self.cpl is not None:
+            P.unnote_launch(self.cpl.fkey, self.cpl.fbytes, self.cpl.flops)
+            cflops = self.cpl.flops
+        P.note_launch(self.key, self.fbytes, c1.flops + c2.flops + cflops)
         if self.bdesc is not None:
             for c in (c1, c2):
                 P.unnote_launch(c.dmeta[0][0], c.dmeta[0][1], c.flops)

@@ -648,3 +648,87 @@ def test_first_conv_nchw_refuses_what_it_does_not_implement():
     d.flags = L.CONV_NCHW
     d.x1 = d.wpack = d.y = x.data_ptr()
     assert lib.msau_conv2d(torch.cuda.current_stream().cuda_stream, L.BF16, d) != 0       # refused, not launched
+
+
+@pytest.mark.parametrize("c,hw,B,pool", [(8, (57, 61), 3, False), (8, (64, 90), 2, True), (8, (71, 250), 2, True), (8, (33, 31), 4, False),
+                                          (16, (60, 129), 2, False), (16, (49, 70), 3, True), (16, (40, 15), 2, True), (16, (16, 28), 4, False)])
+def test_coupling_conv_in_the_residual_pairs_forward_launch(monkeypatch, c, hw, B, pool):
+    """MSAU_PAIR_COUPLE (round 5): z = ReLU(conv1x1(concat(prev, y))) of a coupled stage (model/model.py:143-148,246-252) computed by
+    the row-streaming pair's forward launch from the finished row of y, optionally with the zero-padded 2x2 max pool of z
+    (model/model.py:158-160), against the stand-alone launches (MSAU_PAIR_COUPLE=0, pool as its own launch).  8 channels: the
+    stand-alone coupling launch is rowconv8_kernel<2, 1, 1> -- the same single MFMA with the same k order -- so EVERYTHING is
+    bit-identical: y, z, pooled z, positions (through the pool's gradient), every gradient.  16 channels: the stand-alone launch is a
+    tile kernel that sums the two sources in two MFMAs and adds the bias last, so z may differ in the last bit of a few elements:
+    <= 1 bf16 ulp everywhere, bit-equal in > 99.5 %, gradients within bf16 noise.  Both against torch on the CPU."""
+    from msau_amd.plan import PairOp
+    torch.manual_seed(21)
+    H, W = hw
+    x = torch.randn(B, c, H, W)
+    p = {"w": 0.2 * torch.randn(c, c, 3, 3), "b": 0.1 * torch.randn(c), "w2": 0.2 * torch.randn(c, c, 3, 3), "b2": 0.1 * torch.randn(c),
+         "w0": 0.3 * torch.randn(c, c, 1, 1), "b0": 0.1 * torch.randn(c), "wc": 0.25 * torch.randn(c, 2 * c, 1, 1), "bc": 0.1 * torch.randn(c)}
+    Ho, Wo = ((H + 1) // 2, (W + 1) // 2) if pool else (H, W)
+    gy = torch.randn(B, c, Ho, Wo)
+    seen = []
+
+    def build(plan):
+        x0 = plan.x_in
+        prev = Act(plan, "prev", H, W, c, relu_out=True)
+        ConvOp(plan, "c0", x0, None, "w0", "b0", prev, 1, relu_out=True)
+        r1 = Act(plan, "r1", H, W, c, relu_out=True)
+        c1 = ConvOp(plan, "c1", x0, None, "w", "b", r1, 3, relu_in=True, relu_out=True)
+        out = Act(plan, "out", H, W, c, relu_out=True)
+        c2 = ConvOp(plan, "c2", r1, None, "w2", "b2", out, 3, relu_out=True, fwd_add=x0)
+        c1.bwd_add = out
+        PairOp(plan, c1, c2)
+        z = Act(plan, "z", H, W, c, relu_out=True)
+        cp = ConvOp(plan, "cpl", prev, out, "wc", "bc", z, 1, relu_out=True)
+        if pool:
+            q = Act(plan, "q", Ho, Wo, c)
+            PoolOp(plan, "p", z, q)
+            plan.logits = q
+        else:
+            plan.logits = z
+        seen.append((plan, cp, z, out))
+    monkeypatch.setenv("MSAU_ROWS_MIN_TASKS", "1")
+    res, mids = {}, {}
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MSAU_PAIR_COUPLE", mode)
+            monkeypatch.setenv("MSAU_FUSE_POOL", mode)               # stand-alone mode: the pool as its own launch (bit-exact by its own test)
+            L.load().msau_reload_env()
+            res[mode] = run_graph(build, p, x, gy, L.BF16)
+            plan, cp, z, out = seen[-1]
+            mids[mode] = (z.data.clone(), out.data.clone())
+    finally:
+        monkeypatch.undo()
+        L.load().msau_reload_env()
+    (plan1, cp1, _, _), (plan0, cp0, _, _) = seen
+    assert plan1.pairs[0].active and cp1.cpl_fused_into is plan1.pairs[0] and cp0.cpl_fused_into is None
+    assert plan1.pairs[0].key.startswith("rowpair_kernel") and plan0.pairs[0].key.startswith("rowpair_kernel")
+    if pool:
+        assert any(isinstance(o, PoolOp) and o.fused_into is plan1.pairs[0] for o in plan1.ops)
+    assert torch.equal(mids["1"][1], mids["0"][1]), "the block's own output"
+    z1, z0 = mids["1"][0].float(), mids["0"][0].float()
+    if c == 8:
+        assert torch.equal(z1, z0), "z"
+        for a, b in zip(res["1"], res["0"]):
+            if isinstance(a, dict):
+                for n in a:
+                    assert torch.equal(a[n], b[n]), n
+            elif a is not None:
+                assert torch.equal(a, b)
+    else:
+        ulp = torch.pow(2.0, torch.floor(torch.log2(torch.maximum(z1.abs(), z0.abs()).clamp_min(2.0 ** -120))) - 7)
+        assert bool(((z1 - z0).abs() <= ulp).all()), float(((z1 - z0).abs() / ulp).max())
+        assert float((z1 != z0).float().mean()) < 5e-3
+        assert err(res["1"][0], res["0"][0], True) < 1e-2
+        assert err(res["1"][2], res["0"][2], True) < 3e-2
+        for n in res["1"][3]:
+            assert err(res["1"][3][n], res["0"][3][n], True) < 3e-2, n
+    # against torch (fp32, CPU)
+    prev_r = O.conv_same(x, p["w0"], p["b0"], relu=True)
+    r = O.conv_same(torch.relu(x), p["w"], p["b"], relu=True)
+    out_r = torch.relu(O.conv_same(r, p["w2"], p["b2"]) + x)
+    z_r = O.conv_same(torch.cat([prev_r, out_r], 1), p["wc"], p["bc"], relu=True)
+    y_r = torch.nn.functional.max_pool2d(torch.nn.functional.pad(z_r, (0, W % 2, 0, H % 2)), 2, 2) if pool else z_r
+    assert err(res["1"][0], y_r, True) < 3e-2

@@ -12,7 +12,10 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 def kernels(obj):
     with tempfile.TemporaryDirectory() as tmp:
-        subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", os.path.abspath(obj)], cwd=tmp, check=True,
+        import shutil
+        local = os.path.join(tmp, os.path.basename(obj))
+        shutil.copy(obj, local)                          # (the extracted images are written beside the object)
+        subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", local], cwd=tmp, check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         dev = [f for f in os.listdir(tmp) if "gfx950" in f]
         assert dev, os.listdir(tmp)
