@@ -368,33 +368,47 @@ __global__ void pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint
     }
 }
 
-// One image row per blockIdx.y (+ 65535 * blockIdx.z), threads along (x, channel group): no 64-bit divisions (the flat-index
-// form spent ~300 of its ~400 instructions per item on three of them).
+// One POOLED row per blockIdx.y (+ 65535 * blockIdx.z), threads along (pooled x, channel group); a thread owns the whole 2x2
+// window: dy and the positions are read ONCE (rounds 1-4 ran a thread per input pixel -- the four pixels of a window sat in two
+// workgroup rows and each fetched the window's 16 + 8 bytes again: PMC x1.27 the algorithmic bytes, profiles/r04_traffic.json),
+// the two pixels of a window row are 32 contiguous bytes per lane.  No 64-bit divisions.
 template <typename T>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx,
-                                                       const T* __restrict__ mask, int rows, int H, int W, int Ho, int Wo, int Cs, int accumulate) {
+                                                       const T* __restrict__ mask, int orows, int H, int W, int Ho, int Wo, int Cs, int accumulate) {
     const int cgs = Cs >> 3;
-    const int row = blockIdx.y + 65535 * blockIdx.z;                 // b * H + iy
-    const int t = blockIdx.x * 256 + threadIdx.x;                    // ix * cgs + cg
-    if (row >= rows || t >= W * cgs) return;
-    const int b = row / H, iy = row - b * H;
-    const int ix = t / cgs, cg = t - ix * cgs;
-    const int pos = ((iy & 1) << 1) | (ix & 1);
-    const int64_t i = (int64_t)row * W * cgs + t;
-    const int64_t o = ((((int64_t)b * Ho + (iy >> 1)) * Wo + (ix >> 1)) * cgs + cg) * 8;
-    typename Vec8<T>::type g = load8<T>(dy + o);
-    uint64_t packed = *reinterpret_cast<const uint64_t*>(idx + o);
-    typename Vec8<T>::type old = accumulate ? load8<T>(dx + i * 8) : zero8<T>();
-    typename Vec8<T>::type m;
-    if (mask) m = load8<T>(mask + i * 8);
-    typename Vec8<T>::type r;
+    const int orow = blockIdx.y + 65535 * blockIdx.z;                // b * Ho + oy
+    const int t = blockIdx.x * 256 + threadIdx.x;                    // ox * cgs + cg
+    if (orow >= orows || t >= Wo * cgs) return;
+    const int b = orow / Ho, oy = orow - b * Ho;
+    const int ox = t / cgs, cg = t - ox * cgs;
+    const int64_t o = ((int64_t)orow * Wo * cgs + t) * 8;
+    const typename Vec8<T>::type g = load8<T>(dy + o);
+    const uint64_t packed = *reinterpret_cast<const uint64_t*>(idx + o);
+    typedef typename Vec8<T>::type V8;
+    V8 old[4], m[4];
+    bool ok[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float v = (float)old[j] + ((int)((packed >> (8 * j)) & 0xff) == pos ? (float)g[j] : 0.f);
-        if (mask && !((float)m[j] > 0.f)) v = 0.f;
-        r[j] = (T)v;
+    for (int pos = 0; pos < 4; ++pos) {
+        const int iy = 2 * oy + (pos >> 1), ix = 2 * ox + (pos & 1);
+        ok[pos] = iy < H && ix < W;
+        const int64_t i = (((int64_t)b * H + iy) * W + ix) * cgs + cg;
+        old[pos] = accumulate && ok[pos] ? load8<T>(dx + i * 8) : zero8<T>();
+        if (mask && ok[pos]) m[pos] = load8<T>(mask + i * 8);
     }
-    store8<T>(dx + i * 8, r);
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) {
+        if (!ok[pos]) continue;
+        const int iy = 2 * oy + (pos >> 1), ix = 2 * ox + (pos & 1);
+        const int64_t i = (((int64_t)b * H + iy) * W + ix) * cgs + cg;
+        V8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = (float)old[pos][j] + ((int)((packed >> (8 * j)) & 0xff) == pos ? (float)g[j] : 0.f);
+            if (mask && !((float)m[pos][j] > 0.f)) v = 0.f;
+            r[j] = (T)v;
+        }
+        store8<T>(dx + i * 8, r);
+    }
 }
 
 // =============================================================================================
@@ -900,8 +914,8 @@ extern "C" int msau_maxpool2x2_bwd(void* stream, int dtype, const void* dy, cons
     hipStream_t s = static_cast<hipStream_t>(stream);
     int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     MSAU_CHECK_ARG((int64_t)B * H < 65535ll * 65535ll && (int64_t)W * (Cs / 8) < (1ll << 30), "maxpool_bwd: image too large");
-    const int rows = B * H;
-    const dim3 grid(cdiv(W * (Cs / 8), 256), rows < 65535 ? rows : 65535, cdiv(rows, 65535));
+    const int rows = B * Ho;                                         // pooled rows: a thread owns a 2x2 window
+    const dim3 grid(cdiv(Wo * (Cs / 8), 256), rows < 65535 ? rows : 65535, cdiv(rows, 65535));
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(pool_bwd_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(dy), idx, static_cast<float*>(dx), static_cast<const float*>(mask), rows, H, W, Ho, Wo, Cs, accumulate),
                hipLaunchKernelGGL(pool_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, static_cast<const bf16_t*>(dy), idx, static_cast<bf16_t*>(dx), static_cast<const bf16_t*>(mask), rows, H, W, Ho, Wo, Cs, accumulate));

@@ -306,24 +306,48 @@ def test_every_launch_is_correctly_rounded(monkeypatch, B, H, W, min_h, max_h, s
         if not rows:
             return
         grads_off = {t.name: t.grad.clone() for t in ck.plan.acts if t.grad is not None and not ck.unwritten(t)}
-        # riders on (the shipped default): the data gradients do not change by a bit, the LRN backward in the pair's epilogue
-        # stays within its rounding of the stand-alone pass, the riding weight gradient within the fp32 bound
+        # (1) the weight-gradient rider alone: it changes NO data gradient -- every stored gradient bit for bit, the riding weight
+        #     gradients within the fp32 bound
+        ck1 = _run(B, H, W, 64, 51, {"MSAU_FUSE_LRN_BWD": "0", "MSAU_PAIR_WGRAD": "1", "MSAU_ROWS_MIN_TASKS": "1"}, max_h, monkeypatch,
+                   min_h, samples)
+        fused = [pr for pr in ck1.plan.pairs if pr.active and pr.c1.wg_fused]
+        assert fused and not any(isinstance(op, LrnOp) and op.bwd_fused_into is not None for op in ck1.plan.ops)
+        for t in ck1.plan.acts:
+            if t.grad is not None and not ck1.unwritten(t) and t.name in grads_off:
+                assert torch.equal(t.grad, grads_off[t.name]), t.name               # (whole batch, on the device)
+        ck1.weight_grads(names={pr.c1.name for pr in fused} | {pr.c2.name for pr in fused})
+        # (2) both riders (the shipped default).  The LRN backward in the pair's epilogue runs the stand-alone pass's arithmetic on
+        #     the same storage-rounded dy, but in another instruction context (other fma contractions): at 3x176x144 it came out bit
+        #     for bit, at the bench shape a handful of its 22 M outputs land on the other side of a bf16 rounding boundary -- and every
+        #     gradient computed AFTER it (the earlier stages' whole backward) legitimately inherits that.  So: the rider of the LAST
+        #     stage (the first to run: everything before it is bit-identical to the riders-off run, whose stored dy is therefore ITS dy)
+        #     is held to the float64 bound; every other stored gradient to <= 2 bf16 ulps of the riders-off value on all but 1e-3 of
+        #     its elements and 2e-3 in rel-L2 (a wrong rider term would be off by orders of magnitude more).
         ck2 = _run(B, H, W, 64, 51, {"MSAU_FUSE_LRN_BWD": "1", "MSAU_PAIR_WGRAD": "1", "MSAU_ROWS_MIN_TASKS": "1"}, max_h, monkeypatch,
                    min_h, samples)
         fused = [pr for pr in ck2.plan.pairs if pr.active and pr.c1.wg_fused]
         riders = [op for op in ck2.plan.ops if isinstance(op, LrnOp) and op.bwd_fused_into is not None]
         assert fused and riders
+        last_stage = max(op.stage for op in riders)
+        exact = 0
         for t in ck2.plan.acts:
             if t.grad is None or ck2.unwritten(t) or t.name not in grads_off:
                 continue
             rider = next((op for op in riders if op.a is t), None)
-            if rider is not None:
-                # float64 LRN backward of the gradient the riders-off run STORED for the LRN's output (the rider's launch computes the
-                # same values and rounds them the same way before its epilogue: DESIGN section 5)
+            if rider is not None and rider.stage == last_stage:
                 ref, terms = lrn_bwd_ref(ck2.n(t.data, t.C), ck2.n(grads_off[rider.y.name], rider.y.C))
                 assert_rounded(ck2.n(t.grad, t.C), ref, ACC * 0.2 * terms, f"LRN-backward rider {t.name}")
-            else:
-                assert torch.equal(t.grad, grads_off[t.name]), t.name           # (whole batch, on the device)
+                exact += 1
+                continue
+            a, b = t.grad.float(), grads_off[t.name].float()
+            if torch.equal(a, b):
+                exact += 1
+                continue
+            ulp = torch.pow(2.0, torch.floor(torch.log2(torch.maximum(a.abs(), b.abs()).clamp_min(2.0 ** -120))) - 7)
+            far = ((a - b).abs() > 2 * ulp).float().mean()
+            rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
+            assert float(far) < 1e-3 and rel < 2e-3, (t.name, float(far), rel)
+        assert exact >= 3, exact                     # (at least the last stage's tensors ahead of its rider are bit-equal)
         ck2.weight_grads(names={pr.c1.name for pr in fused} | {pr.c2.name for pr in fused})
     finally:
         monkeypatch.undo()
