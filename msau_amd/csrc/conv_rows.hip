@@ -1104,6 +1104,94 @@ __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// The level-1 -> level-0 transposed conv (Deconv2DBnLrnDrop, model/layers/layers.py:249-250: ConvTranspose2d(k 3, stride 2, padding 1,
+// output_padding from output_size), 16 -> 8 channels) in the same form.  The tile kernel runs it as a 3x3 conv over the zero-stuffed
+// input (msau_conv2d, ups = 2): three of four products multiply a stuffed zero and it staged 18 x 18 stuffed tiles per 16 x 16
+// outputs -- 14.8 us for 33 MB back to back, half the rate of the level's other launches.  Here only the live taps exist.  With the
+// (flipped) image msau_pack_params writes for the ups = 2 conv, out[Y][X] = sum W'[ky][kx] s[Y + ky - 1][X + kx - 1], s[2y][2x] = in[y][x]:
+//     Y = 2y    : ky = 1 on input row y;          Y = 2y + 1 : ky = 0 on row y and ky = 2 on row y + 1        (the same in x)
+// so an output pixel PAIR (2x, 2x + 1) reads input pixels x and x + 1: K = (dx, 16 channels) = 32, one k-step per live tap row.
+// MFMA rows = (output parity px, co), columns = 16 input columns of a strip; A[(px, co)][(dx, ci)] = W'[ky][kx(px, dx)][co][ci] with
+// kx(0, 0) = 1, kx(1, 0) = 0, kx(1, 1) = 2 and (0, 1) empty; the B fragment "pixel x + dx, channel group cg" (lane group lg = 2 dx + cg)
+// is one 16-byte global load per lane and INPUT row -- no LDS, no staging -- and serves the two output rows it feeds from registers:
+// one MFMA for an even output row, two for an odd one.  A result lane holds 4 channels of one output pixel: 8-byte stores, 512
+// contiguous bytes per wave-instruction.  Tasks are (image, segment of output rows, strip of 16 input = 32 output columns).
+struct RowDeconvArgs {
+    msau_conv_desc d;
+    int nstrips, nseg, SH, ntasks, tasks_per_xcd;
+    int in_row_bytes, out_row_bytes;
+    unsigned in_img_bytes, out_img_bytes;
+};
+
+__global__ __launch_bounds__(256) void rowdeconv8_kernel(const RowDeconvArgs a) {
+    const msau_conv_desc& d = a.d;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tloc = (blockIdx.x >> 3) * 4 + wave;
+    const int task = (blockIdx.x & 7) * a.tasks_per_xcd + tloc;
+    if (tloc >= a.tasks_per_xcd || task >= a.ntasks) return;
+    const int t1 = task / a.nstrips, strip = task - t1 * a.nstrips;
+    const int b = t1 / a.nseg, seg = t1 - b * a.nseg;
+    const int Hin = d.Hin, Win = d.Win, Hout = d.Hout, Wout = d.Wout;
+    const int xh0 = strip * 16;                                           // first input column of the strip
+    const int Y0 = seg * a.SH, Y1 = min(Hout, Y0 + a.SH);                 // output rows (SH is a multiple of 8: Y0 is even)
+    const int lr = lane & 15, lg = lane >> 4;
+    const int c0 = (lg & 1) * 4;
+
+    // ---- A fragments of the three tap rows
+    bf16x8 A[3];
+    {
+        const int co = lr & 7, px = lr >> 3, dx = lg >> 1, cg = lg & 1;
+        const int kx = px == 0 ? (dx == 0 ? 1 : -1) : (dx == 0 ? 0 : 2);
+        const bf16_t* w = static_cast<const bf16_t*>(d.wpack) + co * 160 + cg * 8;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) A[ky] = kx >= 0 ? load8<bf16_t>(w + (ky * 3 + kx) * 16) : zero8<bf16_t>();
+    }
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (d.bias) bias = *reinterpret_cast<const f32x4*>(d.bias + c0);
+
+    const __amdgpu_buffer_rsrc_t rx = rsrc_of(static_cast<const char*>(d.x1) + (long long)b * a.in_img_bytes, a.in_img_bytes);
+    const __amdgpu_buffer_rsrc_t ry = rsrc_of(static_cast<char*>(d.y) + (long long)b * a.out_img_bytes, a.out_img_bytes);
+    const int xi = xh0 + lr + (lg >> 1);
+    const unsigned lcol = xi < Win ? (unsigned)(xi * 32 + (lg & 1) * 16) : kOOB;             // (beyond the image: the stuffed zeros)
+    const int ylast = min(Hin - 1, Y1 >> 1);                              // last input row this task reads
+    auto load_row = [&](int r) -> u32x4 {
+        return __builtin_amdgcn_raw_buffer_load_b128(rx, r <= ylast ? (unsigned)(r * a.in_row_bytes) + lcol : kOOB, 0, 0);
+    };
+    const int Xo = 2 * (xh0 + lr) + (lg >> 1);
+    const unsigned out_col = Xo < Wout ? (unsigned)(Xo * 16 + c0 * 2) : kOOB;
+    auto store_row = [&](int Y, const f32x4& acc) {
+        bf16x4 o;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) o[jj] = (bf16_t)acc[jj];
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ry, Y < Y1 ? (unsigned)(Y * a.out_row_bytes) + out_col : kOOB, 0, 0);
+    };
+
+    // X[k]: input rows in fragment layout; at iteration I (input row y) rows y, y + 1 are X[I % 4], X[(I + 1) % 4], row y + 3 is requested
+    u32x4 X[4];
+    const int yh0 = Y0 >> 1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) X[k] = load_row(yh0 + k);
+    auto step = [&](auto ic, const int yg) {
+        constexpr int I = decltype(ic)::value;
+        const int y = yg + I;
+        X[(I + 3) % 4] = load_row(y + 3);
+        f32x4 e = mma8(A[1], __builtin_bit_cast(bf16x8, X[I % 4]), bias);                    // Y = 2y
+        f32x4 o = mma8(A[0], __builtin_bit_cast(bf16x8, X[I % 4]), bias);                    // Y = 2y + 1
+        o = mma8(A[2], __builtin_bit_cast(bf16x8, X[(I + 1) % 4]), o);
+        store_row(2 * y, e);
+        store_row(2 * y + 1, o);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int yg = yh0; 2 * yg < Y1; yg += 4) {
+        step(IC<0>{}, yg);
+        step(IC<1>{}, yg);
+        step(IC<2>{}, yg);
+        step(IC<3>{}, yg);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // Weight gradient of the 8 -> 8 3x3 convs in the same form (msau_conv2d_wgrad descriptors; dispatched from conv_wgrad.hip).
 // The tile kernel re-reads tile halos (PMC, profiles/r03_traffic.json: x1.49 the algorithmic bytes); here a wave walks a
 // 30-column strip and every row of x and g is read exactly once.  Pixels are the MFMA's K: per 32 pixels of a row and per
@@ -1261,7 +1349,7 @@ constexpr int kFwd1 = MSAU_PAIR_RELU_IN | MSAU_PAIR_RELU_MID, kFwd2 = MSAU_CONV_
 constexpr int kBwd1 = MSAU_PAIR_MASK_MID, kBwd2 = MSAU_CONV_MASK_A | MSAU_CONV_ADD;
 
 // environment switches of this file, read once; msau_reload_env() makes the next call read them again (tests, A/B tools)
-struct RowsEnv { int on, sh, sh16, waves, min_tasks, maxc, conv, wgrad, wgrad4, dout, pairwg, couple; };
+struct RowsEnv { int on, sh, sh16, waves, min_tasks, maxc, conv, wgrad, wgrad4, dout, pairwg, couple, deconv; };
 RowsEnv g_env;
 bool g_env_ok = false;
 const RowsEnv& rows_env() {
@@ -1276,6 +1364,7 @@ const RowsEnv& rows_env() {
         g_env.wgrad4 = geti("MSAU_WGRAD_ROWS4", 0);              // ... and the 4x4 end conv's: correct (tests), but 13 us per step SLOWER than the tile kernel beside the main stream: off
         g_env.conv = geti("MSAU_CONV_ROWS", 1);                  // single convolutions of the 8-channel level on the row kernels
         g_env.pairwg = geti("MSAU_PAIR_WGRAD", 1);               // the first conv's weight gradient inside the pair's data-gradient launch
+        g_env.deconv = geti("MSAU_DECONV_ROWS", 1);              // the 16 -> 8 transposed conv on the row kernel (live taps only)
         g_env.couple = geti("MSAU_PAIR_COUPLE", 1);              // the coupling 1x1 conv inside the pair's forward launch
         g_env.dout = geti("MSAU_DOUT_ROWS", 1);                  // the two-output data gradients (8 -> 8 + 8, 3x3 and 1x1) on the row kernels
         g_env.maxc = geti("MSAU_ROWS_MAXC", 16);                 // widest layer the row kernels take (8: the 16-channel pairs stay on the tile kernels)
@@ -1402,6 +1491,14 @@ int launch_rowconv8(hipStream_t s, const RowConvArgs& a) {
 int rowconv_case(int dtype, const msau_conv_desc* d) {
     const RowsEnv& e = rows_env();
     if (!e.on || !e.conv || dtype != MSAU_BF16) return 0;
+    if (d->ups == 2) {                                                     // the 16 -> 8 transposed conv (rowdeconv8_kernel)
+        if (!e.deconv || d->C1 != 16 || d->C2 != 0 || d->Cout != 8 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->dil != 1 || d->flags) return 0;
+        if (d->pad_t != 1 || d->pad_l != 1) return 0;
+        if ((d->Hout != 2 * d->Hin && d->Hout != 2 * d->Hin - 1) || (d->Wout != 2 * d->Win && d->Wout != 2 * d->Win - 1)) return 0;
+        if ((int64_t)d->Hout * d->Wout * 16 >= (1ll << 31)) return 0;
+        if ((int64_t)d->B * cdiv(d->Win, 16) * cdiv(d->Hout, 8) < e.min_tasks) return 0;
+        return 12;
+    }
     const bool dout = d->flags & MSAU_CONV_DOUT;
     if (d->Cout != (dout ? 16 : 8) || d->C1 != 8 || (d->C2 != 0 && d->C2 != 8) || d->stride != 1 || d->ups != 1 || d->dil != 1) return 0;
     if (d->Hin != d->Hout || d->Win != d->Wout || d->KH != d->KW) return 0;
@@ -1436,6 +1533,28 @@ int msau_rowconv_takes(int dtype, const msau_conv_desc* d) { return rowconv_case
 
 int msau_rowconv_launch(hipStream_t s, int dtype, const msau_conv_desc* d, int kchunk, int rows) {
     const int which = rowconv_case(dtype, d);
+    if (which == 12) {
+        MSAU_CHECK_ARG(kchunk == 160 && rows == 16, "rowdeconv: packed image of another geometry (kchunk %d, rows %d)", kchunk, rows);
+        RowDeconvArgs a;
+        a.d = *d;
+        a.nstrips = cdiv(d->Win, 16);
+        const RowsEnv& e = rows_env();
+        int nseg = e.waves / (d->B * a.nstrips);
+        if (nseg < 1) nseg = 1;
+        int sh = e.sh > 0 ? e.sh : cdiv(d->Hout, nseg);
+        if (sh < 8) sh = 8;
+        a.SH = roundup(sh, 8);                                             // (4 input rows per loop trip)
+        a.nseg = cdiv(d->Hout, a.SH);
+        a.ntasks = d->B * a.nstrips * a.nseg;
+        a.tasks_per_xcd = roundup(cdiv(a.ntasks, 8), 4);
+        a.in_row_bytes = d->Win * 32;
+        a.out_row_bytes = d->Wout * 16;
+        a.in_img_bytes = (unsigned)d->Hin * (unsigned)a.in_row_bytes;
+        a.out_img_bytes = (unsigned)d->Hout * (unsigned)a.out_row_bytes;
+        hipLaunchKernelGGL(rowdeconv8_kernel, dim3(8 * (a.tasks_per_xcd / 4)), dim3(256), 0, s, a);
+        MSAU_CHECK_LAUNCH("rowdeconv8_kernel");
+        return 0;
+    }
     RowConvArgs a;
     a.d = *d;
     a.nstrips = cdiv(d->Wout, 32);

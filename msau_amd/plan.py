@@ -399,7 +399,7 @@ class ConvOp(Op):
                 ex2 = sum(1 for f in (L.CONV_ACCUM, L.CONV_MASK_B) if d.flags2 & f)
                 return f"conv_lean_kernel<{T},CIN{d.C1},CT{info[0]},K{d.KH},dout>", (nin + half * (2 + ex1 + ex2)) * esz
             if info[6] == 3:
-                name = f"rowconv_kernel<{T},CIN{d.C1 + d.C2},CO{d.Cout},K{d.KH}{',lrn' if d.flags & L.CONV_LRN else ''}>"
+                name = f"rowconv_kernel<{T},CIN{d.C1 + d.C2},CO{d.Cout},K{d.KH}{',lrn' if d.flags & L.CONV_LRN else ''}{',ups2' if d.ups == 2 else ''}>"
             elif info[6] == 2:
                 name = f"conv_chunked_kernel<{T},CIN{d.C1},K{d.KH}>"
             elif info[6]:

@@ -732,3 +732,47 @@ def test_coupling_conv_in_the_residual_pairs_forward_launch(monkeypatch, c, hw, 
     z_r = O.conv_same(torch.cat([prev_r, out_r], 1), p["wc"], p["bc"], relu=True)
     y_r = torch.nn.functional.max_pool2d(torch.nn.functional.pad(z_r, (0, W % 2, 0, H % 2)), 2, 2) if pool else z_r
     assert err(res["1"][0], y_r, True) < 3e-2
+
+
+@pytest.mark.parametrize("hw_in,odd,B", [((20, 32), (0, 0), 2), ((21, 19), (1, 1), 3), ((9, 70), (1, 0), 2), ((65, 33), (0, 1), 4), ((168, 128), (0, 0), 2)])
+def test_row_streaming_transposed_conv_matches_the_zero_stuffed_launch_and_torch(monkeypatch, hw_in, odd, B):
+    """rowdeconv8_kernel (conv_rows.hip, round 5): the level-1 -> level-0 transposed conv (16 -> 8 channels, k 3, stride 2, padding 1,
+    output_size even or odd per axis: model/model.py:230, model/layers/layers.py:249-250) computed from the live taps only, against the
+    tile kernel's conv over the zero-stuffed input (MSAU_DECONV_ROWS=0: same packed image, other summation order) and against
+    torch.nn.functional.conv_transpose2d on the rounded operands; the backward (strided data gradient, weight gradient) is untouched
+    and must give the same bits in both modes."""
+    torch.manual_seed(31)
+    Hi, Wi = hw_in
+    Ho, Wo = 2 * Hi - odd[0], 2 * Wi - odd[1]
+    x = torch.randn(B, 16, Hi, Wi)
+    p = {"w": 0.2 * torch.randn(16, 8, 3, 3), "b": 0.1 * torch.randn(8)}            # ConvTranspose2d weight: [Cin][Cout][k][k]
+    gy = torch.randn(B, 8, Ho, Wo)
+    seen = []
+
+    def build(plan):
+        y = Act(plan, "y", Ho, Wo, 8)
+        seen.append(ConvOp(plan, "dc", plan.x_in, None, "w", "b", y, 3, kind="deconv"))
+        plan.logits = y
+    monkeypatch.setenv("MSAU_ROWS_MIN_TASKS", "1")
+    res = {}
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MSAU_DECONV_ROWS", mode)
+            L.load().msau_reload_env()
+            res[mode] = run_graph(build, p, x, gy, L.BF16)
+    finally:
+        monkeypatch.undo()
+        L.load().msau_reload_env()
+    assert seen[0].fkey.startswith("rowconv_kernel") and "ups2" in seen[0].fkey and not seen[1].fkey.startswith("rowconv_kernel"), (seen[0].fkey, seen[1].fkey)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    ref = torch.nn.functional.conv_transpose2d(bf(x), bf(p["w"]), p["b"], stride=2, padding=1, output_padding=(1 - odd[0], 1 - odd[1]))
+    assert tuple(ref.shape[2:]) == (Ho, Wo)
+    for mode in ("1", "0"):
+        assert err(res[mode][0], ref, True) < 1e-2, mode
+    a, b = res["1"][0], res["0"][0]
+    ulp = torch.pow(2.0, torch.floor(torch.log2(torch.maximum(a.abs(), b.abs()).clamp_min(2.0 ** -120))) - 7)
+    # one bf16 ulp (a sum that lands on the other side of a rounding boundary) + the fp32 order noise of a result that cancels to ~0
+    assert bool(((a - b).abs() <= ulp + 1e-5 * float(ref.abs().max())).all()) and float((a != b).float().mean()) < 2e-2, float((a != b).float().mean())
+    assert torch.equal(res["1"][2], res["0"][2]), "input gradient"
+    for n in res["1"][3]:
+        assert torch.equal(res["1"][3][n], res["0"][3][n]), n
