@@ -585,6 +585,10 @@ int msau_owner_slabs(const msau_wgrad_desc* d);   /* slabs an MSAU_CONV_OWNER we
 /* occupy the stream for ~microseconds (<= 200000) with a single sleeping wave: measurement aid only */
 int msau_spin(void* stream, int microseconds);
 int msau_fill_zero(void* stream, void* p, int64_t bytes);
+/* stress check of what msau_run_ops_overlap's FORK events rest on (tests): `iters` rounds of [a kernel on `stream` rewrites `words`
+ * 32-bit words, an event created with (system_fence = 1) or without (0: hipEventDisableSystemFence) the system-scope fence forks, a
+ * kernel on `side_stream` counts the words that do not hold the new pattern, a default event joins]; *mismatches = that count, summed */
+int msau_fork_visibility_check(void* stream, void* side_stream, int iters, int64_t words, int system_fence, int64_t* mismatches);
 /* a non-blocking stream with queue priority -1 (device's highest), 0 (default) or +1 (device's lowest); the caller owns it */
 int msau_stream_create(int priority, void** stream_out);
 int msau_stream_destroy(void* stream);

@@ -186,6 +186,7 @@ _SIGNATURES = {
     "msau_run_ops_overlap": (C.c_int, [vp, vp, C.POINTER(Op), C.c_int, C.c_int]),
     "msau_spin": (C.c_int, [vp, C.c_int]),
     "msau_fill_zero": (C.c_int, [vp, vp, i64]),
+    "msau_fork_visibility_check": (C.c_int, [vp, vp, C.c_int, i64, C.c_int, C.POINTER(i64)]),
     "msau_stream_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "msau_stream_destroy": (C.c_int, [vp]),
     "msau_softmax_channels_nchw": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, i64]),

@@ -1071,6 +1071,53 @@ __global__ void spin_kernel(long long cycles) {
     while (wall_clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
 }
 
+// ---- stress check of the fork events (main -> side) created WITHOUT the system-scope fence (sequence.hip: msau_run_ops_dp) ----
+// A producer kernel on `stream` rewrites a buffer with a new pattern, a fence-less event forks, a consumer kernel on `side_stream`
+// counts the words that do not hold the new pattern; a default (fenced) event joins before the next rewrite, exactly as the executor's
+// sweeps do.  The consumer of iteration i - 1 has left the OLD pattern in the L2s of the XCDs its workgroups ran on: a consumer that is
+// not made to see the producer's writes reads stale lines, and this count is not zero.
+__global__ void vis_fill_kernel(unsigned* __restrict__ a, long long words, unsigned pattern) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (long long)gridDim.x * blockDim.x)
+        a[i] = pattern ^ (unsigned)i;
+}
+__global__ void vis_check_kernel(const unsigned* __restrict__ a, long long words, unsigned pattern, unsigned long long* __restrict__ bad) {
+    unsigned long long local = 0;
+    // (another thread -> word mapping than the producer's: the consumer's workgroups do not sit where the producer's did)
+    for (long long i = words - 1 - ((long long)blockIdx.x * blockDim.x + threadIdx.x); i >= 0; i -= (long long)gridDim.x * blockDim.x)
+        local += a[i] != (pattern ^ (unsigned)i);
+    if (local) atomicAdd(bad, local);
+}
+
+extern "C" int msau_fork_visibility_check(void* stream, void* side_stream, int iters, int64_t words, int system_fence, int64_t* mismatches) {
+    MSAU_CHECK_ARG(stream && side_stream && stream != side_stream && iters > 0 && iters <= 100000 && words > 0 && words <= (1ll << 28) && mismatches,
+                   "fork_visibility_check: bad args");
+    hipStream_t ms = static_cast<hipStream_t>(stream), ss = static_cast<hipStream_t>(side_stream);
+    unsigned* buf = nullptr;
+    unsigned long long* bad = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ok = hipMalloc(&buf, (size_t)words * 4) == hipSuccess && hipMalloc(&bad, 8) == hipSuccess &&
+              hipMemsetAsync(bad, 0, 8, ms) == hipSuccess &&
+              hipEventCreateWithFlags(&fork, hipEventDisableTiming | (system_fence ? 0u : hipEventDisableSystemFence)) == hipSuccess &&
+              hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
+    const int grid = (int)((words + 4 * 256 - 1) / (4 * 256) < 2048 ? (words + 4 * 256 - 1) / (4 * 256) : 2048);
+    for (int it = 0; ok && it < iters; ++it) {
+        const unsigned pattern = 0x9E3779B9u * (unsigned)(it + 1);
+        hipLaunchKernelGGL(vis_fill_kernel, dim3(grid), dim3(256), 0, ms, buf, (long long)words, pattern);
+        ok = ok && hipEventRecord(fork, ms) == hipSuccess && hipStreamWaitEvent(ss, fork, 0) == hipSuccess;
+        hipLaunchKernelGGL(vis_check_kernel, dim3(grid), dim3(256), 0, ss, buf, (long long)words, pattern, bad);
+        ok = ok && hipEventRecord(join, ss) == hipSuccess && hipStreamWaitEvent(ms, join, 0) == hipSuccess;
+    }
+    unsigned long long host = ~0ull;
+    ok = ok && hipStreamSynchronize(ms) == hipSuccess && hipMemcpy(&host, bad, 8, hipMemcpyDeviceToHost) == hipSuccess;
+    if (fork) (void)hipEventDestroy(fork);
+    if (join) (void)hipEventDestroy(join);
+    if (buf) (void)hipFree(buf);
+    if (bad) (void)hipFree(bad);
+    if (!ok) return msau_set_error(MSAU_ERR_HIP, "fork_visibility_check: a HIP call failed (%s)", hipGetErrorString(hipGetLastError()));
+    *mismatches = (int64_t)host;
+    return 0;
+}
+
 extern "C" int msau_spin(void* stream, int microseconds) {
     MSAU_CHECK_ARG(microseconds >= 0 && microseconds <= 200000, "spin: 0..200000 us");
     // wall_clock64 ticks at 100 MHz on gfx950 (s_memrealtime)

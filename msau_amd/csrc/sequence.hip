@@ -87,17 +87,21 @@ extern "C" int msau_run_ops_overlap(void* stream, void* side_stream, const msau_
 extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_stream, const msau_op* ops, int n, int join) {
     MSAU_CHECK_ARG((ops || n == 0) && side_stream && side_stream != stream && (!comm_stream || (comm_stream != stream && comm_stream != side_stream)),
                    "run_ops_overlap: bad args");
-    // Two pools of timing-disabled events, reused across calls.  Default: ordinary events everywhere (HIP documents
-    // hipEventDisableSystemFence for timing-only events; without the fence the visibility of a producer's writes to a consumer on
-    // the OTHER queue rests on each dispatch packet's own agent-scope release / acquire, which is runtime behaviour nobody
-    // documents for a multi-XCD part -- a failure would be silently stale data).  Round 4 measured what the fence costs: created
-    // with hipEventDisableSystemFence the ~20 forks of a backward sweep run the step 1 % faster (3.036 -> 3.005 ms, bit-equal
-    // results in 8 fresh processes).  That is kept as an opt-in, MSAU_EVENT_FENCE=0, for the main <-> side events only; the
-    // gradient exchange's events (the comm stream: RCCL's kernels feed the fabric) always keep the system-scope fence.
+    // Two pools of timing-disabled events, reused across calls: with and without the system-scope fence HIP attaches to an event
+    // record (a write-back + invalidate for the host and for peers; HIP documents hipEventDisableSystemFence for timing-only events).
+    //   FORK events (main -> side, ~20 per backward sweep: the side launches read what main-stream launches wrote) are created WITHOUT
+    //   it: the consumer's visibility of the producer's writes then rests on the agent-scope release / acquire of the dispatch packets
+    //   themselves -- the same mechanism that makes two consecutive launches of ONE stream see each other's data across the 8 XCDs --
+    //   and it is checked, not assumed: msau_fork_visibility_check (tests/test_host... -m gpu: 0 stale words in thousands of forks
+    //   at 64 KB .. 256 MB), the bit-reproducibility tests of the whole step beside the side stream, tools/det_check.py.  Cost of the
+    //   fence: 2.99 -> 2.956 ms/step (round 5, interleaved A/B).
+    //   JOIN events (side -> main: the slabs before clip + Adam, the forward's attention branch) and everything on the comm stream
+    //   (RCCL's kernels feed the fabric) keep the default, fenced form: there are three or four per step.
+    //   MSAU_EVENT_FENCE=1 fences the forks as well.
     static thread_local std::vector<hipEvent_t> pool, pool_sys;
     hipStream_t ms = static_cast<hipStream_t>(stream), ss = static_cast<hipStream_t>(side_stream);
     size_t used = 0, used_sys = 0;
-    static const bool fence_all = !(std::getenv("MSAU_EVENT_FENCE") && std::getenv("MSAU_EVENT_FENCE")[0] == '0');
+    static const bool fence_all = std::getenv("MSAU_EVENT_FENCE") && std::getenv("MSAU_EVENT_FENCE")[0] == '1';
     auto next_event_of = [&](hipEvent_t* ev, bool sys) -> int {
         std::vector<hipEvent_t>& pl = sys ? pool_sys : pool;
         size_t& u = sys ? used_sys : used;
@@ -158,7 +162,7 @@ extern "C" int msau_run_ops_dp(void* stream, void* side_stream, void* comm_strea
     };
     auto join_side = [&]() -> int {
         hipEvent_t ev;
-        int rc = next_event(&ev);
+        int rc = next_event_of(&ev, true);                                 // (joins keep the system-scope fence)
         if (rc) return rc;
         if (hipEventRecord(ev, ss) != hipSuccess || hipStreamWaitEvent(ms, ev, 0) != hipSuccess)
             return msau_set_error(MSAU_ERR_HIP, "run_ops_overlap: join failed");

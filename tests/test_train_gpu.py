@@ -656,7 +656,7 @@ def test_box_list_fed_step_at_the_size_of_baseline_config_4_vs_oracle(dtype):
 
 @pytest.mark.gpu
 def test_fork_events_without_the_system_fence_give_the_same_bits(tmp_path):
-    """csrc/sequence.hip creates the main <-> side stream events with hipEventDisableSystemFence.  One cold
+    """csrc/sequence.hip creates the FORK events (main -> side) with hipEventDisableSystemFence.  One cold
     training step of the cfg-2 golden net per FRESH process (tools/det_check.py: exact fingerprints of every activation and
     gradient): two processes with the flag, one with HIP's default events (MSAU_EVENT_FENCE=1) -- one bit pattern."""
     import subprocess
@@ -674,3 +674,24 @@ def test_fork_events_without_the_system_fence_give_the_same_bits(tmp_path):
     for d in outs[1:]:
         bad = [k for k in keys if not torch.equal(outs[0][k], d[k])]
         assert not bad, bad[:5]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("words,iters", [(16 * 1024, 3000), (1 << 20, 1500), (11 * (1 << 20), 400), (64 * (1 << 20), 60)])
+def test_fork_without_the_system_fence_shows_the_producers_writes_to_the_other_queue(words, iters):
+    """What the fence-less FORK events of msau_run_ops_overlap rest on (round-4 advice: "add a stress test with producer / consumer on
+    different queues checking DATA, not just determinism").  A kernel on the main stream rewrites a buffer (64 KB: resident in every
+    L2 .. 256 MB: beyond the Infinity Cache; 44 MB: a level-0 activation), a hipEventDisableSystemFence event forks, a kernel on a
+    stream that provably runs on ANOTHER hardware queue (_lib.concurrent_stream) counts the words that do not hold the new pattern,
+    with another thread -> word mapping than the producer's -- the previous round's consumer has left the OLD pattern in the L2s of the
+    XCDs it ran on.  Any stale read is a non-zero count.  The same loop with default events is the control."""
+    from msau_amd import _lib as L
+    import ctypes as C
+    dev = torch.device("cuda", 0)
+    main = torch.cuda.current_stream(dev)
+    side = L.concurrent_stream(dev)
+    assert side is not None and side.cuda_stream != main.cuda_stream
+    for fence in (0, 1):
+        bad = C.c_int64(-1)
+        L.call("msau_fork_visibility_check", main.cuda_stream, side.cuda_stream, iters, words, fence, C.byref(bad))
+        assert bad.value == 0, (fence, words, bad.value)
