@@ -1089,7 +1089,7 @@ __global__ void vis_check_kernel(const unsigned* __restrict__ a, long long words
 }
 
 extern "C" int msau_fork_visibility_check(void* stream, void* side_stream, int iters, int64_t words, int system_fence, int64_t* mismatches) {
-    MSAU_CHECK_ARG(stream && side_stream && stream != side_stream && iters > 0 && iters <= 100000 && words > 0 && words <= (1ll << 28) && mismatches,
+    MSAU_CHECK_ARG(side_stream && stream != side_stream && iters > 0 && iters <= 100000 && words > 0 && words <= (1ll << 28) && mismatches,
                    "fork_visibility_check: bad args");
     hipStream_t ms = static_cast<hipStream_t>(stream), ss = static_cast<hipStream_t>(side_stream);
     unsigned* buf = nullptr;
