@@ -109,6 +109,13 @@ enum {
                                    16 <= Win <= 320 as far as the three-row LDS ring fits (msau_firstconv_takes decides;
                                    msau_conv2d_launch_info reports it); other flags: RELU_OUT only; results equal msau_nchw_to_nhwc + the dense launch bit for bit.
                                    msau_conv2d_launch_info: info[7] & 64 when the launch can take it. */
+    MSAU_CONV_WGRAD    = 8192,  /* with MSAU_CONV_DOUT on the two-output data gradient of the 1x1 coupling conv over concat(8, 8) -> 8
+                                   (model/model.py:143-148,246-252): the conv's WEIGHT gradient rides on this launch.  Its g operand is
+                                   this launch's input x1 and the second source of the forward conv is already here as mask_b2 (the
+                                   ReLU mask of y2 is the forward tensor itself), so only the first source is read in addition: wg_x1.
+                                   wg_slabs = msau_conv2d_rider_slabs() slabs of [2 chunks][8][16] fp32 in the layout msau_wgrad_reduce
+                                   expects for that conv (cch 8, kext 16, ones column 8 of chunk 0); the stand-alone weight-gradient
+                                   launch, its read of g and of the second source disappear.  Row-streaming 8-channel bf16 instance only. */
     MSAU_CONV_HEAD     = 64     /* inference head (kv_model.py:305-313): besides y, write softmax over the Cout real
                                    channels of the (storage-rounded) result to head_probs (fp32 [B][Hout][Wout][Cout],
                                    dense) and the index of its first maximum to head_argmax (uint8 [B][Hout][Wout]).
@@ -144,7 +151,13 @@ typedef struct {
     int32_t reserved0;
     void* pool_y;               /* MSAU_CONV_POOL only                                              */
     uint8_t* pool_idx;          /* MSAU_CONV_POOL only, may be NULL                                 */
+    const void* wg_x1;          /* MSAU_CONV_WGRAD only: the forward conv's first source [B][H][W][8]  */
+    float* wg_slabs;            /* MSAU_CONV_WGRAD only: [msau_conv2d_rider_slabs()][2][8][16] partial sums, one slab per workgroup */
+    int32_t wg_nslabs;          /* MSAU_CONV_WGRAD only: the slab count the caller allocated: the launch refuses to write another number */
+    int32_t reserved1;
 } msau_conv_desc;
+/* number of slabs an MSAU_CONV_WGRAD launch of this descriptor writes (= its workgroups); 0 if no instance takes the flag */
+int msau_conv2d_rider_slabs(int dtype, const msau_conv_desc* d);
 
 /* Geometry of the packed weight image the conv kernel expects for a given layer.
  * rows = roundup16(Cout) padded up to a power-of-two number of 16-row tiles; K is laid out as

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MSAU_HIP_LIB", os.path.join(HERE, "libmsau_hip.so"))
 F32, BF16 = 0, 1
 
 CONV_RELU_IN, CONV_RELU_OUT, CONV_ADD, CONV_ACCUM, CONV_MASK_A, CONV_MASK_B, CONV_HEAD, CONV_DOUT = 1, 2, 4, 8, 16, 32, 64, 128
-CONV_LRN, CONV_POOL, CONV_IDS, CONV_OWNER, CONV_NCHW = 256, 512, 1024, 2048, 4096
+CONV_LRN, CONV_POOL, CONV_IDS, CONV_OWNER, CONV_NCHW, CONV_WGRAD = 256, 512, 1024, 2048, 4096, 8192
 
 i32, i64, vp, f32 = C.c_int32, C.c_int64, C.c_void_p, C.c_float
 
@@ -24,7 +24,8 @@ class ConvDesc(C.Structure):
                                    "pad_t", "pad_l", "stride", "ups", "flags")] + \
                [(n, vp) for n in ("x1", "x2", "wpack", "bias", "add", "mask_a", "mask_b", "y", "head_probs", "head_argmax")] + \
                [("head_classes", i32), ("flags2", i32), ("y2", vp), ("mask_b2", vp)] + \
-               [("lrn_alpha_over_n", f32), ("lrn_beta", f32), ("lrn_k", f32), ("reserved0", i32), ("pool_y", vp), ("pool_idx", vp)]
+               [("lrn_alpha_over_n", f32), ("lrn_beta", f32), ("lrn_k", f32), ("reserved0", i32), ("pool_y", vp), ("pool_idx", vp)] + \
+               [("wg_x1", vp), ("wg_slabs", vp), ("wg_nslabs", i32), ("reserved1", i32)]
 
 
 class ConvPairDesc(C.Structure):
@@ -130,6 +131,7 @@ _SIGNATURES = {
     "msau_lds_wrow_stride": (C.c_int, [C.c_int, C.c_int]),
     "msau_conv_pack_geometry": (C.c_int, [C.c_int] * 9 + [C.POINTER(ConvPackGeom)]),
     "msau_conv2d": (C.c_int, [vp, C.c_int, C.POINTER(ConvDesc)]),
+    "msau_conv2d_rider_slabs": (C.c_int, [C.c_int, C.POINTER(ConvDesc)]),
     "msau_conv2d_launch_info": (C.c_int, [C.c_int, C.POINTER(ConvDesc), C.POINTER(i32)]),
     "msau_conv_pair_applicable": (C.c_int, [C.c_int, C.POINTER(ConvPairDesc)]),
     "msau_conv_pair": (C.c_int, [vp, C.c_int, C.POINTER(ConvPairDesc)]),

@@ -405,6 +405,8 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
     MSAU_CHECK_ARG(!(d->flags & MSAU_CONV_ADD) || d->add, "conv2d: ADD without pointer");
     MSAU_CHECK_ARG(!(d->flags & MSAU_CONV_MASK_A) || d->mask_a, "conv2d: MASK_A without pointer");
     MSAU_CHECK_ARG(!(d->flags & MSAU_CONV_MASK_B) || d->mask_b, "conv2d: MASK_B without pointer");
+    if (d->flags & MSAU_CONV_WGRAD)                                            // a rider only the row-streaming coupling instance carries
+        MSAU_CHECK_ARG(msau_conv2d_rider_slabs(dtype, d) > 0, "conv2d: MSAU_CONV_WGRAD is not implemented for this launch (msau_conv2d_rider_slabs says 0)");
     if (d->flags & MSAU_CONV_OWNER) {                                          // ownerconv.hip: box lists instead of a painted input tensor
         MSAU_CHECK_ARG(msau_ownerconv_takes(dtype, d), "conv2d: MSAU_CONV_OWNER is the 3x3 stride-1 C -> 8 conv, no other flag but RELU_OUT");
         return msau_ownerconv_fwd(static_cast<hipStream_t>(stream), dtype, d);

@@ -888,9 +888,23 @@ struct RowConvArgs {
     unsigned img_bytes;
 };
 
-template <int NS, int KH, int KW, int EPI, int EPI2 = 0>
+// WG (MSAU_CONV_WGRAD, the 1x1 two-output instance = the data gradient of the coupling conv z = ReLU(Wc concat(prev, y) + bc),
+// model/model.py:143-148,246-252): the conv's weight gradient in the same launch.  g is this launch's input row (lanes of groups 0, 1
+// hold a pixel each); y is already here as the ReLU-mask operand of the second output (the forward tensor itself, 8 bytes per lane in
+// the result layout); prev costs one more 16-byte load per lane and row.  The three rows go to LDS as [pixel][8 channels] and come
+// back transposed (ds_read_b64_tr_b16: pixels become the MFMA's K): per 32 pixels ONE MFMA gives
+//     D[(s, ci)][co] += sum_px  x_s[ci](px) * g[co](px)          (s = 0: prev, 1: y)
+// -- the 32 bytes a lane group reads per pixel are chunks {ch 0-3, ch 4-7} of source 0 and of source 1 instead of two neighbouring
+// pixels of one source (rowwgrad8_kernel's shifted windows) -- and one more against ones the bias gradient.  The four waves of a
+// workgroup add up in LDS in a fixed order and write ONE slab [2 chunks][8][16] (kext 16, ones column 8 of chunk 0): the layout
+// msau_wgrad_reduce expects for wgrad_lean<C8, CO8, K1>, whose launch (66 MB at the bench size) disappears.
+constexpr int WGC_ROW = 32 * 16;                  // a staged row: 32 pixels x 8 bf16
+
+template <int NS, int KH, int KW, int EPI, int EPI2 = 0, bool WG = false>
 __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
     constexpr bool DOUT = (EPI & MSAU_CONV_DOUT) != 0;                     // two outputs (stored weight rows 0..7 -> y, 8..15 -> y2)
+    static_assert(!WG || (DOUT && KW == 1 && NS == 1 && EPI == MSAU_CONV_DOUT && EPI2 == MSAU_CONV_MASK_B), "the rider belongs to the coupling conv's data gradient");
+    __shared__ __align__(16) unsigned char wsm[WG ? 4 * 3 * WGC_ROW + 64 + 2 * 8 * 16 * 4 : 16];
     constexpr bool K1D = KW == 1 && NS == 2;                               // 1x1 over concat(x1, x2)
     static_assert((KW == 3 && (NS == 1 || NS == 2)) || (K1D && KH == 1) || (KW == 1 && NS == 1 && KH == 1 && DOUT) || (KW == 4 && NS == 1),
                   "instances: 3x3, 1x1 dual, 1x1 two-output, 4x4");
@@ -910,7 +924,10 @@ __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tloc = (blockIdx.x >> 3) * 4 + wave;
     const int task = (blockIdx.x & 7) * a.tasks_per_xcd + tloc;
-    if (tloc >= a.tasks_per_xcd || task >= a.ntasks) return;
+    const bool live = tloc < a.tasks_per_xcd && task < a.ntasks;          // wave-uniform
+    if constexpr (!WG) { if (!live) return; }                             // (WG: idle waves wait at the slab reduction)
+    f32x4 wacc = {0.f, 0.f, 0.f, 0.f}, waccb = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
     const int t1 = task / a.nstrips, strip = task - t1 * a.nstrips;
     const int b = t1 / a.nseg, seg = t1 - b * a.nseg;
     const int H = d.Hout, W = d.Wout;
@@ -999,10 +1016,37 @@ __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
         if constexpr (HAS_MB) OPB[P] = __builtin_amdgcn_raw_buffer_load_b64(rmb, o, 0, 0);
     };
 
+    // ---- WG: prev rows in the ring beside the g rows; the three staging rows of this wave; the transposed-read addresses
+    u32x4 PVX[WG ? NXR : 1];
+    const __amdgpu_buffer_rsrc_t rwp = rsrc_of(WG ? static_cast<const char*>(d.wg_x1) + img : nullptr, WG ? a.img_bytes : 0u);
+    auto load_prev = [&](int r, auto slot) {
+        constexpr int S = decltype(slot)::value;
+        if constexpr (WG) PVX[S] = __builtin_amdgcn_raw_buffer_load_b128(rwp, r >= y0 && r < y1 ? (unsigned)(r * a.row_bytes) + lcol_m : kOOB, 0, 0);
+    };
+    unsigned char* const wbase = wsm + wave * 3 * WGC_ROW;                 // [g | prev | y]
+    unsigned char* const wzero = wsm + 4 * 3 * WGC_ROW;                    // 16 zero bytes (+ pad): MFMA rows 8..15 of the g operand
+    const int wpx = (2 * lr + lg) * 16;                                    // groups 0, 1: this lane's pixel of the row
+    const int wry = j * 16 + c0 * 2;                                       // result layout slot (the mask operand's)
+    const int trp = 8 * (lane >> 4) + ((lane & 15) >> 2), trc = lane & 3;  // transposed read: pixel trp (+ 4), chunk trc of the 32-byte window
+    const unsigned char* const tr_x = wbase + (trc < 2 ? WGC_ROW : 2 * WGC_ROW) + trp * 16 + (trc & 1) * 8;
+    const unsigned char* const tr_g = trc < 2 ? wbase + trp * 16 + (trc & 1) * 8 : wzero + (trc & 1) * 8;
+    const int tr_g_hi = trc < 2 ? 4 * 16 : 0;
+    auto trfrag = [&](const unsigned char* p, int hi) -> bf16x8 {
+        const bf16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)p);
+        const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(p + hi));
+        return __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    const u32x4 wones_bits = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    if constexpr (WG) {
+        if (lane < 4) reinterpret_cast<unsigned*>(wzero)[lane] = 0u;       // (every live wave writes the same zeros)
+        __builtin_amdgcn_wave_barrier();
+    }
+
     // prologue: rows r0 .. r0 + NXR - 2 of the first output row (r0 = y0 - pad_t); operands of rows y0, y0 + 1
     {
         const int r0 = y0 - d.pad_t;
         [&]<int... K>(std::integer_sequence<int, K...>) { (load_row(r0 + K, IC<K>{}), ...); }(std::make_integer_sequence<int, NXR - 1>{});
+        [&]<int... K>(std::integer_sequence<int, K...>) { (load_prev(r0 + K, IC<K>{}), ...); }(std::make_integer_sequence<int, NXR - 1>{});
     }
     load_ops(y0, IC<0>{});
     load_ops(y0 + 1, IC<1>{});
@@ -1011,6 +1055,7 @@ __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
         constexpr int I = decltype(ic)::value, P = I & 1;
         const int t = tg + I;
         load_row(t - d.pad_t + NXR - 1, IC<(I + NXR - 1) % NXR>{});
+        load_prev(t - d.pad_t + NXR - 1, IC<(I + NXR - 1) % NXR>{});
         f32x4 acc = bias;
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky)
@@ -1038,6 +1083,20 @@ __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
             }
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o1), ry, oo, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o2), ry2, oo, 0, 0);
+            if constexpr (WG) {
+                // rows of g, prev, y of output row t -> LDS as [pixel][8 channels] (rows outside [y0, y1) were loaded as zeros)
+                if (lg < 2) {
+                    *reinterpret_cast<u32x4*>(wbase + wpx) = X[0][I % NXR][0];
+                    *reinterpret_cast<u32x4*>(wbase + WGC_ROW + wpx) = PVX[I % NXR];
+                }
+                *reinterpret_cast<u32x2*>(wbase + 2 * WGC_ROW + wry) = OPB2[P];
+                __builtin_amdgcn_wave_barrier();
+                const bf16x8 xf = trfrag(tr_x, 4 * 16);                    // rows (source, ci), k = 8 pixels of this lane group
+                const bf16x8 gf = trfrag(tr_g, tr_g_hi);                   // rows co (8..15: zeros)
+                __builtin_amdgcn_wave_barrier();
+                wacc = mma8(xf, gf, wacc);
+                waccb = mma8(__builtin_bit_cast(bf16x8, wones_bits), gf, waccb);
+            }
             load_ops(t + 2, IC<P>{});
             __builtin_amdgcn_sched_barrier(0);
             return;
@@ -1101,6 +1160,28 @@ __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
     };
     for (int tg = y0; tg < y1; tg += NXR)
         [&]<int... K>(std::integer_sequence<int, K...>) { (step(IC<K>{}, tg), ...); }(std::make_integer_sequence<int, NXR>{});
+    }   // live
+    if constexpr (WG) {
+        // ---- the four waves' sums -> one slab [chunk = source][co][16], fixed order
+        float* slab = reinterpret_cast<float*>(wsm + 4 * 3 * WGC_ROW + 64);
+        for (int i = threadIdx.x; i < 2 * 8 * 16; i += 256) slab[i] = 0.f;
+        __syncthreads();
+        const int n = lane & 15, kg = lane >> 4;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w && n < 8) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int row = 4 * kg + jj;                           // (source, ci)
+                    slab[(row >> 3) * 128 + n * 16 + (row & 7)] += wacc[jj];
+                }
+                if (kg == 0) slab[n * 16 + 8] += waccb[0];                 // the ones column: the bias gradient
+            }
+            __syncthreads();
+        }
+        float* out = a.d.wg_slabs + (size_t)blockIdx.x * (2 * 8 * 16);
+        for (int i = threadIdx.x; i < 2 * 8 * 16; i += 256) out[i] = slab[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -1349,7 +1430,7 @@ constexpr int kFwd1 = MSAU_PAIR_RELU_IN | MSAU_PAIR_RELU_MID, kFwd2 = MSAU_CONV_
 constexpr int kBwd1 = MSAU_PAIR_MASK_MID, kBwd2 = MSAU_CONV_MASK_A | MSAU_CONV_ADD;
 
 // environment switches of this file, read once; msau_reload_env() makes the next call read them again (tests, A/B tools)
-struct RowsEnv { int on, sh, sh16, waves, min_tasks, maxc, conv, wgrad, wgrad4, dout, pairwg, couple, deconv; };
+struct RowsEnv { int on, sh, sh16, waves, min_tasks, maxc, conv, wgrad, wgrad4, dout, pairwg, couple, deconv, cplwg; };
 RowsEnv g_env;
 bool g_env_ok = false;
 const RowsEnv& rows_env() {
@@ -1364,6 +1445,7 @@ const RowsEnv& rows_env() {
         g_env.wgrad4 = geti("MSAU_WGRAD_ROWS4", 0);              // ... and the 4x4 end conv's: correct (tests), but 13 us per step SLOWER than the tile kernel beside the main stream: off
         g_env.conv = geti("MSAU_CONV_ROWS", 1);                  // single convolutions of the 8-channel level on the row kernels
         g_env.pairwg = geti("MSAU_PAIR_WGRAD", 1);               // the first conv's weight gradient inside the pair's data-gradient launch
+        g_env.cplwg = geti("MSAU_COUPLE_WGRAD", 1);              // the coupling conv's weight gradient inside its data-gradient launch
         g_env.deconv = geti("MSAU_DECONV_ROWS", 1);              // the 16 -> 8 transposed conv on the row kernel (live taps only)
         g_env.couple = geti("MSAU_PAIR_COUPLE", 1);              // the coupling 1x1 conv inside the pair's forward launch
         g_env.dout = geti("MSAU_DOUT_ROWS", 1);                  // the two-output data gradients (8 -> 8 + 8, 3x3 and 1x1) on the row kernels
@@ -1511,6 +1593,7 @@ int rowconv_case(int dtype, const msau_conv_desc* d) {
         const int f1 = f & ~MSAU_CONV_DOUT, f2 = d->flags2;
         if (k == 3 && d->pad_t == 1 && d->pad_l == 1 && f2 == 0) return f1 == 0 ? 9 : f1 == MSAU_CONV_ACCUM ? 10 : 0;
         if (k == 1 && d->pad_t == 0 && d->pad_l == 0 && f1 == 0 && f2 == MSAU_CONV_MASK_B && d->mask_b2) return 11;
+        if (k == 1 && d->pad_t == 0 && d->pad_l == 0 && f1 == MSAU_CONV_WGRAD && f2 == MSAU_CONV_MASK_B && d->mask_b2 && d->wg_x1 && d->wg_slabs && e.cplwg) return 13;
         return 0;
     }
     if (k == 3 && !dual && d->pad_t == 1 && d->pad_l == 1) {
@@ -1530,6 +1613,32 @@ int rowconv_case(int dtype, const msau_conv_desc* d) {
 }  // namespace
 
 int msau_rowconv_takes(int dtype, const msau_conv_desc* d) { return rowconv_case(dtype, d) != 0; }
+
+namespace {
+// task split of a rowconv8 launch (3x3 / 1x1 / 4x4 instances)
+void rowconv_split(const msau_conv_desc* d, RowConvArgs& a) {
+    a.nstrips = cdiv(d->Wout, 32);
+    const int unr = d->KH == 4 ? 8 : d->KH + MSAU_ROWCONV_PF;
+    const RowsEnv& e = rows_env();
+    int nseg = e.waves / (d->B * a.nstrips);
+    if (nseg < 1) nseg = 1;
+    int sh = e.sh > 0 ? e.sh : cdiv(d->Hout, nseg);
+    if (sh < 8) sh = 8;
+    sh = roundup(sh, unr);
+    a.SH = sh < d->Hout ? sh : d->Hout;
+    a.nseg = cdiv(d->Hout, a.SH);
+    a.ntasks = d->B * a.nstrips * a.nseg;
+    a.tasks_per_xcd = roundup(cdiv(a.ntasks, 8), 4);
+}
+}  // namespace
+
+// slabs (= workgroups) of an MSAU_CONV_WGRAD launch of this descriptor; 0 if no instance takes the flag
+extern "C" int msau_conv2d_rider_slabs(int dtype, const msau_conv_desc* d) {
+    if (!d || !(d->flags & MSAU_CONV_WGRAD) || rowconv_case(dtype, d) != 13) return 0;
+    RowConvArgs a;
+    rowconv_split(d, a);
+    return 8 * (a.tasks_per_xcd / 4);
+}
 
 int msau_rowconv_launch(hipStream_t s, int dtype, const msau_conv_desc* d, int kchunk, int rows) {
     const int which = rowconv_case(dtype, d);
@@ -1557,20 +1666,7 @@ int msau_rowconv_launch(hipStream_t s, int dtype, const msau_conv_desc* d, int k
     }
     RowConvArgs a;
     a.d = *d;
-    a.nstrips = cdiv(d->Wout, 32);
-    const int unr = d->KH == 4 ? 8 : d->KH + MSAU_ROWCONV_PF;
-    {
-        const RowsEnv& e = rows_env();
-        int nseg = e.waves / (d->B * a.nstrips);
-        if (nseg < 1) nseg = 1;
-        int sh = e.sh > 0 ? e.sh : cdiv(d->Hout, nseg);
-        if (sh < 8) sh = 8;
-        sh = roundup(sh, unr);
-        a.SH = sh < d->Hout ? sh : d->Hout;
-    }
-    a.nseg = cdiv(d->Hout, a.SH);
-    a.ntasks = d->B * a.nstrips * a.nseg;
-    a.tasks_per_xcd = roundup(cdiv(a.ntasks, 8), 4);
+    rowconv_split(d, a);
     a.row_bytes = d->Wout * 16;
     a.img_bytes = (unsigned)d->Hout * (unsigned)a.row_bytes;
     a.wrow = kchunk;
@@ -1587,6 +1683,12 @@ int msau_rowconv_launch(hipStream_t s, int dtype, const msau_conv_desc* d, int k
         case 9: return launch_rowconv8<1, 3, 3, MSAU_CONV_DOUT>(s, a);
         case 10: return launch_rowconv8<1, 3, 3, MSAU_CONV_DOUT | MSAU_CONV_ACCUM>(s, a);
         case 11: return launch_rowconv8<1, 1, 1, MSAU_CONV_DOUT, MSAU_CONV_MASK_B>(s, a);
+        case 13:
+            MSAU_CHECK_ARG(8 * (a.tasks_per_xcd / 4) == d->wg_nslabs, "conv2d: MSAU_CONV_WGRAD launch has %d workgroups, the caller allocated %d slabs "
+                           "(msau_conv2d_rider_slabs under other MSAU_ROWS_* settings?)", 8 * (a.tasks_per_xcd / 4), d->wg_nslabs);
+            hipLaunchKernelGGL((rowconv8_kernel<1, 1, 1, MSAU_CONV_DOUT, MSAU_CONV_MASK_B, true>), dim3(8 * (a.tasks_per_xcd / 4)), dim3(256), 0, s, a);
+            MSAU_CHECK_LAUNCH("rowconv8_kernel");
+            return 0;
     }
     return msau_set_error(MSAU_ERR_ARG, "rowconv: no instance");
 }

@@ -373,11 +373,31 @@ class ConvOp(Op):
             u.b_count = out.C
         P.add_unpack_entry(u, slab_elems, self.reduce_group())
         self.uentry = u
+        # the coupling 1x1 conv's weight gradient rides on its two-output data-gradient launch where an instance has it (the
+        # row-streaming 8-channel one): g is that launch's input, the second source its ReLU-mask operand; MSAU_CONV_WGRAD
+        dd = self.ddesc[0]
+        if conv and self.k == 1 and x2 is not None and self.dd_off is not None and dd is not None and not self.relu_in \
+                and dd.flags == L.CONV_DOUT and dd.flags2 == L.CONV_MASK_B and u.kext == 16 and u.slab_elems == 256 and u.cch == 8 \
+                and u.nchunks == 2 and os.environ.get("MSAU_COUPLE_WGRAD", "1") != "0" and P.cfg.get("couple_wgrad", True):
+            dd.flags |= L.CONV_WGRAD
+            dd.wg_x1, dd.wg_slabs = _ptr(x1.data), 1                 # (placeholder: the slab arena does not exist yet)
+            ns = int(L.load().msau_conv2d_rider_slabs(P.dtype, C.byref(dd)))
+            if ns > 0:
+                dd.wg_nslabs = ns
+                self.wg_slab_off = P.alloc_slab(ns * 256)
+                u.slab_off, u.nslabs = self.wg_slab_off, ns
+                u.b_src_off, u.b_nslabs = self.wg_slab_off + 8, ns
+                self.wg_fused = True
+            else:
+                dd.flags &= ~L.CONV_WGRAD
+                dd.wg_x1 = dd.wg_slabs = None
 
     def late_bind(self):
         P = self.plan
         if self.wdesc is not None:
             self.wdesc.slabs = P.slab_ptr(self.slab_off)
+        if self.wg_fused and self.pair is None and self.ddesc[0] is not None and self.ddesc[0].flags & L.CONV_WGRAD:
+            self.ddesc[0].wg_slabs = P.slab_ptr(self.wg_slab_off)
         # ---- launch metadata for profiling / roofline accounting (bench.py)
         T = "f32" if P.dtype == L.F32 else "bf16"
         esz = 4 if P.dtype == L.F32 else 2
@@ -397,7 +417,8 @@ class ConvOp(Op):
                 half = nout // 2
                 ex1 = sum(1 for f in (L.CONV_ADD, L.CONV_ACCUM, L.CONV_MASK_B) if d.flags & f)
                 ex2 = sum(1 for f in (L.CONV_ACCUM, L.CONV_MASK_B) if d.flags2 & f)
-                return f"conv_lean_kernel<{T},CIN{d.C1},CT{info[0]},K{d.KH},dout>", (nin + half * (2 + ex1 + ex2)) * esz
+                rider = (half * esz + d.wg_nslabs * 256 * 4) if d.flags & L.CONV_WGRAD else 0       # the first source read, the slabs written
+                return f"conv_lean_kernel<{T},CIN{d.C1},CT{info[0]},K{d.KH},dout{',wgrad' if rider else ''}>", (nin + half * (2 + ex1 + ex2)) * esz + rider
             if info[6] == 3:
                 name = f"rowconv_kernel<{T},CIN{d.C1 + d.C2},CO{d.Cout},K{d.KH}{',lrn' if d.flags & L.CONV_LRN else ''}{',ups2' if d.ups == 2 else ''}>"
             elif info[6] == 2:

@@ -776,3 +776,57 @@ def test_row_streaming_transposed_conv_matches_the_zero_stuffed_launch_and_torch
     assert torch.equal(res["1"][2], res["0"][2]), "input gradient"
     for n in res["1"][3]:
         assert torch.equal(res["1"][3][n], res["0"][3][n]), n
+
+
+@pytest.mark.parametrize("hw,B", [((40, 64), 2), ((37, 45), 3), ((9, 130), 2), ((130, 140), 4)])
+def test_coupling_conv_weight_gradient_in_its_data_gradient_launch(monkeypatch, hw, B):
+    """MSAU_CONV_WGRAD (round 5): the weight / bias gradient of the 8-channel coupling conv z = ReLU(Wc concat(prev, y) + bc)
+    (model/model.py:143-148) computed by its own two-output data-gradient launch (rowconv8_kernel<1, 1, 1, DOUT, MASK_B, WG>) against
+    the stand-alone weight-gradient launch (MSAU_COUPLE_WGRAD=0): every data gradient and every other parameter gradient bit for
+    bit, wc / bc within the fp32 summation-order bound, and against torch autograd on the rounded operands."""
+    torch.manual_seed(41)
+    H, W = hw
+    c = 8
+    x = torch.randn(B, c, H, W)
+    p = {"w0": 0.3 * torch.randn(c, c, 1, 1), "b0": 0.1 * torch.randn(c), "w1": 0.2 * torch.randn(c, c, 3, 3), "b1": 0.1 * torch.randn(c),
+         "wc": 0.25 * torch.randn(c, 2 * c, 1, 1), "bc": 0.1 * torch.randn(c)}
+    gy = torch.randn(B, c, H, W)
+    seen = []
+
+    def build(plan):
+        x0 = plan.x_in
+        prev = Act(plan, "prev", H, W, c, relu_out=True)
+        ConvOp(plan, "c0", x0, None, "w0", "b0", prev, 1, relu_out=True)
+        cur = Act(plan, "cur", H, W, c, relu_out=True)
+        ConvOp(plan, "c1", x0, None, "w1", "b1", cur, 3, relu_out=True)
+        z = Act(plan, "z", H, W, c, relu_out=True)
+        seen.append(ConvOp(plan, "cpl", prev, cur, "wc", "bc", z, 1, relu_out=True))
+        plan.logits = z
+    monkeypatch.setenv("MSAU_ROWS_MIN_TASKS", "1")
+    res = {}
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MSAU_COUPLE_WGRAD", mode)
+            L.load().msau_reload_env()
+            res[mode] = run_graph(build, p, x, gy, L.BF16)
+    finally:
+        monkeypatch.undo()
+        L.load().msau_reload_env()
+    assert seen[0].wg_fused and not seen[1].wg_fused
+    assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][2], res["0"][2])
+    for n in res["1"][3]:
+        if n in ("wc", "bc"):
+            d = (res["1"][3][n] - res["0"][3][n]).abs().max()
+            assert float(d) <= 2e-5 * float(res["0"][3][n].abs().max()) * (H * W * B) ** 0.5 + 1e-6, (n, float(d))
+        else:
+            assert torch.equal(res["1"][3][n], res["0"][3][n]), n
+    # torch autograd on bf16-rounded operands (the stored activations are bf16; accumulation fp32)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    prev_r = bf(O.conv_same(bf(x), bf(p["w0"]), p["b0"], relu=True))
+    cur_r = bf(O.conv_same(bf(x), bf(p["w1"]), p["b1"], relu=True))
+    wc = bf(p["wc"]).requires_grad_(True)
+    bc = p["bc"].clone().requires_grad_(True)
+    z_r = O.conv_same(torch.cat([prev_r, cur_r], 1), wc, bc, relu=True)
+    gz = bf(bf(gy) * (bf(z_r.detach()) > 0))                  # the gradient tensor the launch reads: masked, stored in bf16
+    O.conv_same(torch.cat([prev_r, cur_r], 1), wc, bc).backward(gz)
+    assert err(res["1"][3]["wc"], wc.grad, False) < 2e-3 and err(res["1"][3]["bc"], bc.grad, False) < 2e-3
