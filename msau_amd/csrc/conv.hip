@@ -427,7 +427,7 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
                                   "msau_conv2d_launch_info info[7]); run msau_softmax_argmax_nhwc on y instead");
     }
     if (d->flags & MSAU_CONV_DOUT) {
-        const int okf = MSAU_CONV_DOUT | MSAU_CONV_ADD | MSAU_CONV_ACCUM | MSAU_CONV_MASK_B;
+        const int okf = MSAU_CONV_DOUT | MSAU_CONV_ADD | MSAU_CONV_ACCUM | MSAU_CONV_MASK_B | MSAU_CONV_WGRAD;   // (WGRAD: checked above)
         MSAU_CHECK_ARG(d->y2 && !(d->flags & ~okf) && !(d->flags2 & ~(MSAU_CONV_ACCUM | MSAU_CONV_MASK_B)) &&
                        (!(d->flags2 & MSAU_CONV_MASK_B) || d->mask_b2), "conv2d: bad DOUT arguments");
         if (!msau_conv_lean_dout_capable(dtype, d, g.nchunks, g.CT) && !(g.nslices == 1 && msau_rowconv_takes(dtype, d)))

@@ -795,8 +795,10 @@ def test_coupling_conv_weight_gradient_in_its_data_gradient_launch(monkeypatch, 
 
     def build(plan):
         x0 = plan.x_in
-        prev = Act(plan, "prev", H, W, c, relu_out=True)
-        ConvOp(plan, "c0", x0, None, "w0", "b0", prev, 1, relu_out=True)
+        # (prev without a ReLU of its own: in the net the previous stage's tensor has later contributions, so this launch writes
+        #  its gradient un-masked -- the flag set the rider's instance is compiled for)
+        prev = Act(plan, "prev", H, W, c)
+        ConvOp(plan, "c0", x0, None, "w0", "b0", prev, 1)
         cur = Act(plan, "cur", H, W, c, relu_out=True)
         ConvOp(plan, "c1", x0, None, "w1", "b1", cur, 3, relu_out=True)
         z = Act(plan, "z", H, W, c, relu_out=True)
@@ -822,7 +824,7 @@ def test_coupling_conv_weight_gradient_in_its_data_gradient_launch(monkeypatch, 
             assert torch.equal(res["1"][3][n], res["0"][3][n]), n
     # torch autograd on bf16-rounded operands (the stored activations are bf16; accumulation fp32)
     bf = lambda t: t.to(torch.bfloat16).float()
-    prev_r = bf(O.conv_same(bf(x), bf(p["w0"]), p["b0"], relu=True))
+    prev_r = bf(O.conv_same(bf(x), bf(p["w0"]), p["b0"]))
     cur_r = bf(O.conv_same(bf(x), bf(p["w1"]), p["b1"], relu=True))
     wc = bf(p["wc"]).requires_grad_(True)
     bc = p["bc"].clone().requires_grad_(True)
