@@ -778,7 +778,7 @@ def test_row_streaming_transposed_conv_matches_the_zero_stuffed_launch_and_torch
         assert torch.equal(res["1"][3][n], res["0"][3][n]), n
 
 
-@pytest.mark.parametrize("hw,B", [((40, 64), 2), ((37, 45), 3), ((9, 130), 2), ((130, 140), 4)])
+@pytest.mark.parametrize("hw,B", [((64, 128), 4), ((97, 75), 6), ((130, 140), 4)])      # (sizes at which the plan fuses the two data gradients into one launch)
 def test_coupling_conv_weight_gradient_in_its_data_gradient_launch(monkeypatch, hw, B):
     """MSAU_CONV_WGRAD (round 5): the weight / bias gradient of the 8-channel coupling conv z = ReLU(Wc concat(prev, y) + bc)
     (model/model.py:143-148) computed by its own two-output data-gradient launch (rowconv8_kernel<1, 1, 1, DOUT, MASK_B, WG>) against
