@@ -479,7 +479,9 @@ def test_fused_residual_pair_is_bit_identical_to_two_launches(monkeypatch, dtype
     if exact:
         assert l1 == l0 and torch.equal(q1, q0) and torch.equal(g1, g0) and torch.equal(p1, p0)
     else:
-        assert abs(l1 - l0) < 1e-3 * abs(l0) and err(q1.float().cpu(), q0.float().cpu(), True) < 5e-2
+        # (the softmax prediction of the forward-only plan: 3e-2 .. 7e-2 between the two trajectories, depending on how many launches
+        #  differ between the modes -- since round 5 the fused mode also carries the coupling convs)
+        assert abs(l1 - l0) < 1e-3 * abs(l0) and err(q1.float().cpu(), q0.float().cpu(), True) < 1e-1
         assert err(g1.cpu(), g0.cpu(), True) < 3e-1 and float((p1 - p0).abs().max()) < 2.5e-4      # Adam's first step is lr * sign(g)
 
 
