@@ -349,7 +349,7 @@ class ConvOp(Op):
         wg = L.WgradGeom()
         w.nslabs = 1
         L.call("msau_wgrad_geometry", P.dtype, C.byref(w), C.byref(wg))
-        nslabs = max(1, min(wg.max_slabs, int(os.environ.get('MSAU_SLAB_CAP', '384')), max(64, (int(os.environ.get('MSAU_SLAB_MB', '3')) << 20) // max(wg.slab_bytes, 1))))
+        nslabs = max(1, min(wg.max_slabs, int(os.environ.get('MSAU_SLAB_CAP', '384')), max(int(os.environ.get('MSAU_SLAB_MIN', '64')), (int(os.environ.get('MSAU_SLAB_MB', '3')) << 20) // max(wg.slab_bytes, 1))))
         w.nslabs = nslabs
         slab_elems = wg.slab_bytes // 4
         self.slab_off = P.alloc_slab(nslabs * slab_elems)
