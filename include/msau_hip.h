@@ -116,11 +116,6 @@ enum {
                                    wg_slabs = msau_conv2d_rider_slabs() slabs of [2 chunks][8][16] fp32 in the layout msau_wgrad_reduce
                                    expects for that conv (cch 8, kext 16, ones column 8 of chunk 0); the stand-alone weight-gradient
                                    launch, its read of g and of the second source disappear.  Row-streaming 8-channel bf16 instance only. */
-    MSAU_CONV_CSUM2    = 16384, /* with MSAU_CONV_DOUT (3x3 over concat(8, 8), the merge conv of the decoder, model/model.py:242-244): also
-                                   write per-workgroup channel sums of the STORED second output y2 to csum2[msau_conv2d_rider_slabs()][8]
-                                   (fp32, fixed summation order) -- y2 is the gradient of the transposed conv's output, whose sum over the
-                                   pixels is that layer's bias gradient: the msau_channel_sum pass over it (22 MB at the bench size) disappears.
-                                   Row-streaming 8-channel bf16 instances only. */
     MSAU_CONV_HEAD     = 64     /* inference head (kv_model.py:305-313): besides y, write softmax over the Cout real
                                    channels of the (storage-rounded) result to head_probs (fp32 [B][Hout][Wout][Cout],
                                    dense) and the index of its first maximum to head_argmax (uint8 [B][Hout][Wout]).
@@ -158,12 +153,10 @@ typedef struct {
     uint8_t* pool_idx;          /* MSAU_CONV_POOL only, may be NULL                                 */
     const void* wg_x1;          /* MSAU_CONV_WGRAD only: the forward conv's first source [B][H][W][8]  */
     float* wg_slabs;            /* MSAU_CONV_WGRAD only: [msau_conv2d_rider_slabs()][2][8][16] partial sums, one slab per workgroup */
-    int32_t wg_nslabs;          /* MSAU_CONV_WGRAD / MSAU_CONV_CSUM2: the slab / partial count the caller allocated: the launch refuses to write another number */
+    int32_t wg_nslabs;          /* MSAU_CONV_WGRAD only: the slab count the caller allocated: the launch refuses to write another number */
     int32_t reserved1;
-    float* csum2;               /* MSAU_CONV_CSUM2 only: [msau_conv2d_rider_slabs()][8] partial channel sums of y2           */
 } msau_conv_desc;
-/* number of slabs (MSAU_CONV_WGRAD) / partial-sum rows (MSAU_CONV_CSUM2) a launch of this descriptor writes (= its workgroups);
- * 0 if no instance takes the flag */
+/* number of slabs an MSAU_CONV_WGRAD launch of this descriptor writes (= its workgroups); 0 if no instance takes the flag */
 int msau_conv2d_rider_slabs(int dtype, const msau_conv_desc* d);
 
 /* Geometry of the packed weight image the conv kernel expects for a given layer.

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MSAU_HIP_LIB", os.path.join(HERE, "libmsau_hip.so"))
 F32, BF16 = 0, 1
 
 CONV_RELU_IN, CONV_RELU_OUT, CONV_ADD, CONV_ACCUM, CONV_MASK_A, CONV_MASK_B, CONV_HEAD, CONV_DOUT = 1, 2, 4, 8, 16, 32, 64, 128
-CONV_LRN, CONV_POOL, CONV_IDS, CONV_OWNER, CONV_NCHW, CONV_WGRAD, CONV_CSUM2 = 256, 512, 1024, 2048, 4096, 8192, 16384
+CONV_LRN, CONV_POOL, CONV_IDS, CONV_OWNER, CONV_NCHW, CONV_WGRAD = 256, 512, 1024, 2048, 4096, 8192
 
 i32, i64, vp, f32 = C.c_int32, C.c_int64, C.c_void_p, C.c_float
 
@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
                [(n, vp) for n in ("x1", "x2", "wpack", "bias", "add", "mask_a", "mask_b", "y", "head_probs", "head_argmax")] + \
                [("head_classes", i32), ("flags2", i32), ("y2", vp), ("mask_b2", vp)] + \
                [("lrn_alpha_over_n", f32), ("lrn_beta", f32), ("lrn_k", f32), ("reserved0", i32), ("pool_y", vp), ("pool_idx", vp)] + \
-               [("wg_x1", vp), ("wg_slabs", vp), ("wg_nslabs", i32), ("reserved1", i32), ("csum2", vp)]
+               [("wg_x1", vp), ("wg_slabs", vp), ("wg_nslabs", i32), ("reserved1", i32)]
 
 
 class ConvPairDesc(C.Structure):

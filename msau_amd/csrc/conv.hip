@@ -405,8 +405,8 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
     MSAU_CHECK_ARG(!(d->flags & MSAU_CONV_ADD) || d->add, "conv2d: ADD without pointer");
     MSAU_CHECK_ARG(!(d->flags & MSAU_CONV_MASK_A) || d->mask_a, "conv2d: MASK_A without pointer");
     MSAU_CHECK_ARG(!(d->flags & MSAU_CONV_MASK_B) || d->mask_b, "conv2d: MASK_B without pointer");
-    if (d->flags & (MSAU_CONV_WGRAD | MSAU_CONV_CSUM2))                        // riders only row-streaming instances carry
-        MSAU_CHECK_ARG(msau_conv2d_rider_slabs(dtype, d) > 0, "conv2d: MSAU_CONV_WGRAD / MSAU_CONV_CSUM2 is not implemented for this launch (msau_conv2d_rider_slabs says 0)");
+    if (d->flags & MSAU_CONV_WGRAD)                                            // a rider only the row-streaming coupling instance carries
+        MSAU_CHECK_ARG(msau_conv2d_rider_slabs(dtype, d) > 0, "conv2d: MSAU_CONV_WGRAD is not implemented for this launch (msau_conv2d_rider_slabs says 0)");
     if (d->flags & MSAU_CONV_OWNER) {                                          // ownerconv.hip: box lists instead of a painted input tensor
         MSAU_CHECK_ARG(msau_ownerconv_takes(dtype, d), "conv2d: MSAU_CONV_OWNER is the 3x3 stride-1 C -> 8 conv, no other flag but RELU_OUT");
         return msau_ownerconv_fwd(static_cast<hipStream_t>(stream), dtype, d);
@@ -427,7 +427,7 @@ extern "C" int msau_conv2d(void* stream, int dtype, const msau_conv_desc* d) {
                                   "msau_conv2d_launch_info info[7]); run msau_softmax_argmax_nhwc on y instead");
     }
     if (d->flags & MSAU_CONV_DOUT) {
-        const int okf = MSAU_CONV_DOUT | MSAU_CONV_ADD | MSAU_CONV_ACCUM | MSAU_CONV_MASK_B | MSAU_CONV_WGRAD | MSAU_CONV_CSUM2;   // (riders: checked above)
+        const int okf = MSAU_CONV_DOUT | MSAU_CONV_ADD | MSAU_CONV_ACCUM | MSAU_CONV_MASK_B | MSAU_CONV_WGRAD;   // (WGRAD: checked above)
         MSAU_CHECK_ARG(d->y2 && !(d->flags & ~okf) && !(d->flags2 & ~(MSAU_CONV_ACCUM | MSAU_CONV_MASK_B)) &&
                        (!(d->flags2 & MSAU_CONV_MASK_B) || d->mask_b2), "conv2d: bad DOUT arguments");
         if (!msau_conv_lean_dout_capable(dtype, d, g.nchunks, g.CT) && !(g.nslices == 1 && msau_rowconv_takes(dtype, d)))

@@ -900,15 +900,11 @@ struct RowConvArgs {
 // msau_wgrad_reduce expects for wgrad_lean<C8, CO8, K1>, whose launch (66 MB at the bench size) disappears.
 constexpr int WGC_ROW = 32 * 16;                  // a staged row: 32 pixels x 8 bf16
 
-// CS2 (MSAU_CONV_CSUM2, the 3x3 two-output instances = the data gradient of the decoder's merge conv): per-workgroup channel sums of
-// the stored second output (the gradient of the transposed conv's output: its bias gradient).  A lane adds up its 4 channels over
-// the rows it stores; at the end the 32 lanes of a channel quad and the four waves meet in LDS in a fixed order.
-template <int NS, int KH, int KW, int EPI, int EPI2 = 0, bool WG = false, bool CS2 = false>
+template <int NS, int KH, int KW, int EPI, int EPI2 = 0, bool WG = false>
 __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
     constexpr bool DOUT = (EPI & MSAU_CONV_DOUT) != 0;                     // two outputs (stored weight rows 0..7 -> y, 8..15 -> y2)
     static_assert(!WG || (DOUT && KW == 1 && NS == 1 && EPI == MSAU_CONV_DOUT && EPI2 == MSAU_CONV_MASK_B), "the rider belongs to the coupling conv's data gradient");
-    static_assert(!CS2 || (DOUT && KW == 3 && !WG), "the channel sums belong to the merge conv's data gradient");
-    __shared__ __align__(16) unsigned char wsm[WG ? 4 * 3 * WGC_ROW + 64 + 2 * 8 * 16 * 4 : CS2 ? 256 * 16 : 16];
+    __shared__ __align__(16) unsigned char wsm[WG ? 4 * 3 * WGC_ROW + 64 + 2 * 8 * 16 * 4 : 16];
     constexpr bool K1D = KW == 1 && NS == 2;                               // 1x1 over concat(x1, x2)
     static_assert((KW == 3 && (NS == 1 || NS == 2)) || (K1D && KH == 1) || (KW == 1 && NS == 1 && KH == 1 && DOUT) || (KW == 4 && NS == 1),
                   "instances: 3x3, 1x1 dual, 1x1 two-output, 4x4");
@@ -929,9 +925,8 @@ __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
     const int tloc = (blockIdx.x >> 3) * 4 + wave;
     const int task = (blockIdx.x & 7) * a.tasks_per_xcd + tloc;
     const bool live = tloc < a.tasks_per_xcd && task < a.ntasks;          // wave-uniform
-    if constexpr (!WG && !CS2) { if (!live) return; }                     // (WG / CS2: idle waves wait at the workgroup's reduction)
+    if constexpr (!WG) { if (!live) return; }                             // (WG: idle waves wait at the slab reduction)
     f32x4 wacc = {0.f, 0.f, 0.f, 0.f}, waccb = {0.f, 0.f, 0.f, 0.f};
-    f32x4 cs2 = {0.f, 0.f, 0.f, 0.f};
     if (live) {
     const int t1 = task / a.nstrips, strip = task - t1 * a.nstrips;
     const int b = t1 / a.nseg, seg = t1 - b * a.nseg;
@@ -1088,12 +1083,6 @@ __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
             }
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o1), ry, oo, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o2), ry2, oo, 0, 0);
-            if constexpr (CS2) {
-                if (!(oo & kOOB)) {                                        // (what is stored, as stored: msau_channel_sum read the tensor)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) cs2[jj] += (float)o2[jj];
-                }
-            }
             if constexpr (WG) {
                 // rows of g, prev, y of output row t -> LDS as [pixel][8 channels] (rows outside [y0, y1) were loaded as zeros)
                 if (lg < 2) {
@@ -1192,20 +1181,6 @@ __global__ __launch_bounds__(256) void rowconv8_kernel(const RowConvArgs a) {
         }
         float* out = a.d.wg_slabs + (size_t)blockIdx.x * (2 * 8 * 16);
         for (int i = threadIdx.x; i < 2 * 8 * 16; i += 256) out[i] = slab[i];
-    }
-    if constexpr (CS2) {
-        // lane (lr, lg) holds channels 4 (lg & 1) .. + 3: thread c < 8 adds up the 128 lanes of its quad in thread order
-        f32x4* all = reinterpret_cast<f32x4*>(wsm);
-        all[threadIdx.x] = cs2;
-        __syncthreads();
-        if (threadIdx.x < 8) {
-            const int h = threadIdx.x >> 2, jj = threadIdx.x & 3;
-            float t = 0.f;
-            for (int w = 0; w < 4; ++w)
-                for (int g2 = 0; g2 < 2; ++g2)
-                    for (int r = 0; r < 16; ++r) t += all[w * 64 + (2 * g2 + h) * 16 + r][jj];
-            a.d.csum2[(size_t)blockIdx.x * 8 + threadIdx.x] = t;
-        }
     }
 }
 
@@ -1455,7 +1430,7 @@ constexpr int kFwd1 = MSAU_PAIR_RELU_IN | MSAU_PAIR_RELU_MID, kFwd2 = MSAU_CONV_
 constexpr int kBwd1 = MSAU_PAIR_MASK_MID, kBwd2 = MSAU_CONV_MASK_A | MSAU_CONV_ADD;
 
 // environment switches of this file, read once; msau_reload_env() makes the next call read them again (tests, A/B tools)
-struct RowsEnv { int on, sh, sh16, waves, min_tasks, maxc, conv, wgrad, wgrad4, dout, pairwg, couple, deconv, cplwg, csum2; };
+struct RowsEnv { int on, sh, sh16, waves, min_tasks, maxc, conv, wgrad, wgrad4, dout, pairwg, couple, deconv, cplwg; };
 RowsEnv g_env;
 bool g_env_ok = false;
 const RowsEnv& rows_env() {
@@ -1470,7 +1445,6 @@ const RowsEnv& rows_env() {
         g_env.wgrad4 = geti("MSAU_WGRAD_ROWS4", 0);              // ... and the 4x4 end conv's: correct (tests), but 13 us per step SLOWER than the tile kernel beside the main stream: off
         g_env.conv = geti("MSAU_CONV_ROWS", 1);                  // single convolutions of the 8-channel level on the row kernels
         g_env.pairwg = geti("MSAU_PAIR_WGRAD", 1);               // the first conv's weight gradient inside the pair's data-gradient launch
-        g_env.csum2 = geti("MSAU_MERGE_CSUM", 1);                // the transposed conv's bias gradient as partial sums of the merge conv's data-gradient launch
         g_env.cplwg = geti("MSAU_COUPLE_WGRAD", 1);              // the coupling conv's weight gradient inside its data-gradient launch
         g_env.deconv = geti("MSAU_DECONV_ROWS", 1);              // the 16 -> 8 transposed conv on the row kernel (live taps only)
         g_env.couple = geti("MSAU_PAIR_COUPLE", 1);              // the coupling 1x1 conv inside the pair's forward launch
@@ -1617,13 +1591,7 @@ int rowconv_case(int dtype, const msau_conv_desc* d) {
         if (!e.dout || dual || !d->y2) return 0;
         // the flag sets the reference's nets produce (anything else: the tile kernel's run-time epilogue)
         const int f1 = f & ~MSAU_CONV_DOUT, f2 = d->flags2;
-        if (k == 3 && d->pad_t == 1 && d->pad_l == 1 && f2 == 0) {
-            if (f1 & MSAU_CONV_CSUM2) {
-                if (!d->csum2 || !e.csum2) return 0;
-                return (f1 & ~MSAU_CONV_CSUM2) == 0 ? 14 : (f1 & ~MSAU_CONV_CSUM2) == MSAU_CONV_ACCUM ? 15 : 0;
-            }
-            return f1 == 0 ? 9 : f1 == MSAU_CONV_ACCUM ? 10 : 0;
-        }
+        if (k == 3 && d->pad_t == 1 && d->pad_l == 1 && f2 == 0) return f1 == 0 ? 9 : f1 == MSAU_CONV_ACCUM ? 10 : 0;
         if (k == 1 && d->pad_t == 0 && d->pad_l == 0 && f1 == 0 && f2 == MSAU_CONV_MASK_B && d->mask_b2) return 11;
         if (k == 1 && d->pad_t == 0 && d->pad_l == 0 && f1 == MSAU_CONV_WGRAD && f2 == MSAU_CONV_MASK_B && d->mask_b2 && d->wg_x1 && d->wg_slabs && e.cplwg) return 13;
         return 0;
@@ -1666,9 +1634,7 @@ void rowconv_split(const msau_conv_desc* d, RowConvArgs& a) {
 
 // slabs (= workgroups) of an MSAU_CONV_WGRAD launch of this descriptor; 0 if no instance takes the flag
 extern "C" int msau_conv2d_rider_slabs(int dtype, const msau_conv_desc* d) {
-    if (!d || !(d->flags & (MSAU_CONV_WGRAD | MSAU_CONV_CSUM2))) return 0;
-    const int which = rowconv_case(dtype, d);
-    if (which != 13 && which != 14 && which != 15) return 0;
+    if (!d || !(d->flags & MSAU_CONV_WGRAD) || rowconv_case(dtype, d) != 13) return 0;
     RowConvArgs a;
     rowconv_split(d, a);
     return 8 * (a.tasks_per_xcd / 4);
@@ -1717,13 +1683,6 @@ int msau_rowconv_launch(hipStream_t s, int dtype, const msau_conv_desc* d, int k
         case 9: return launch_rowconv8<1, 3, 3, MSAU_CONV_DOUT>(s, a);
         case 10: return launch_rowconv8<1, 3, 3, MSAU_CONV_DOUT | MSAU_CONV_ACCUM>(s, a);
         case 11: return launch_rowconv8<1, 1, 1, MSAU_CONV_DOUT, MSAU_CONV_MASK_B>(s, a);
-        case 14: case 15:
-            MSAU_CHECK_ARG(8 * (a.tasks_per_xcd / 4) == d->wg_nslabs, "conv2d: MSAU_CONV_CSUM2 launch has %d workgroups, the caller allocated %d partial rows",
-                           8 * (a.tasks_per_xcd / 4), d->wg_nslabs);
-            if (which == 14) hipLaunchKernelGGL((rowconv8_kernel<1, 3, 3, MSAU_CONV_DOUT, 0, false, true>), dim3(8 * (a.tasks_per_xcd / 4)), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((rowconv8_kernel<1, 3, 3, MSAU_CONV_DOUT | MSAU_CONV_ACCUM, 0, false, true>), dim3(8 * (a.tasks_per_xcd / 4)), dim3(256), 0, s, a);
-            MSAU_CHECK_LAUNCH("rowconv8_kernel");
-            return 0;
         case 13:
             MSAU_CHECK_ARG(8 * (a.tasks_per_xcd / 4) == d->wg_nslabs, "conv2d: MSAU_CONV_WGRAD launch has %d workgroups, the caller allocated %d slabs "
                            "(msau_conv2d_rider_slabs under other MSAU_ROWS_* settings?)", 8 * (a.tasks_per_xcd / 4), d->wg_nslabs);

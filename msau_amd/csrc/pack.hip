@@ -176,21 +176,33 @@ __global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ s
         }
     }
     if (e.b_off >= 0 && !conv_bias) {
-        // bias gradient from msau_channel_sum partials (transposed conv): [b_nslabs][b_slab_stride], element stride 1
-        const int col = threadIdx.x & 63, s4 = threadIdx.x >> 6;
-        const int bgroups = (e.b_count + 63) / 64;
+        // bias gradient from channel-sum partials (transposed conv): [b_nslabs][b_slab_stride], element stride 1.  A column (= bias
+        // element) is summed by 256 / ncol threads with four independent loads in flight each, then in a fixed order.  (Rounds 1-4 gave a
+        // column 4 threads and one dependent 4-byte load per iteration: 64 L2 round trips in a row -- for the level-0 / level-1 layers'
+        // 256 partials that serial chain, not the 70 MB of slabs, was the duration of the whole reduction launch: 44 us.)
+        const int ncol = e.b_count <= 16 ? 16 : 64, nrow = 256 / ncol;
+        const int col = threadIdx.x % ncol, row = threadIdx.x / ncol;
+        const int bgroups = (e.b_count + ncol - 1) / ncol;
         for (int grp = blockIdx.x; grp < bgroups; grp += gridDim.x) {
-            const int r = grp * 64 + col;
-            float a = 0.f;
+            const int r = grp * ncol + col;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
             if (r < e.b_count) {
                 const float* p = slabs + e.b_src_off + (int64_t)r * e.b_elem_stride;
-                for (int s = s4; s < e.b_nslabs; s += 4) a += p[(int64_t)s * e.b_slab_stride];
+                int s = row;
+                for (; s + 3 * nrow < e.b_nslabs; s += 4 * nrow) {
+                    a0 += p[(int64_t)s * e.b_slab_stride];
+                    a1 += p[(int64_t)(s + nrow) * e.b_slab_stride];
+                    a2 += p[(int64_t)(s + 2 * nrow) * e.b_slab_stride];
+                    a3 += p[(int64_t)(s + 3 * nrow) * e.b_slab_stride];
+                }
+                for (; s < e.b_nslabs; s += nrow) a0 += p[(int64_t)s * e.b_slab_stride];
             }
             __syncthreads();
-            red[s4][col] = a;
+            red[row][col] = (a0 + a1) + (a2 + a3);
             __syncthreads();
-            if (s4 == 0 && r < e.b_count) {
-                const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+            if (row == 0 && r < e.b_count) {
+                float t = 0.f;
+                for (int i = 0; i < nrow; ++i) t += red[i][col];
                 float* dst = grads + e.b_off + r;
                 *dst = e.accumulate ? *dst + t : t;
             }

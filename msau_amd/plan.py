@@ -391,24 +391,6 @@ class ConvOp(Op):
             else:
                 dd.flags &= ~L.CONV_WGRAD
                 dd.wg_x1 = dd.wg_slabs = None
-        # the decoder's merge conv: the second output of its two-output data gradient is the gradient of the transposed conv's output,
-        # whose sum over the pixels is that layer's bias gradient -- per-workgroup partial sums ride on the launch (MSAU_CONV_CSUM2)
-        dc = next((op for op in P.ops if isinstance(op, ConvOp) and op.kind == "deconv" and op.out is x2), None) if x2 is not None else None
-        if conv and self.k == 3 and dd is not None and self.dd_off is not None and dc is not None and dc.uentry is not None \
-                and not (dd.flags & ~(L.CONV_DOUT | L.CONV_ACCUM)) and dd.flags2 == 0 and x2.Cs == 8 \
-                and os.environ.get("MSAU_MERGE_CSUM", "1") != "0" and P.cfg.get("merge_csum", True):
-            dd.flags |= L.CONV_CSUM2
-            dd.csum2 = 1                                             # (placeholder)
-            ns = int(L.load().msau_conv2d_rider_slabs(P.dtype, C.byref(dd)))
-            if ns > 0:
-                dd.wg_nslabs = ns
-                self.csum2_off = P.alloc_slab(ns * 8)
-                du = dc.uentry
-                du.b_src_off, du.b_slab_stride, du.b_elem_stride, du.b_nslabs = self.csum2_off, 8, 1, ns
-                dc.csum_fused = True
-            else:
-                dd.flags &= ~L.CONV_CSUM2
-                dd.csum2 = None
 
     def late_bind(self):
         P = self.plan
@@ -416,8 +398,6 @@ class ConvOp(Op):
             self.wdesc.slabs = P.slab_ptr(self.slab_off)
         if self.wg_fused and self.pair is None and self.ddesc[0] is not None and self.ddesc[0].flags & L.CONV_WGRAD:
             self.ddesc[0].wg_slabs = P.slab_ptr(self.wg_slab_off)
-        if self.ddesc[0] is not None and self.ddesc[0].flags & L.CONV_CSUM2:
-            self.ddesc[0].csum2 = P.slab_ptr(self.csum2_off)
         # ---- launch metadata for profiling / roofline accounting (bench.py)
         T = "f32" if P.dtype == L.F32 else "bf16"
         esz = 4 if P.dtype == L.F32 else 2
@@ -477,7 +457,7 @@ class ConvOp(Op):
                 + w.nslabs * wg.slab_bytes
             if not self.wg_fused:
                 P.note_launch(self.wkey, self.wbytes, self.flops)
-            if self.kind != "conv" and not getattr(self, "csum_fused", False):   # bias gradient of the transposed conv: one pass over its output gradient
+            if self.kind != "conv":                      # bias gradient of the transposed conv: one pass over its output gradient
                 P.note_launch("msau_channel_sum", self.out.npix * self.out.Cs * esz, 0.0)
 
     def fwd(self, s):
@@ -509,7 +489,7 @@ class ConvOp(Op):
             side = 0        # the net's first conv has no data gradient: nothing is left on the main stream to run beside,
                             # and the side stream is still busy with the two weight gradients enqueued before this one
         recs = [] if self.wg_fused else [(L.OP_WGRAD | side, self.wdesc)]
-        if self.kind != "conv" and not getattr(self, "csum_fused", False):
+        if self.kind != "conv":
             P = self.plan
             self._csum = L.CsumArgs(_ptr(self.out.grad), self.out.npix, self.out.Cs, P.slab_ptr(self.csum_off), self.csum_blocks)
             recs.append((L.OP_CHANNEL_SUM | side, self._csum))
@@ -533,7 +513,7 @@ class ConvOp(Op):
             return
         P = self.plan
         L.call("msau_conv2d_wgrad", s, P.dtype, C.byref(self.wdesc), key=self.wkey)
-        if self.kind != "conv" and not getattr(self, "csum_fused", False):
+        if self.kind != "conv":
             L.call("msau_channel_sum", s, P.dtype, _ptr(self.out.grad), self.out.npix, self.out.Cs,
                    P.slab_ptr(self.csum_off), self.csum_blocks)
 
