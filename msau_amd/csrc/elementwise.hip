@@ -376,9 +376,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx,
                                                        const T* __restrict__ mask, int orows, int H, int W, int Ho, int Wo, int Cs, int accumulate) {
     const int cgs = Cs >> 3;
-    const int orow = blockIdx.y + 65535 * blockIdx.z;                // b * Ho + oy
-    const int t = blockIdx.x * 256 + threadIdx.x;                    // ox * cgs + cg
-    if (orow >= orows || t >= Wo * cgs) return;
+    // flat index over (pooled row, pooled x, channel group): every thread of every workgroup but the last has a window (with one
+    // pooled ROW per workgroup half of the 256 threads had none at the net's sizes: Wo * cgs = 128); 32-bit divisions only
+    const unsigned wc = (unsigned)(Wo * cgs);
+    const unsigned flat = blockIdx.x * 256u + threadIdx.x;
+    const int orow = (int)(flat / wc);                               // b * Ho + oy
+    const int t = (int)(flat - (unsigned)orow * wc);                 // ox * cgs + cg
+    if (orow >= orows) return;
     const int b = orow / Ho, oy = orow - b * Ho;
     const int ox = t / cgs, cg = t - ox * cgs;
     const int64_t o = ((int64_t)orow * Wo * cgs + t) * 8;
@@ -913,9 +917,9 @@ extern "C" int msau_maxpool2x2_bwd(void* stream, int dtype, const void* dy, cons
     MSAU_CHECK_ARG(dy && dx && idx && B > 0 && H > 0 && W > 0 && Cs % 8 == 0, "maxpool_bwd: bad args");
     hipStream_t s = static_cast<hipStream_t>(stream);
     int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    MSAU_CHECK_ARG((int64_t)B * H < 65535ll * 65535ll && (int64_t)W * (Cs / 8) < (1ll << 30), "maxpool_bwd: image too large");
+    MSAU_CHECK_ARG((int64_t)B * Ho * Wo * (Cs / 8) < (1ll << 31) - 256, "maxpool_bwd: image too large");
     const int rows = B * Ho;                                         // pooled rows: a thread owns a 2x2 window
-    const dim3 grid(cdiv(Wo * (Cs / 8), 256), rows < 65535 ? rows : 65535, cdiv(rows, 65535));
+    const dim3 grid((unsigned)(((int64_t)rows * Wo * (Cs / 8) + 255) / 256));
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(pool_bwd_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(dy), idx, static_cast<float*>(dx), static_cast<const float*>(mask), rows, H, W, Ho, Wo, Cs, accumulate),
                hipLaunchKernelGGL(pool_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, static_cast<const bf16_t*>(dy), idx, static_cast<bf16_t*>(dx), static_cast<const bf16_t*>(mask), rows, H, W, Ho, Wo, Cs, accumulate));
