@@ -1272,6 +1272,89 @@ __global__ __launch_bounds__(256) void rowdeconv8_kernel(const RowDeconvArgs a) 
     }
 }
 
+// The level-2 -> level-1 transposed conv, 32 -> 16 channels, the same way: rows = 16 output channels, columns = 16 input columns,
+// K = 32 input channels = one k-step per live (tap row, tap column).  Even / odd output columns need different weights, so they are two
+// accumulators (X = 2x: kx 1 on in[x]; X = 2x + 1: kx 0 on in[x] and kx 2 on in[x + 1]): 3 MFMAs for an even output row, 6 for an odd one,
+// on two 16-byte loads per lane and INPUT row (pixels x and x + 1, channel group lg).  A result lane holds 4 channels of output
+// pixels 2x and 2x + 1 of a row: two 8-byte stores.
+__global__ __launch_bounds__(256) void rowdeconv16_kernel(const RowDeconvArgs a) {
+    const msau_conv_desc& d = a.d;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tloc = (blockIdx.x >> 3) * 4 + wave;
+    const int task = (blockIdx.x & 7) * a.tasks_per_xcd + tloc;
+    if (tloc >= a.tasks_per_xcd || task >= a.ntasks) return;
+    const int t1 = task / a.nstrips, strip = task - t1 * a.nstrips;
+    const int b = t1 / a.nseg, seg = t1 - b * a.nseg;
+    const int Hin = d.Hin, Win = d.Win, Hout = d.Hout, Wout = d.Wout;
+    const int xh0 = strip * 16;
+    const int Y0 = seg * a.SH, Y1 = min(Hout, Y0 + a.SH);
+    const int lr = lane & 15, lg = lane >> 4;
+
+    bf16x8 A[3][3];
+    {
+        const bf16_t* w = static_cast<const bf16_t*>(d.wpack) + lr * 288 + lg * 8;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) A[ky][kx] = load8<bf16_t>(w + (ky * 3 + kx) * 32);
+    }
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (d.bias) bias = *reinterpret_cast<const f32x4*>(d.bias + lg * 4);
+
+    const __amdgpu_buffer_rsrc_t rx = rsrc_of(static_cast<const char*>(d.x1) + (long long)b * a.in_img_bytes, a.in_img_bytes);
+    const __amdgpu_buffer_rsrc_t ry = rsrc_of(static_cast<char*>(d.y) + (long long)b * a.out_img_bytes, a.out_img_bytes);
+    const int xi = xh0 + lr;
+    const unsigned lcol0 = xi < Win ? (unsigned)(xi * 64 + lg * 16) : kOOB;
+    const unsigned lcol1 = xi + 1 < Win ? (unsigned)((xi + 1) * 64 + lg * 16) : kOOB;             // (beyond the image: the stuffed zeros)
+    const int ylast = min(Hin - 1, Y1 >> 1);
+    auto load_row = [&](int r, u32x4& x0, u32x4& x1) {
+        const unsigned ro = r <= ylast ? (unsigned)(r * a.in_row_bytes) : kOOB;
+        x0 = __builtin_amdgcn_raw_buffer_load_b128(rx, r <= ylast ? ro + lcol0 : kOOB, 0, 0);
+        x1 = __builtin_amdgcn_raw_buffer_load_b128(rx, r <= ylast ? ro + lcol1 : kOOB, 0, 0);
+    };
+    const unsigned oc0 = 2 * xi < Wout ? (unsigned)(2 * xi * 32 + lg * 8) : kOOB;
+    const unsigned oc1 = 2 * xi + 1 < Wout ? (unsigned)((2 * xi + 1) * 32 + lg * 8) : kOOB;
+    auto store_px = [&](int Y, const f32x4& acc, unsigned oc) {
+        bf16x4 o;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) o[jj] = (bf16_t)acc[jj];
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ry, Y < Y1 ? (unsigned)(Y * a.out_row_bytes) + oc : kOOB, 0, 0);
+    };
+
+    u32x4 X0[4], X1[4];
+    const int yh0 = Y0 >> 1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) load_row(yh0 + k, X0[k], X1[k]);
+    auto step = [&](auto ic, const int yg) {
+        constexpr int I = decltype(ic)::value;
+        const int y = yg + I;
+        load_row(y + 3, X0[(I + 3) % 4], X1[(I + 3) % 4]);
+        const bf16x8 c0 = __builtin_bit_cast(bf16x8, X0[I % 4]), c1 = __builtin_bit_cast(bf16x8, X1[I % 4]);
+        const bf16x8 n0 = __builtin_bit_cast(bf16x8, X0[(I + 1) % 4]), n1 = __builtin_bit_cast(bf16x8, X1[(I + 1) % 4]);
+        f32x4 e0 = mma8(A[1][1], c0, bias);                                                    // (2y, 2x)
+        f32x4 e1 = mma8(A[1][0], c0, bias);                                                    // (2y, 2x + 1)
+        e1 = mma8(A[1][2], c1, e1);
+        f32x4 o0 = mma8(A[0][1], c0, bias);                                                    // (2y + 1, 2x)
+        o0 = mma8(A[2][1], n0, o0);
+        f32x4 o1 = mma8(A[0][0], c0, bias);                                                    // (2y + 1, 2x + 1)
+        o1 = mma8(A[0][2], c1, o1);
+        o1 = mma8(A[2][0], n0, o1);
+        o1 = mma8(A[2][2], n1, o1);
+        store_px(2 * y, e0, oc0);
+        store_px(2 * y, e1, oc1);
+        store_px(2 * y + 1, o0, oc0);
+        store_px(2 * y + 1, o1, oc1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int yg = yh0; 2 * yg < Y1; yg += 4) {
+        step(IC<0>{}, yg);
+        step(IC<1>{}, yg);
+        step(IC<2>{}, yg);
+        step(IC<3>{}, yg);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // Weight gradient of the 8 -> 8 3x3 convs in the same form (msau_conv2d_wgrad descriptors; dispatched from conv_wgrad.hip).
 // The tile kernel re-reads tile halos (PMC, profiles/r03_traffic.json: x1.49 the algorithmic bytes); here a wave walks a
@@ -1446,7 +1529,7 @@ const RowsEnv& rows_env() {
         g_env.conv = geti("MSAU_CONV_ROWS", 1);                  // single convolutions of the 8-channel level on the row kernels
         g_env.pairwg = geti("MSAU_PAIR_WGRAD", 1);               // the first conv's weight gradient inside the pair's data-gradient launch
         g_env.cplwg = geti("MSAU_COUPLE_WGRAD", 1);              // the coupling conv's weight gradient inside its data-gradient launch
-        g_env.deconv = geti("MSAU_DECONV_ROWS", 1);              // the 16 -> 8 transposed conv on the row kernel (live taps only)
+        g_env.deconv = geti("MSAU_DECONV_ROWS", 2);              // transposed convs from their live taps on the row kernels: 1 = 16 -> 8, 2 = also 32 -> 16
         g_env.couple = geti("MSAU_PAIR_COUPLE", 1);              // the coupling 1x1 conv inside the pair's forward launch
         g_env.dout = geti("MSAU_DOUT_ROWS", 1);                  // the two-output data gradients (8 -> 8 + 8, 3x3 and 1x1) on the row kernels
         g_env.maxc = geti("MSAU_ROWS_MAXC", 16);                 // widest layer the row kernels take (8: the 16-channel pairs stay on the tile kernels)
@@ -1573,13 +1656,14 @@ int launch_rowconv8(hipStream_t s, const RowConvArgs& a) {
 int rowconv_case(int dtype, const msau_conv_desc* d) {
     const RowsEnv& e = rows_env();
     if (!e.on || !e.conv || dtype != MSAU_BF16) return 0;
-    if (d->ups == 2) {                                                     // the 16 -> 8 transposed conv (rowdeconv8_kernel)
-        if (!e.deconv || d->C1 != 16 || d->C2 != 0 || d->Cout != 8 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->dil != 1 || d->flags) return 0;
+    if (d->ups == 2) {                                                     // the 16 -> 8 / 32 -> 16 transposed convs (rowdeconv8 / rowdeconv16)
+        const bool c16 = d->C1 == 16 && d->Cout == 8, c32 = d->C1 == 32 && d->Cout == 16 && e.deconv >= 2;
+        if (!e.deconv || !(c16 || c32) || d->C2 != 0 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->dil != 1 || d->flags) return 0;
         if (d->pad_t != 1 || d->pad_l != 1) return 0;
         if ((d->Hout != 2 * d->Hin && d->Hout != 2 * d->Hin - 1) || (d->Wout != 2 * d->Win && d->Wout != 2 * d->Win - 1)) return 0;
-        if ((int64_t)d->Hout * d->Wout * 16 >= (1ll << 31)) return 0;
+        if ((int64_t)d->Hout * d->Wout * d->Cout * 2 >= (1ll << 31)) return 0;
         if ((int64_t)d->B * cdiv(d->Win, 16) * cdiv(d->Hout, 8) < e.min_tasks) return 0;
-        return 12;
+        return c16 ? 12 : 16;
     }
     const bool dout = d->flags & MSAU_CONV_DOUT;
     if (d->Cout != (dout ? 16 : 8) || d->C1 != 8 || (d->C2 != 0 && d->C2 != 8) || d->stride != 1 || d->ups != 1 || d->dil != 1) return 0;
@@ -1642,8 +1726,8 @@ extern "C" int msau_conv2d_rider_slabs(int dtype, const msau_conv_desc* d) {
 
 int msau_rowconv_launch(hipStream_t s, int dtype, const msau_conv_desc* d, int kchunk, int rows) {
     const int which = rowconv_case(dtype, d);
-    if (which == 12) {
-        MSAU_CHECK_ARG(kchunk == 160 && rows == 16, "rowdeconv: packed image of another geometry (kchunk %d, rows %d)", kchunk, rows);
+    if (which == 12 || which == 16) {
+        MSAU_CHECK_ARG(kchunk == (which == 12 ? 160 : 288) && rows == 16, "rowdeconv: packed image of another geometry (kchunk %d, rows %d)", kchunk, rows);
         RowDeconvArgs a;
         a.d = *d;
         a.nstrips = cdiv(d->Win, 16);
@@ -1656,12 +1740,13 @@ int msau_rowconv_launch(hipStream_t s, int dtype, const msau_conv_desc* d, int k
         a.nseg = cdiv(d->Hout, a.SH);
         a.ntasks = d->B * a.nstrips * a.nseg;
         a.tasks_per_xcd = roundup(cdiv(a.ntasks, 8), 4);
-        a.in_row_bytes = d->Win * 32;
-        a.out_row_bytes = d->Wout * 16;
+        a.in_row_bytes = d->Win * d->C1 * 2;
+        a.out_row_bytes = d->Wout * d->Cout * 2;
         a.in_img_bytes = (unsigned)d->Hin * (unsigned)a.in_row_bytes;
         a.out_img_bytes = (unsigned)d->Hout * (unsigned)a.out_row_bytes;
-        hipLaunchKernelGGL(rowdeconv8_kernel, dim3(8 * (a.tasks_per_xcd / 4)), dim3(256), 0, s, a);
-        MSAU_CHECK_LAUNCH("rowdeconv8_kernel");
+        if (which == 12) hipLaunchKernelGGL(rowdeconv8_kernel, dim3(8 * (a.tasks_per_xcd / 4)), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(rowdeconv16_kernel, dim3(8 * (a.tasks_per_xcd / 4)), dim3(256), 0, s, a);
+        MSAU_CHECK_LAUNCH("rowdeconv_kernel");
         return 0;
     }
     RowConvArgs a;

@@ -734,9 +734,11 @@ def test_coupling_conv_in_the_residual_pairs_forward_launch(monkeypatch, c, hw, 
     assert err(res["1"][0], y_r, True) < 3e-2
 
 
+@pytest.mark.parametrize("cin", [16, 32])
 @pytest.mark.parametrize("hw_in,odd,B", [((20, 32), (0, 0), 2), ((21, 19), (1, 1), 3), ((9, 70), (1, 0), 2), ((65, 33), (0, 1), 4), ((168, 128), (0, 0), 2)])
-def test_row_streaming_transposed_conv_matches_the_zero_stuffed_launch_and_torch(monkeypatch, hw_in, odd, B):
-    """rowdeconv8_kernel (conv_rows.hip, round 5): the level-1 -> level-0 transposed conv (16 -> 8 channels, k 3, stride 2, padding 1,
+def test_row_streaming_transposed_conv_matches_the_zero_stuffed_launch_and_torch(monkeypatch, hw_in, odd, B, cin):
+    """rowdeconv8_kernel / rowdeconv16_kernel (conv_rows.hip, round 5): the level-1 -> level-0 and level-2 -> level-1 transposed convs
+    (16 -> 8 and 32 -> 16 channels, k 3, stride 2, padding 1,
     output_size even or odd per axis: model/model.py:230, model/layers/layers.py:249-250) computed from the live taps only, against the
     tile kernel's conv over the zero-stuffed input (MSAU_DECONV_ROWS=0: same packed image, other summation order) and against
     torch.nn.functional.conv_transpose2d on the rounded operands; the backward (strided data gradient, weight gradient) is untouched
@@ -744,20 +746,21 @@ def test_row_streaming_transposed_conv_matches_the_zero_stuffed_launch_and_torch
     torch.manual_seed(31)
     Hi, Wi = hw_in
     Ho, Wo = 2 * Hi - odd[0], 2 * Wi - odd[1]
-    x = torch.randn(B, 16, Hi, Wi)
-    p = {"w": 0.2 * torch.randn(16, 8, 3, 3), "b": 0.1 * torch.randn(8)}            # ConvTranspose2d weight: [Cin][Cout][k][k]
-    gy = torch.randn(B, 8, Ho, Wo)
+    cout = cin // 2
+    x = torch.randn(B, cin, Hi, Wi)
+    p = {"w": 0.2 * torch.randn(cin, cout, 3, 3), "b": 0.1 * torch.randn(cout)}     # ConvTranspose2d weight: [Cin][Cout][k][k]
+    gy = torch.randn(B, cout, Ho, Wo)
     seen = []
 
     def build(plan):
-        y = Act(plan, "y", Ho, Wo, 8)
+        y = Act(plan, "y", Ho, Wo, cout)
         seen.append(ConvOp(plan, "dc", plan.x_in, None, "w", "b", y, 3, kind="deconv"))
         plan.logits = y
     monkeypatch.setenv("MSAU_ROWS_MIN_TASKS", "1")
     res = {}
     try:
         for mode in ("1", "0"):
-            monkeypatch.setenv("MSAU_DECONV_ROWS", mode)
+            monkeypatch.setenv("MSAU_DECONV_ROWS", "2" if mode == "1" else "0")
             L.load().msau_reload_env()
             res[mode] = run_graph(build, p, x, gy, L.BF16)
     finally:
