@@ -568,9 +568,12 @@ constexpr int WAVE_LDS16 = 2 * MP16;
 // 8-channel group lg & 1) -- and the pooled z takes the place of POOL's pooled y (same code, other operands).
 constexpr int CPL_ROW16 = 16 * 32;                // a finished output row in LDS: 16 pixels x 16 bf16
 
-template <bool BWD, bool BITS, bool POOL, int CPL = 0>
+// LRNB (MSAU_PAIR_LRN_BWD at 16 channels, round 5): as in rowpair_c8_kernel, with a pixel's 16 channels in the four lanes lr + 16 lg:
+// window sums = differences of prefix sums whose other half sits in lane ^ 32, lane totals over lane ^ 16 and lane ^ 32.
+template <bool BWD, bool BITS, bool POOL, int CPL = 0, bool LRNB = false>
 __global__ __launch_bounds__(256) void rowpair_c16_kernel(const RowArgs a) {
     static_assert(!(BWD && POOL), "the pooled output belongs to the forward launch");
+    static_assert(!LRNB || BWD, "the LRN backward rides on the data-gradient launch");
     static_assert(!CPL || (!BWD && !POOL), "the coupling conv rides on the forward launch; its pooled output replaces POOL's");
     __shared__ __align__(16) unsigned char smem[4 * WAVE_LDS16 + (CPL ? 4 * CPL_ROW16 : 0)];
     const msau_conv_pair_desc& d = a.d;
@@ -622,6 +625,10 @@ __global__ __launch_bounds__(256) void rowpair_c16_kernel(const RowArgs a) {
     const __amdgpu_buffer_rsrc_t rbm = rsrc_of(BITS ? d.bits_mid + (long long)b * a.plane_img : nullptr, BITS ? a.plane_img : 0u);
     const __amdgpu_buffer_rsrc_t rba = rsrc_of(BITS ? d.bits_a + (long long)b * a.plane_img : nullptr, BITS ? a.plane_img : 0u);
 
+    const __amdgpu_buffer_rsrc_t rla = rsrc_of(LRNB ? static_cast<const char*>(d.lrn_a) + img : nullptr, LRNB ? a.img_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rlda = rsrc_of(LRNB ? static_cast<char*>(d.lrn_da) + img : nullptr, LRNB ? a.img_bytes : 0u);
+    const bool b075 = d.lrn_beta == 0.75f;
+    u32x2 AL[3] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};                         // LRNB: a(t, x0 + lr, c0..c0+3) of output row t, two rows ahead
     // input row r in fragment layout (two 16-byte loads per lane); outside the image the offset is out of range -> 0
     const int lxa = x0 - 2 + lr + (lg >> 1), lxb = x0 - 2 + lr + 2;
     const unsigned lcol_a = (unsigned)lxa < (unsigned)W ? (unsigned)(lxa * 32 + (lg & 1) * 16) : kOOB;
@@ -725,6 +732,10 @@ __global__ __launch_bounds__(256) void rowpair_c16_kernel(const RowArgs a) {
         constexpr int I = decltype(ic)::value, P = I & 1;
         const int t = tg + I, m = t + 1;
         load_row(t + 5, XA[(I + 5) % 6], XB[(I + 5) % 6]);
+        if constexpr (LRNB) {
+            const int ta = t + 2;
+            AL[(I + 2) % 3] = __builtin_amdgcn_raw_buffer_load_b64(rla, (ta >= y0 && ta < y1) ? (unsigned)(ta * a.row_bytes) + out_col : kOOB, 0, 0);
+        }
         first_use(XA[(I + 2) % 6], XB[(I + 2) % 6], RS[(I + 2) % 3]);
         const bool rowin = (unsigned)m < (unsigned)H;
         // ================= phase 1: intermediate row m =================
@@ -785,6 +796,46 @@ __global__ __launch_bounds__(256) void rowpair_c16_kernel(const RowArgs a) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) o[jj] = (bf16_t)v[jj];
             const bool ownrow = t >= y0 && t < y1;
+            if constexpr (LRNB) {
+                // da = dy d^-beta - 2 beta alpha/n a * sum over the adjoint window [c - 7, c + 8] of dy a d^(-beta-1), d = k + alpha/n * sum over
+                // [c - 8, c + 7] of a^2 (layers.py:145,161-162; size 16): this lane holds channels 4 lg .. 4 lg + 3 of its pixel
+                const bf16x4 av = __builtin_bit_cast(bf16x4, AL[I % 3]);
+                const int h = lg >> 1;
+                auto x16 = [](float f) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, f), 0x401F)); };            // lane ^ 16
+                const int nb32 = (lane ^ 32) * 4;
+                auto x32 = [&](float f) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(nb32, __builtin_bit_cast(int, f))); };   // lane ^ 32
+                float xa[4], gg[4], Pf[4], run = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) { xa[jj] = (float)av[jj]; gg[jj] = (float)o[jj]; run += xa[jj] * xa[jj]; Pf[jj] = run; }
+                const float t1 = x16(run), pr = run + t1, t2 = x32(pr);
+                const float tot = pr + t2;
+                const float E = ((lg & 1) ? t1 : 0.f) + (h ? t2 : 0.f);          // channels below this lane's
+                float dnb[4], Q[4], runq = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float Xe = E + (jj ? Pf[jj - 1] : 0.f);                 // exclusive prefix at channel 4 lg + jj
+                    const float Xo = x32(Xe);                                     // ... at channel (4 lg + jj) +- 8
+                    const float win = h ? tot - Xo : Xo;
+                    const float dd = d.lrn_k + d.lrn_alpha_over_n * win;
+                    float invd;
+                    if (b075) { const float rq = __builtin_amdgcn_rsqf(dd); dnb[jj] = rq * __builtin_amdgcn_sqrtf(rq); invd = rq * rq; }
+                    else { dnb[jj] = __expf(-d.lrn_beta * __logf(dd)); invd = __builtin_amdgcn_rcpf(dd); }
+                    runq += gg[jj] * xa[jj] * dnb[jj] * invd;
+                    Q[jj] = runq;
+                }
+                const float q1 = x16(runq), qp = runq + q1, q2 = x32(qp);
+                const float totq = qp + q2;
+                const float Eq = ((lg & 1) ? q1 : 0.f) + (h ? q2 : 0.f);
+                const float c2 = 2.f * d.lrn_beta * d.lrn_alpha_over_n;
+                bf16x4 da;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float Io = x32(Eq + Q[jj]);                             // the inclusive prefix 8 channels away
+                    const float adj = h ? totq - Io : Io;
+                    da[jj] = (bf16_t)(gg[jj] * dnb[jj] - c2 * xa[jj] * adj);
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, da), rlda, ownrow ? (unsigned)(t * a.row_bytes) + out_col : kOOB, 0, 0);
+            } else
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ry, ownrow ? (unsigned)(t * a.row_bytes) + out_col : kOOB, 0, 0);
             if constexpr (!BWD && BITS) {
                 u64 bal[4];
@@ -1513,7 +1564,7 @@ constexpr int kFwd1 = MSAU_PAIR_RELU_IN | MSAU_PAIR_RELU_MID, kFwd2 = MSAU_CONV_
 constexpr int kBwd1 = MSAU_PAIR_MASK_MID, kBwd2 = MSAU_CONV_MASK_A | MSAU_CONV_ADD;
 
 // environment switches of this file, read once; msau_reload_env() makes the next call read them again (tests, A/B tools)
-struct RowsEnv { int on, sh, sh16, waves, min_tasks, maxc, conv, wgrad, wgrad4, dout, pairwg, couple, deconv, cplwg; };
+struct RowsEnv { int on, sh, sh16, waves, min_tasks, maxc, conv, wgrad, wgrad4, dout, pairwg, couple, deconv, cplwg, lrnb16; };
 RowsEnv g_env;
 bool g_env_ok = false;
 const RowsEnv& rows_env() {
@@ -1528,6 +1579,7 @@ const RowsEnv& rows_env() {
         g_env.wgrad4 = geti("MSAU_WGRAD_ROWS4", 0);              // ... and the 4x4 end conv's: correct (tests), but 13 us per step SLOWER than the tile kernel beside the main stream: off
         g_env.conv = geti("MSAU_CONV_ROWS", 1);                  // single convolutions of the 8-channel level on the row kernels
         g_env.pairwg = geti("MSAU_PAIR_WGRAD", 1);               // the first conv's weight gradient inside the pair's data-gradient launch
+        g_env.lrnb16 = geti("MSAU_LRN_BWD16", 1);                // the LRN backward also on the 16-channel pair's data-gradient launch
         g_env.cplwg = geti("MSAU_COUPLE_WGRAD", 1);              // the coupling conv's weight gradient inside its data-gradient launch
         g_env.deconv = geti("MSAU_DECONV_ROWS", 2);              // transposed convs from their live taps on the row kernels: 1 = 16 -> 8, 2 = also 32 -> 16
         g_env.couple = geti("MSAU_PAIR_COUPLE", 1);              // the coupling 1x1 conv inside the pair's forward launch
@@ -1563,7 +1615,7 @@ int msau_rowpair_takes(int dtype, const msau_conv_pair_desc* d) {
     const bool fwd = (d->flags1 & ~MSAU_PAIR_COUPLE) == kFwd1 && (d->flags2 & ~pool_ok) == kFwd2,
                bwd = (d->flags1 & ~(MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1)) == kBwd1 && d->flags2 == kBwd2;
     if (!fwd && !bwd) return 0;
-    if (lrnb && !(bwd && d->C == 8 && d->lrn_a && d->lrn_da && d->lrn_k > 0.f)) return 0;
+    if (lrnb && !(bwd && (d->C == 8 || (d->C == 16 && e.lrnb16)) && d->lrn_a && d->lrn_da && d->lrn_k > 0.f)) return 0;
     if (wg1 && !(bwd && d->C == 8 && d->wg1_x && d->wg1_slabs && e.pairwg)) return 0;
     if (cpl) {
         // the coupling conv rides on the forward launch: its packed image must be the one the kernels index (1x1 over
@@ -1630,7 +1682,8 @@ int msau_rowpair_launch(hipStream_t s, const msau_conv_pair_desc* d) {
         else if (bits) hipLaunchKernelGGL((rowpair_c8_kernel<false, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((rowpair_c8_kernel<false, false>), grid, block, 0, s, a);
     } else {
-        if (bwd) hipLaunchKernelGGL((rowpair_c16_kernel<true, true, false>), grid, block, 0, s, a);
+        if (bwd && (d->flags1 & MSAU_PAIR_LRN_BWD)) hipLaunchKernelGGL((rowpair_c16_kernel<true, true, false, 0, true>), grid, block, 0, s, a);
+        else if (bwd) hipLaunchKernelGGL((rowpair_c16_kernel<true, true, false>), grid, block, 0, s, a);
         else if (cpl == 2 && bits) hipLaunchKernelGGL((rowpair_c16_kernel<false, true, false, 2>), grid, block, 0, s, a);
         else if (cpl == 2) hipLaunchKernelGGL((rowpair_c16_kernel<false, false, false, 2>), grid, block, 0, s, a);
         else if (cpl && bits) hipLaunchKernelGGL((rowpair_c16_kernel<false, true, false, 1>), grid, block, 0, s, a);
