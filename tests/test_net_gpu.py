@@ -506,14 +506,14 @@ def test_lrn_backward_in_the_pair_epilogue_matches_the_standalone_pass(monkeypat
         plan = m._plan_for(x, True)
         lrns = [op for op in plan.ops if isinstance(op, LrnOp)]
         nf = sum(1 for op in lrns if op.bwd_fused_into is not None)
-        assert nf == (3 if fuse == "1" else 0), nf                      # one 8-channel level per stage
-        da = [op.a.grad.float().cpu() for op in lrns if op.a.Cs == 8]
+        assert nf == (6 if fuse == "1" else 0), nf                      # the 8- and (round 5) the 16-channel level of each stage
+        da = [op.a.grad.float().cpu() for op in lrns if op.a.Cs in (8, 16)]
         outs.append((da, eng.flat_grad.float().cpu(), m.flat_parameters.float().cpu(), sum(n for n, _, _ in plan.launch_meta.values())))
     for a, b in zip(outs[0][0], outs[1][0]):
         assert float(b.abs().max()) > 0 and err(a, b, True) < 1e-2
     assert err(outs[0][1], outs[1][1], True) < 2e-2
     assert err(outs[0][2], outs[1][2], True) < 1e-3
-    assert outs[0][3] == outs[1][3] - 3
+    assert outs[0][3] == outs[1][3] - 6
 
 
 @pytest.mark.parametrize("B,channels,H,W", [(4, 64, 112, 96), (3, 13, 75, 91), (2, 8, 45, 150)])
