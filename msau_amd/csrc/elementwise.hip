@@ -703,7 +703,7 @@ __global__ void channel_sum_kernel(const T* __restrict__ g, int64_t npix, int Cs
 // =============================================================================================
 // global-norm clip + Adam (train_chargrid_funsd_msau.py:24-26,58-59)
 // =============================================================================================
-__global__ void sqsum_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partials, float* __restrict__ state) {
+__global__ void sqsum_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partials, float* __restrict__ state, float beta1, float beta2) {
     __shared__ float red[kThreads / 64];
     float s = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -717,7 +717,14 @@ __global__ void sqsum_kernel(const float* __restrict__ g, int64_t n, float* __re
         float t = 0.f;
         for (int i = 0; i < kThreads / 64; ++i) t += red[i];
         partials[blockIdx.x] = t;
-        if (blockIdx.x == 0 && state) state[0] += 1.f;             // the step counter: read by every workgroup of adam_kernel
+        if (blockIdx.x == 0 && state) {
+            // the step counter and Adam's bias corrections, once: every workgroup of adam_kernel reads them (rounds 1-4: each of
+            // its 512 workgroups evaluated two double-precision pow() before touching a parameter)
+            const float step = state[0] + 1.f;
+            state[0] = step;
+            state[3] = (float)(1.0 - pow((double)beta1, (double)step));
+            state[4] = (float)(1.0 - pow((double)beta2, (double)step));
+        }
     }
 }
 
@@ -732,13 +739,12 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         for (int i = threadIdx.x; i < npart; i += 64) s += partials[i];
         for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
         if (threadIdx.x == 0) {
-            const float step = state[0];                              // already advanced by sqsum_kernel
             const float norm = sqrtf(s) * grad_scale;
             const float coef = max_norm / (norm + 1e-6f);               // torch.nn.utils.clip_grad_norm_
             sh[0] = coef < 1.f ? coef : 1.f;
-            sh[1] = (float)(1.0 - pow((double)beta1, (double)step));
-            sh[2] = (float)(1.0 - pow((double)beta2, (double)step));
-            if (blockIdx.x == 0) { state[1] = norm; state[2] = sh[0]; state[3] = sh[1]; state[4] = sh[2]; }
+            sh[1] = state[3];                                            // bias corrections: sqsum_kernel's workgroup 0
+            sh[2] = state[4];
+            if (blockIdx.x == 0) { state[1] = norm; state[2] = sh[0]; }
         }
     }
     __syncthreads();
@@ -1061,9 +1067,12 @@ extern "C" int msau_clip_adam_step(void* stream, float* params, const float* gra
     MSAU_CHECK_ARG(params && grads && m && v && state && ws && n > 0, "clip_adam: bad args");
     hipStream_t s = static_cast<hipStream_t>(stream);
     int nb = adam_blocks(n);
-    hipLaunchKernelGGL(sqsum_kernel, dim3(nb), dim3(kThreads), 0, s, grads, n, ws, state);
+    // 128 partial sums of squares (two per lane of the wave that adds them up again in EVERY workgroup of adam_kernel; with one
+    // partial per adam workgroup, 512, that prologue was eight dependent loads in front of 5 elements per thread)
+    const int nsq = nb < 128 ? nb : 128;
+    hipLaunchKernelGGL(sqsum_kernel, dim3(nsq), dim3(kThreads), 0, s, grads, n, ws, state, beta1, beta2);
     MSAU_CHECK_LAUNCH("sqsum");
-    hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(kThreads), 0, s, params, grads, m, v, state, ws, nb, n, lr, beta1, beta2, eps, max_norm, grad_scale);
+    hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(kThreads), 0, s, params, grads, m, v, state, ws, nsq, n, lr, beta1, beta2, eps, max_norm, grad_scale);
     MSAU_CHECK_LAUNCH("adam");
     return 0;
 }
