@@ -705,17 +705,22 @@ __global__ void channel_sum_kernel(const T* __restrict__ g, int64_t npix, int Cs
 // =============================================================================================
 __global__ void sqsum_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partials, float* __restrict__ state, float beta1, float beta2) {
     __shared__ float red[kThreads / 64];
-    float s = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float v = g[i];
-        s += v * v;
+    // four independent loads in flight per thread (a fixed order: the same bits on every run)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const float v0 = g[i], v1 = g[i + stride], v2 = g[i + 2 * stride], v3 = g[i + 3 * stride];
+        s0 += v0 * v0; s1 += v1 * v1; s2 += v2 * v2; s3 += v3 * v3;
     }
+    for (; i < n; i += stride) { const float v = g[i]; s0 += v * v; }
+    float s = (s0 + s1) + (s2 + s3);
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
         float t = 0.f;
-        for (int i = 0; i < kThreads / 64; ++i) t += red[i];
+        for (int i2 = 0; i2 < kThreads / 64; ++i2) t += red[i2];
         partials[blockIdx.x] = t;
         if (blockIdx.x == 0 && state) {
             // the step counter and Adam's bias corrections, once: every workgroup of adam_kernel reads them (rounds 1-4: each of
