@@ -116,6 +116,10 @@ enum {
                                    wg_slabs = msau_conv2d_rider_slabs() slabs of [2 chunks][8][16] fp32 in the layout msau_wgrad_reduce
                                    expects for that conv (cch 8, kext 16, ones column 8 of chunk 0); the stand-alone weight-gradient
                                    launch, its read of g and of the second source disappear.  Row-streaming 8-channel bf16 instance only. */
+    MSAU_CONV_ELU      = 32768, /* activation_name="elu" (model/model.py:412-416): MSAU_CONV_RELU_OUT means v = ELU(v) (alpha 1: v > 0 ? v : exp(v) - 1)
+                                   and MSAU_CONV_MASK_B (the tensor's own stored output y) means v *= (y > 0 ? 1 : y + 1), the derivative of ELU at
+                                   the pre-activation.  MSAU_CONV_RELU_IN / MASK_A stay ReLU: the reference's residual block starts with a
+                                   hard-wired torch.nn.ReLU (model/model.py:35,39).  Generic kernel only (no fused / row / lean instance). */
     MSAU_CONV_HEAD     = 64     /* inference head (kv_model.py:305-313): besides y, write softmax over the Cout real
                                    channels of the (storage-rounded) result to head_probs (fp32 [B][Hout][Wout][Cout],
                                    dense) and the index of its first maximum to head_argmax (uint8 [B][Hout][Wout]).
@@ -381,7 +385,8 @@ int msau_lrn_bwd(void* stream, int dtype, const void* a, const void* dy, void* d
 /* ------------------------------------------------------------------------------------------
  * 2x2 stride-2 max pool after zero SAME padding (model/model.py:158-160).  idx = argmax position
  * (0..3, first maximum in row-major window order, as torch CPU) kept as one byte per output element.
- * bwd: dx = (accumulate ? dx : 0) + scatter(dy); dx *= (mask > 0) if mask != NULL.
+ * bwd: dx = ((accumulate & 1) ? dx : 0) + scatter(dy); dx *= (mask > 0) if mask != NULL -- or, with bit 1 of `accumulate` set (the
+ * masked tensor is the output of an ELU, activation_name="elu"), dx *= (mask > 0 ? 1 : mask + 1).
  * ------------------------------------------------------------------------------------------ */
 int msau_maxpool2x2_fwd(void* stream, int dtype, const void* x, void* y, uint8_t* idx, int B, int H, int W, int Cs);
 int msau_maxpool2x2_bwd(void* stream, int dtype, const void* dy, const uint8_t* idx, void* dx, const void* mask,

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MSAU_HIP_LIB", os.path.join(HERE, "libmsau_hip.so"))
 F32, BF16 = 0, 1
 
 CONV_RELU_IN, CONV_RELU_OUT, CONV_ADD, CONV_ACCUM, CONV_MASK_A, CONV_MASK_B, CONV_HEAD, CONV_DOUT = 1, 2, 4, 8, 16, 32, 64, 128
-CONV_LRN, CONV_POOL, CONV_IDS, CONV_OWNER, CONV_NCHW, CONV_WGRAD = 256, 512, 1024, 2048, 4096, 8192
+CONV_LRN, CONV_POOL, CONV_IDS, CONV_OWNER, CONV_NCHW, CONV_WGRAD, CONV_ELU = 256, 512, 1024, 2048, 4096, 8192, 32768
 
 i32, i64, vp, f32 = C.c_int32, C.c_int64, C.c_void_p, C.c_float
 

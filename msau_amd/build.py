@@ -29,6 +29,9 @@ EXTRA_FLAGS = {"elementwise.hip": ["-Xclang", "-target-feature", "-Xclang", "-pa
                # the box-list-fed first conv (cfg 4's bf16 train path, beside the same side-stream kernels): its fp32 partial-sum loops
                # compiled to 247 packed-fp32 instructions, 91 of them with op_sel_hi -- the pattern the rule above is about
                "ownerconv.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
+               # the generic conv kernel: its ELU epilogue (expm1f, the (y + 1) derivative factor; round 5) compiled to 210 op_sel'd
+               # packed-fp32 instructions -- the same rule; the generic kernel takes a handful of level-3 launches of the bf16 step
+               "conv.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
                # the box variant's kernels (cfg 5) run in a bf16 train path beside the same side-stream weight gradients: same rule
                "boxconv.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
                # attention on the matrix cores: MFMA results in VGPRs as well (the statistics kernel read every score back with

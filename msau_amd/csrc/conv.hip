@@ -273,13 +273,23 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
                 for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
             }
             if (flags & MSAU_CONV_RELU_OUT) {
+                if (flags & MSAU_CONV_ELU) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : expm1f(v[j]);          // torch.nn.ELU(alpha = 1)
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
             }
             if (flags & MSAU_CONV_MASK_B) {
                 V4 m = load4<T>(mask_b + pbase + co);
+                if (flags & MSAU_CONV_ELU) {                                  // d ELU / dz at the stored y = ELU(z): z > 0 ? 1 : exp(z) = y + 1
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : 0.f;
+                    for (int j = 0; j < 4; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : v[j] * ((float)m[j] + 1.f);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : 0.f;
+                }
             }
             V4 o;
 #pragma unroll

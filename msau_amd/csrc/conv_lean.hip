@@ -797,6 +797,7 @@ int lean_strided(hipStream_t s, const LeanArgs& a, int c8, int CT, bool ups) {
 // Returns 1 if a lean instance handled the launch, 0 if the caller must use the generic kernel,
 // < 0 on error.  `kchunk` / `nchunks` / `CT` come from the generic geometry (same packed image).
 int msau_conv_lean_applicable(int dtype, const msau_conv_desc* d, int nchunks, int CT) {
+    if (d->flags & MSAU_CONV_ELU) return 0;                    // (ELU epilogues: the generic kernel only)
     if (d->stride * d->ups == 2) {
         const int esz = dtype == MSAU_F32 ? 4 : 2;
         if ((int64_t)d->Hin * d->Win * d->C1 * esz >= (1ll << 31) || (int64_t)d->Wout * d->Cout * esz * 20 >= (1ll << 31)) return 0;
@@ -956,6 +957,7 @@ static int chunked_variant(int dtype, const msau_conv_desc* d, int cch, int nchu
     return 0;
 }
 int msau_conv_chunked_capable(int dtype, const msau_conv_desc* d, int cch, int nchunks, int CT) {
+    if (d->flags & MSAU_CONV_ELU) return 0;
     return chunked_variant(dtype, d, cch, nchunks, CT) != 0;
 }
 

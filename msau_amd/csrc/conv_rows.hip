@@ -1708,7 +1708,7 @@ int launch_rowconv8(hipStream_t s, const RowConvArgs& a) {
 // instance index of a descriptor, 0 = none
 int rowconv_case(int dtype, const msau_conv_desc* d) {
     const RowsEnv& e = rows_env();
-    if (!e.on || !e.conv || dtype != MSAU_BF16) return 0;
+    if (!e.on || !e.conv || dtype != MSAU_BF16 || (d->flags & MSAU_CONV_ELU)) return 0;
     if (d->ups == 2) {                                                     // the 16 -> 8 / 32 -> 16 transposed convs (rowdeconv8 / rowdeconv16)
         const bool c16 = d->C1 == 16 && d->Cout == 8, c32 = d->C1 == 32 && d->Cout == 16 && e.deconv >= 2;
         if (!e.deconv || !(c16 || c32) || d->C2 != 0 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->dil != 1 || d->flags) return 0;

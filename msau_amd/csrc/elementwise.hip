@@ -389,6 +389,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dy,
     const typename Vec8<T>::type g = load8<T>(dy + o);
     const uint64_t packed = *reinterpret_cast<const uint64_t*>(idx + o);
     typedef typename Vec8<T>::type V8;
+    const bool elu = accumulate & 2;                                 // bit 1: `mask` is the output of an ELU, not of a ReLU
+    accumulate &= 1;
     V8 old[4], m[4];
     bool ok[4];
 #pragma unroll
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dy,
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float v = (float)old[pos][j] + ((int)((packed >> (8 * j)) & 0xff) == pos ? (float)g[j] : 0.f);
-            if (mask && !((float)m[pos][j] > 0.f)) v = 0.f;
+            if (mask && !((float)m[pos][j] > 0.f)) v = elu ? v * ((float)m[pos][j] + 1.f) : 0.f;       // (ELU: y <= 0 -> d/dz = y + 1)
             r[j] = (T)v;
         }
         store8<T>(dx + i * 8, r);

@@ -225,8 +225,9 @@ class MSAUWrapper(nn.Module):
         self.filter_size = kw.get("filter_size", 3)
         self.pool_size = kw.get("pool_size", 2)
         self.activation_name = kw.get("activation_name", "relu")
-        if self.activation_name != "relu":
-            raise NotImplementedError("only activation_name='relu' has HIP kernels")
+        if self.activation_name not in ("relu", "elu"):
+            # (the reference's constructor leaves `self.activation` unset for any other name and fails with AttributeError two lines on)
+            raise ValueError("activation_name must be 'relu' or 'elu' (model/model.py:412-416)")
         self.model = kw.get("model", "msau")
         self.num_scales = kw.get("num_scales", 3)
         self.final_act = kw.get("final_act", "softmax")
@@ -245,7 +246,7 @@ class MSAUWrapper(nn.Module):
             raise NotImplementedError(f"featRoot * 2^(scale_space_num-1) = {widest} channels: the HIP kernels support up to 256")
         self.cfg = dict(channels=channels, n_class=n_class, scale_space_num=self.scale_space_num,
                         res_depth=self.res_depth, featRoot=self.featRoot, filter_size=self.filter_size,
-                        pool_size=self.pool_size, num_blocks=self.num_blocks)
+                        pool_size=self.pool_size, num_blocks=self.num_blocks, activation=self.activation_name)
         self.cfg.update(self._variant_cfg(kw))
         for opt in ("reuse_activations", "overlap_wgrad", "overlap_max_pix", "deterministic"):      # execution options of the plan
             if opt in kw:

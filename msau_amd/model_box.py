@@ -30,6 +30,8 @@ class BMSAUWrapper(MSAUWrapper):
             self.max_box_sizes = self.max_box_sizes[0]
         if self.num_box_convs < 1 or self.num_box_per_channels < 1 or self.max_box_sizes < 1:
             raise ValueError("num_box_convs, num_box_per_channels and max_box_sizes must be positive")
+        if kw.get("activation_name", "relu") != "relu":
+            raise NotImplementedError("the box variant's kernels implement activation_name='relu' only")
         super().__init__(channels, n_class, kw)
 
     def _variant_cfg(self, kw: dict) -> dict:

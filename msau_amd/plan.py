@@ -192,7 +192,7 @@ class ConvOp(Op):
         self.uentry = None
         self.dd_off = None           # one launch for both sources of a concat conv (MSAU_CONV_DOUT) when an instance has it
         if P.training and conv and x2 is not None and None not in self.slots and x1.C == x1.Cs == x2.C == x2.Cs \
-                and x1.Cs + x2.Cs <= 128 and os.environ.get("MSAU_FUSE_DGRAD", "1") != "0":
+                and x1.Cs + x2.Cs <= 128 and os.environ.get("MSAU_FUSE_DGRAD", "1") != "0" and not P.act_flag:
             proto = L.ConvDesc()
             proto.B, proto.Hin, proto.Win, proto.Hout, proto.Wout = P.B, out.H, out.W, x1.H, x1.W
             proto.C1, proto.C2, proto.Cout = out.Cs, 0, x1.Cs + x2.Cs
@@ -235,7 +235,7 @@ class ConvOp(Op):
         d.C1, d.C2, d.Cout = x1.Cs, (x2.Cs if x2 is not None else 0), out.Cs
         d.KH = d.KW = self.k
         d.dil, d.pad_t, d.pad_l, d.stride, d.ups = self.dil, self.pad_t, self.pad_l, 1, (1 if conv else 2)
-        d.flags = (L.CONV_RELU_IN if self.relu_in else 0) | (L.CONV_RELU_OUT if self.relu_out else 0) | \
+        d.flags = (L.CONV_RELU_IN if self.relu_in else 0) | ((L.CONV_RELU_OUT | P.act_flag) if self.relu_out else 0) | \
                   (L.CONV_ADD if self.fwd_add is not None else 0)
         d.x1, d.x2 = _ptr(x1.data), _ptr(x2.data if x2 is not None else None)
         d.wpack, d.bias = P.pack_ptr(self.w_off), P.pack_ptr(self.b_off)
@@ -321,7 +321,7 @@ class ConvOp(Op):
             if accum:
                 fl |= L.CONV_ACCUM
             if maskb:
-                fl |= L.CONV_MASK_B
+                fl |= L.CONV_MASK_B | P.act_flag
                 dd.mask_b = _ptr(x.data)
             dd.flags = fl
             dd.x1, dd.wpack, dd.bias, dd.y = _ptr(out.grad), P.pack_ptr(self.d_off[si]), None, _ptr(x.grad)
@@ -551,7 +551,7 @@ class PairOp:
         """after both ConvOps are bound: build the fused descriptors if an instance takes the shape"""
         P, c1, c2 = self.plan, self.c1, self.c2
         x0, r1, out = c1.x1, c1.out, c2.out
-        if os.environ.get("MSAU_FUSE_PAIR", "1") == "0" or not P.cfg.get("fuse_pair", True):
+        if os.environ.get("MSAU_FUSE_PAIR", "1") == "0" or not P.cfg.get("fuse_pair", True) or P.act_flag:
             return
         ok = (c1.kind == c2.kind == "conv" and c1.k == c2.k == 3 and c1.dil == c2.dil == 1 and c1.x2 is None and c2.x2 is None
               and c1.relu_in and c1.relu_out and c1.fwd_add is None and not c2.relu_in and c2.relu_out and c2.fwd_add is x0
@@ -922,7 +922,7 @@ class PoolOp(Op):
             return []
         accum, maskb = x.slot_flags(self.slot)
         self._ba = L.PoolArgs(_ptr(y.grad), _ptr(x.grad), _ptr(self.idx), _ptr(x.data) if maskb else None,
-                              self.plan.B, x.H, x.W, x.Cs, int(accum))
+                              self.plan.B, x.H, x.W, x.Cs, int(accum) | (2 if maskb and self.plan.act_flag else 0))
         self.plan.rec_meta[C.addressof(self._ba)] = (self.bkey, self.bbytes)
         return [(L.OP_POOL_BWD, self._ba)]
 
@@ -939,7 +939,8 @@ class PoolOp(Op):
             return
         accum, maskb = x.slot_flags(self.slot)
         L.call("msau_maxpool2x2_bwd", s, self.plan.dtype, _ptr(y.grad), _ptr(self.idx), _ptr(x.grad),
-               _ptr(x.data) if maskb else None, self.plan.B, x.H, x.W, x.Cs, int(accum), key=self.bkey)
+               _ptr(x.data) if maskb else None, self.plan.B, x.H, x.W, x.Cs, int(accum) | (2 if maskb and self.plan.act_flag else 0),
+               key=self.bkey)
 
 
 class AttnCoreOp(Op):
@@ -1018,6 +1019,10 @@ class Plan:
         self.poff, self.pshape, self.training = poff, pshape, training
         # forward-only plans keep no activation beyond its last reader: buffers are handed out by liveness
         self.reuse = (not training) and bool(cfg.get("reuse_activations", True))
+        # activation_name="elu" (model/model.py:412-416): the convs' output activation and its derivative on the generic kernels
+        # (MSAU_CONV_ELU); the residual block's leading activation stays ReLU as in the reference (model.py:35,39)
+        assert cfg.get("activation", "relu") in ("relu", "elu"), cfg.get("activation")
+        self.act_flag = L.CONV_ELU if cfg.get("activation", "relu") == "elu" else 0
         self.head_probs = self.head_argmax = None
         self.head_fused = False
         self.acts: List[Act] = []

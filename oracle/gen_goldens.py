@@ -53,7 +53,7 @@ def checksum(sd):
 def build_ref(cfg):
     kw = dict(scale_space_num=cfg["scale_space_num"], res_depth=cfg["res_depth"],
               featRoot=cfg["featRoot"], filter_size=cfg["filter_size"],
-              pool_size=cfg["pool_size"], final_act="softmax")
+              pool_size=cfg["pool_size"], final_act="softmax", activation_name=cfg.get("activation", "relu"))
     with contextlib.redirect_stdout(io.StringIO()):
         net = MSAUWrapper(cfg["channels"], cfg["n_class"], kw)
     net.msau_net.num_blocks = cfg["num_blocks"]          # blocks are independent modules
@@ -193,6 +193,8 @@ if __name__ == "__main__" and os.environ.get("MSAU_GOLDEN_NET", "1") == "1" and 
     net_golden("net_r3_s3_c8_21x35", dict(base, channels=8, res_depth=3, scale_space_num=3), 1, 21, 35, seed=15)
     # the reference's CONSTRUCTOR DEFAULTS (model/model.py:406-408): 6 scales -> 256 channels, dilation up to 32, res_depth 3
     net_golden("net_defaults_s6_r3_c8_70x96", dict(base, channels=8, scale_space_num=6, res_depth=3), 1, 70, 96, seed=17)
+    # activation_name="elu" (model/model.py:412-416): the only other activation the wrapper knows; odd size, all levels
+    net_golden("net_elu_f8_c13_33x26", dict(base, channels=13, activation="elu"), 1, 33, 26, seed=18)
     # cfg 2 geometry checksum: 336x256x64, 3 stages, forward + loss + grads summaries
     net_golden("net_cfg2_336x256x64", dict(base, channels=64), 1, 336, 256, seed=16)
 

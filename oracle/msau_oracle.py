@@ -76,10 +76,18 @@ def pad_same(x: Tensor, kh: int, kw: int, sh: int = 1, sw: int = 1, dilation: in
 # ---------------------------------------------------------------------------
 # A2  Conv2dBnLrnDrop (bn/lrn/dropout inactive)      model/layers/layers.py:82-102
 # ---------------------------------------------------------------------------
-def conv_same(x: Tensor, w: Tensor, b: Tensor, dilation: int = 1, relu: bool = False) -> Tensor:
+def activation_of(cfg: dict):
+    """MSAUWrapper's `activation_name` (model/model.py:412-416): "relu" -> torch.nn.ReLU, "elu" -> torch.nn.ELU (alpha 1)."""
+    name = cfg.get("activation", "relu")
+    assert name in ("relu", "elu"), name
+    return F.elu if name == "elu" else torch.relu
+
+
+def conv_same(x: Tensor, w: Tensor, b: Tensor, dilation: int = 1, relu: bool = False, act=None) -> Tensor:
+    """(`relu=True` applies `act`, torch.relu unless the caller passes the net's activation)"""
     kh, kw = w.shape[2], w.shape[3]
     y = F.conv2d(pad_same(x, kh, kw, 1, 1, dilation), w, b, dilation=dilation)
-    return torch.relu(y) if relu else y
+    return (act or torch.relu)(y) if relu else y
 
 
 # ---------------------------------------------------------------------------
@@ -120,15 +128,15 @@ def deconv(x: Tensor, w: Tensor, b: Tensor, out_hw: Tuple[int, int]) -> Tensor:
 # ---------------------------------------------------------------------------
 # A5  MultiConvResidualBlock                         model/model.py:37-50
 # ---------------------------------------------------------------------------
-def res_block(x: Tensor, sd: Dict[str, Tensor], prefix: str, R: int, q=_ident) -> Tensor:
-    r = torch.relu(x)
+def res_block(x: Tensor, sd: Dict[str, Tensor], prefix: str, R: int, q=_ident, act=torch.relu) -> Tensor:
+    r = torch.relu(x)                                  # model.py:35,39: `self.relu = torch.nn.ReLU()` whatever activation_name says
     for i in range(R):
         w = sd[f"{prefix}.conv_res_list.{i}.custom_conv.weight"]
         b = sd[f"{prefix}.conv_res_list.{i}.custom_conv.bias"]
-        r = conv_same(r, w, b, relu=(i < R - 1))
+        r = conv_same(r, w, b, relu=(i < R - 1), act=act)
         if i < R - 1:
             r = q(r)                                   # the inner tensors are stored (the backward reads them)
-    return q(torch.relu(r + x))
+    return q(act(r + x))
 
 
 # ---------------------------------------------------------------------------
@@ -153,6 +161,7 @@ def stage_forward(inp: Tensor, sd: Dict[str, Tensor], b: int, cfg: dict,
                   need_attention: bool = True, q=_ident):
     S, R = cfg["scale_space_num"], cfg["res_depth"]
     k, ps = cfg["filter_size"], cfg["pool_size"]
+    act = activation_of(cfg)
     assert ps == 2
     coupled = b > 0
     pd = f"msau_net.blocks.{b}.downsamplingblock"
@@ -162,11 +171,11 @@ def stage_forward(inp: Tensor, sd: Dict[str, Tensor], b: int, cfg: dict,
     x = inp
     for l in range(S):                                                  # model.py:136-162
         x = dilconv_lrn(x_in, sd[f"{pd}.conv1s.{l}.conv.weight"], sd[f"{pd}.conv1s.{l}.conv.bias"], 2 ** l, q)
-        x = res_block(x, sd, f"{pd}.conv_res_list.{l}", R, q)
+        x = res_block(x, sd, f"{pd}.conv_res_list.{l}", R, q, act)
         if coupled:                                                     # model.py:143-148
             x = q(conv_same(torch.cat([prev_dw[l], x], dim=1),
                             sd[f"{pd}.conv1_1s.{l}.custom_conv.weight"],
-                            sd[f"{pd}.conv1_1s.{l}.custom_conv.bias"], relu=True))
+                            sd[f"{pd}.conv1_1s.{l}.custom_conv.bias"], relu=True, act=act))
         if l > S - 2:                                                   # model.py:149-150
             dw[l] = self_attention(x, sd, f"{pd}.layer_attentions.attention_block", q) if need_attention else x
         else:
@@ -180,11 +189,11 @@ def stage_forward(inp: Tensor, sd: Dict[str, Tensor], b: int, cfg: dict,
                      tuple(dw[l].shape[2:])))
         x = q(conv_same(torch.cat([dw[l], d], dim=1),
                         sd[f"{pu}.conv1s.{l}.custom_conv.weight"], sd[f"{pu}.conv1s.{l}.custom_conv.bias"]))
-        x = res_block(x, sd, f"{pu}.conv_res_list.{l}", R, q)
+        x = res_block(x, sd, f"{pu}.conv_res_list.{l}", R, q, act)
         if coupled:
             x = q(conv_same(torch.cat([prev_up[l], x], dim=1),
                             sd[f"{pu}.conv1_1s.{l}.custom_conv.weight"],
-                            sd[f"{pu}.conv1_1s.{l}.custom_conv.bias"], relu=True))
+                            sd[f"{pu}.conv1_1s.{l}.custom_conv.bias"], relu=True, act=act))
         up[l] = x
         cur = x
     return cur, dw, up

@@ -11,7 +11,8 @@ from oracle import msau_oracle as O
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 NET_CASES = ["net_f8_c13_33x26", "net_f4_c13_b2_64x48", "net_1stage_c32_b2_40x40",
-             "net_2stage_c24_dense_24x40", "net_r3_s3_c8_21x35", "net_cfg2_336x256x64", "net_defaults_s6_r3_c8_70x96"]
+             "net_2stage_c24_dense_24x40", "net_r3_s3_c8_21x35", "net_cfg2_336x256x64", "net_defaults_s6_r3_c8_70x96",
+             "net_elu_f8_c13_33x26"]
 
 
 def load_ops():

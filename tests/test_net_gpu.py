@@ -19,7 +19,7 @@ LOGIT_TOL = {"fp32": 2e-4, "bf16": 6e-2}
 def _model(cfg, sd, dtype, **extra):
     kw = dict(scale_space_num=cfg["scale_space_num"], res_depth=cfg["res_depth"], featRoot=cfg["featRoot"],
               filter_size=cfg["filter_size"], pool_size=cfg["pool_size"], final_act="softmax",
-              num_blocks=cfg["num_blocks"], dtype=dtype, **extra)
+              num_blocks=cfg["num_blocks"], dtype=dtype, activation_name=cfg.get("activation", "relu"), **extra)
     m = MSAUWrapper(cfg["channels"], cfg["n_class"], kw)
     missing = m.load_state_dict(sd, strict=True)
     return m.cuda()
