@@ -142,6 +142,20 @@ def test_dead_parameters_are_the_last_stage_attention():
     assert len(m._dead) == 6 and sum(int(np.prod(m._pshape[k])) for k in m._dead) == 5200
 
 
+def test_activation_name_relu_and_elu_construct_anything_else_is_refused():
+    """model/model.py:412-416 knows "relu" and "elu" (any other name leaves `self.activation` unset and the reference's own constructor
+    dies two lines later): both construct here with the reference's state_dict keys, anything else is a ValueError; the box variant's
+    kernels are ReLU only and say so."""
+    from msau_amd.model_box import BMSAUWrapper
+    kw = dict(scale_space_num=3, res_depth=2, featRoot=8, final_act="softmax")
+    keys = list(MSAUWrapper(13, 5, dict(kw)).state_dict())
+    assert list(MSAUWrapper(13, 5, dict(kw, activation_name="elu")).state_dict()) == keys
+    with pytest.raises(ValueError, match="activation_name"):
+        MSAUWrapper(13, 5, dict(kw, activation_name="tanh"))
+    with pytest.raises(NotImplementedError, match="relu"):
+        BMSAUWrapper(13, 5, dict(kw, activation_name="elu"))
+
+
 def test_compute_without_gpu_raises_not_falls_back():
     m = MSAUWrapper(13, 5, dict(scale_space_num=3, res_depth=2, featRoot=8, final_act="softmax"))
     with pytest.raises(RuntimeError):

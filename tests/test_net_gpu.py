@@ -125,7 +125,7 @@ def test_reference_style_step_fp32(name):
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
-@pytest.mark.parametrize("name", ["net_f8_c13_33x26", "net_f4_c13_b2_64x48", "net_2stage_c24_dense_24x40"])
+@pytest.mark.parametrize("name", ["net_f8_c13_33x26", "net_f4_c13_b2_64x48", "net_2stage_c24_dense_24x40", "net_elu_f8_c13_33x26"])
 def test_fused_engine_step_fp32(name, use_graph):
     """TrainEngine.step (fused CE + backward + clip + Adam on the flat buffers) gives the same loss,
     gradients, norm and parameter update as the reference's step."""

@@ -39,7 +39,7 @@ def _param_grads(m, eng):
 BF16_NORM_TOL, BF16_SAMPLE_TOL, BF16_FLOOR = 1e-1, 1.5e-1, 2e-3
 
 
-@pytest.mark.parametrize("name", ["net_cfg2_336x256x64", "net_f4_c13_b2_64x48"])
+@pytest.mark.parametrize("name", ["net_cfg2_336x256x64", "net_f4_c13_b2_64x48", "net_elu_f8_c13_33x26"])
 def test_bf16_parameter_gradients_match_reference(name):
     g, cfg, sd, x, label = load_net_case(name)
     m = _model(cfg, sd, "bf16")
