@@ -43,7 +43,8 @@ const char* msau_source_hash(void);
 /* sizeof() of the structs below as the library was compiled, for bindings that mirror them (a mirror that is too short
  * makes the library read past it): which = 0 msau_conv_desc, 1 msau_wgrad_desc, 2 msau_pack_entry, 3 msau_unpack_entry,
  * 4 msau_op, 5 msau_lrn_args, 6 msau_pool_args, 7 msau_attn_args, 8 msau_csum_args, 9 msau_reduce_args,
- * 10 msau_conv_pack_geom, 11 msau_wgrad_geom, 12 msau_conv_pair_desc, 13 msau_box_args, 14 msau_allreduce_args, 15 msau_owner_ctx;
+ * 10 msau_conv_pack_geom, 11 msau_wgrad_geom, 12 msau_conv_pair_desc, 13 msau_box_args, 14 msau_allreduce_args, 15 msau_owner_ctx,
+ * 16 msau_attn_proj_bwd_args;
  * -1 for anything else. */
 int msau_sizeof(int which);
 /* LDS strides (bytes) the tile kernels give a pixel of `raw_bytes` channels / a weight row of `nks` 32-deep k-steps (csrc/msau_common.h:
@@ -403,6 +404,27 @@ int msau_selfattn_fwd(void* stream, int dtype, const void* f, const void* g, con
 int msau_selfattn_bwd(void* stream, int dtype, const void* f, const void* g, const void* h, const void* dy,
                       const float* stats, void* df, void* dg, void* dh, float* ws, int B, int N, int Ds, int Cs);
 
+/* The data gradients of the attention block's three 1x1 projections (model/layers/attention.py:152-154: f, g: C -> C/8, h: C -> C, all
+ * reading the same tensor x) as ONE launch instead of three accumulating msau_conv2d launches:
+ *   v  = Wf^T df + Wg^T dg + Wh^T dh        (fp32 accumulation over K = C/8 + C/8 + C in one MFMA chain)
+ *   v += add                  if add        (the attention residual y = o + x: dy)
+ *   v += dx_old               if accumulate (an earlier contribution to dx, e.g. the decoder's transposed conv)
+ *   v  = mask_b > 0 ? v : 0   if mask_b     (ReLU of x's producer)
+ *   dx = round(v)
+ * wf_pack / wg_pack / wh_pack: the packed DATA-GRADIENT images of the three convs exactly as msau_conv2d takes them
+ * (msau_conv_pack_geometry(dtype, C/8 or C, 0, C, 1, 1, 1, 1, 1): one chunk, 64 rows, kchunk 32 / 32 / 64) -- the launch reads its
+ * weight fragments straight from them.  bf16, C = 64 only (MSAU_ERR_ARG otherwise: the caller keeps the three launches). */
+typedef struct {
+    const void* df; const void* dg; const void* dh;         /* [npix][C/8], [npix][C/8], [npix][C] */
+    const void* wf_pack; const void* wg_pack; const void* wh_pack;
+    const void* add;                                        /* [npix][C] or NULL */
+    const void* mask_b;                                     /* [npix][C] or NULL */
+    void* dx;                                               /* [npix][C] */
+    int64_t npix;
+    int32_t C, accumulate;
+} msau_attn_proj_bwd_args;
+int msau_attn_proj_bwd(void* stream, int dtype, const msau_attn_proj_bwd_args* a);
+
 /* ------------------------------------------------------------------------------------------
  * Masked cross entropy (model/model.py:446-459) with the batch rule of SURVEY 8(e):
  *   loss = scale * sum_b 1/max(cnt_b,1) * sum_{p: label!=0} -log softmax(logits_p)[label_p]
@@ -529,7 +551,8 @@ enum {
     MSAU_OP_CONV_PAIR = 11,  /* args: msau_conv_pair_desc     */
     MSAU_OP_BOX_FWD = 12,    /* args: msau_box_args           */
     MSAU_OP_BOX_BWD = 13,    /* args: msau_box_args           */
-    MSAU_OP_ALLREDUCE = 14   /* args: msau_allreduce_args     */
+    MSAU_OP_ALLREDUCE = 14,  /* args: msau_allreduce_args     */
+    MSAU_OP_ATTN_PROJ_BWD = 15 /* args: msau_attn_proj_bwd_args */
 };
 typedef struct { int32_t kind; int32_t dtype; const void* args; } msau_op;
 typedef struct { const void* a; const void* dy; void* out; int64_t npix; int32_t C, Cs, n; float alpha, beta, k; } msau_lrn_args;

@@ -112,6 +112,11 @@ class OwnerCtx(C.Structure):
                [(n, i32) for n in ("n_boxes", "n_vec", "C", "csum_blocks", "wt_floats", "reserved0")]
 
 
+class AttnProjBwdArgs(C.Structure):
+    _fields_ = [(n, vp) for n in ("df", "dg", "dh", "wf_pack", "wg_pack", "wh_pack", "add", "mask_b", "dx")] + \
+               [("npix", i64), ("C", i32), ("accumulate", i32)]
+
+
 OP_SIDE = 0x100
 OP_PROBE = 0x200
 OP_COMM = 0x400
@@ -120,6 +125,7 @@ OP_ALLREDUCE = 14
 OP_WGRAD_REDUCE = 10
 OP_CONV_PAIR = 11
 OP_BOX_FWD, OP_BOX_BWD = 12, 13
+OP_ATTN_PROJ_BWD = 15
 OP_CONV2D, OP_WGRAD, OP_LRN_FWD, OP_LRN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_CHANNEL_SUM = range(1, 10)
 
 _SIGNATURES = {
@@ -132,6 +138,7 @@ _SIGNATURES = {
     "msau_conv_pack_geometry": (C.c_int, [C.c_int] * 9 + [C.POINTER(ConvPackGeom)]),
     "msau_conv2d": (C.c_int, [vp, C.c_int, C.POINTER(ConvDesc)]),
     "msau_conv2d_rider_slabs": (C.c_int, [C.c_int, C.POINTER(ConvDesc)]),
+    "msau_attn_proj_bwd": (C.c_int, [vp, C.c_int, C.POINTER(AttnProjBwdArgs)]),
     "msau_conv2d_launch_info": (C.c_int, [C.c_int, C.POINTER(ConvDesc), C.POINTER(i32)]),
     "msau_conv_pair_applicable": (C.c_int, [C.c_int, C.POINTER(ConvPairDesc)]),
     "msau_conv_pair": (C.c_int, [vp, C.c_int, C.POINTER(ConvPairDesc)]),
@@ -202,7 +209,7 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 # ctypes mirrors in the order of msau_sizeof(which): load() refuses a library whose structs have another size
 ABI_STRUCTS = (ConvDesc, WgradDesc, PackEntry, UnpackEntry, Op, LrnArgs, PoolArgs, AttnArgs, CsumArgs, ReduceArgs,
-               ConvPackGeom, WgradGeom, ConvPairDesc, BoxArgs, AllreduceArgs, OwnerCtx)
+               ConvPackGeom, WgradGeom, ConvPairDesc, BoxArgs, AllreduceArgs, OwnerCtx, AttnProjBwdArgs)
 
 
 class MsauHipError(RuntimeError):

@@ -15,7 +15,7 @@ int msau_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* msau_last_error(void) { return g_err; }
-extern "C" int msau_version(void) { return 9; }
+extern "C" int msau_version(void) { return 10; }
 
 extern "C" int msau_lds_pixel_stride(int raw_bytes, int esz, int c8_per_chunk, int read_stride) { return lds_pixel_stride(raw_bytes, esz, c8_per_chunk, read_stride); }
 extern "C" int msau_lds_wrow_stride(int nks, int esz) { return lds_wrow_stride(nks, esz); }
@@ -39,6 +39,7 @@ extern "C" int msau_sizeof(int which) {
         case 13: return (int)sizeof(msau_box_args);
         case 14: return (int)sizeof(msau_allreduce_args);
         case 15: return (int)sizeof(msau_owner_ctx);
+        case 16: return (int)sizeof(msau_attn_proj_bwd_args);
         default: return -1;
     }
 }

@@ -110,6 +110,7 @@ class ConvOp(Op):
         self.pair: Optional["PairOp"] = None        # set when this conv runs as half of a fused two-conv launch
         self.cpl: Optional["ConvOp"] = None         # on a pair's second conv: the coupling 1x1 conv that reads its output (may ride on the launch)
         self.cpl_fused_into: Optional["PairOp"] = None   # on a coupling conv: the pair whose forward launch computes it (MSAU_PAIR_COUPLE)
+        self.proj: Optional["ProjBwd"] = None       # on an attention projection: the fused data-gradient launch of f, g, h
         if kind == "conv" and k == 1 and x2 is not None and relu_out and not relu_in and fwd_add is None and plan.ops:
             prod = plan.ops[-1]
             if isinstance(prod, ConvOp) and prod.out is x2 and prod.pair is not None and prod is prod.pair.c2 \
@@ -440,7 +441,8 @@ class ConvOp(Op):
                 src_c = (self.x1.C + self.x2.C) if self.dd_off is not None else (self.x1, self.x2)[si].C
                 fl = 2.0 * P.B * (self.out.H * self.out.W if self.kind == "conv" else self.x1.H * self.x1.W) * taps * src_c * self.out.C
                 self.dmeta[si] = conv_meta(dd)
-                P.note_launch(self.dmeta[si][0], self.dmeta[si][1], fl)
+                if self.proj is None or not self.proj.active:
+                    P.note_launch(self.dmeta[si][0], self.dmeta[si][1], fl)
         if self.wdesc is not None:
             w, wg = self.wdesc, self.wgeom
             ctn = -(-w.Cout // 16)
@@ -501,6 +503,8 @@ class ConvOp(Op):
                 rm[C.addressof(self.pair.bdesc)] = (self.pair.key, self.pair.bbytes)
                 recs.append((L.OP_CONV_PAIR, self.pair.bdesc))
             return recs
+        if self.proj is not None and self.proj.active:  # f, g, h of an attention block: one launch, behind the last of the three
+            return recs + (self.proj.recs() if self is self.proj.f else [])
         for si, dd in enumerate(self.ddesc):
             if dd is not None:
                 rm[C.addressof(dd)] = self.dmeta[si]
@@ -524,6 +528,10 @@ class ConvOp(Op):
         if self.pair is not None and self.pair.active and self.pair.bdesc is not None:
             if self is self.pair.c2:
                 L.call("msau_conv_pair", s, P.dtype, C.byref(self.pair.bdesc), key=self.pair.key)
+            return
+        if self.proj is not None and self.proj.active:
+            if self is self.proj.f:
+                self.proj.launch(s)
             return
         for si, dd in enumerate(self.ddesc):
             if dd is not None:
@@ -1011,6 +1019,66 @@ class AttnCoreOp(Op):
                _ptr(self.ws), self.plan.B, self.N, self.f.Cs, self.h.Cs, key=self.bkey)
 
 
+class ProjBwd:
+    """The data gradients of an attention block's f, g, h projections (attention.py:152-154: three 1x1 convs reading the same
+    tensor) as ONE launch (msau_attn_proj_bwd, csrc/attention_mfma.hip) instead of three accumulating msau_conv2d launches.
+    Like PairOp not an entry of plan.ops: the ConvOps keep their packed images, weight-gradient launches and bookkeeping; the
+    LAST of the three in backward order (f) emits the fused record, the other two emit no data gradient."""
+
+    def __init__(self, plan: "Plan", f: ConvOp, g: ConvOp, h: ConvOp):
+        self.plan, self.f, self.g, self.h = plan, f, g, h
+        self.active = False
+        self.args = None
+        for c in (f, g, h):
+            c.proj = self
+        plan.projs.append(self)
+
+    def bind(self):
+        """after ConvOp.bind (the three descriptors say what the launches would have done), before late_bind (launch accounting)"""
+        P, f, g, h = self.plan, self.f, self.g, self.h
+        x = f.x1
+        df, dg, dh = f.ddesc[0], g.ddesc[0], h.ddesc[0]
+        if P.dtype != L.BF16 or P.act_flag or os.environ.get("MSAU_ATTN_PROJ_FUSE", "1") == "0" or None in (df, dg, dh):
+            return
+        if not (x.C == x.Cs == 64 and f.out.Cs == g.out.Cs == 8 and h.out.Cs == 64 and f.k == g.k == h.k == 1
+                and g.x1 is x and h.x1 is x and f.x2 is None and g.x2 is None and h.x2 is None
+                and f.dd_off is None and not (f.relu_in or g.relu_in or h.relu_in)):
+            return
+        # what the three launches would have carried, in backward order h, g, f: only the first may write, only the last may mask
+        A, M, D = L.CONV_ACCUM, L.CONV_MASK_B, L.CONV_ADD
+        if (dh.flags & ~(A | D)) or dg.flags != A or (df.flags & ~M) != A:
+            return
+        for c, kch in ((f, 32), (g, 32), (h, 64)):          # the image layout the kernel reads its weight fragments from
+            gd = c._geom(c.out.Cs, 0, x.Cs, 1, 1, 1)
+            if (gd.nchunks, gd.rows, gd.kchunk) != (1, 64, kch):
+                return
+        a = L.AttnProjBwdArgs()
+        a.df, a.dg, a.dh = _ptr(f.out.grad), _ptr(g.out.grad), _ptr(h.out.grad)
+        a.wf_pack, a.wg_pack, a.wh_pack = (P.pack_ptr(c.d_off[0]) for c in (f, g, h))
+        a.add = dh.add if dh.flags & D else None
+        a.mask_b = df.mask_b if df.flags & M else None
+        a.dx, a.npix, a.C, a.accumulate = _ptr(x.grad), x.npix, x.Cs, int(bool(dh.flags & A))
+        self.args, self.active = a, True
+
+    def late_bind(self):
+        if not self.active:
+            return
+        P, x = self.plan, self.f.x1
+        esz = 2
+        nops = 1 + (1 if self.args.add else 0) + self.args.accumulate + (1 if self.args.mask_b else 0)
+        self.key = "attn_proj_bwd<bf16,C64>"
+        self.bytes = x.npix * (self.f.out.Cs + self.g.out.Cs + self.h.out.Cs + nops * x.Cs) * esz
+        self.flops = 2.0 * x.npix * x.C * (self.f.out.C + self.g.out.C + self.h.out.C)
+        P.note_launch(self.key, self.bytes, self.flops)
+
+    def recs(self):
+        self.plan.rec_meta[C.addressof(self.args)] = (self.key, self.bytes)
+        return [(L.OP_ATTN_PROJ_BWD, self.args)]
+
+    def launch(self, s):
+        L.call("msau_attn_proj_bwd", s, self.plan.dtype, C.byref(self.args), key=self.key)
+
+
 class Plan:
     def __init__(self, cfg: dict, B: int, H: int, W: int, dtype: int, device, poff: Dict[str, int],
                  pshape: Dict[str, Tuple[int, ...]], training: bool = True, builder=None):
@@ -1028,6 +1096,7 @@ class Plan:
         self.acts: List[Act] = []
         self.ops: List[Op] = []
         self.pairs: List[PairOp] = []
+        self.projs: List[ProjBwd] = []
         self.box_ops: List["BoxOp"] = []
         self.box_scratch = 0
         self.box_ws_ii = 0
@@ -1171,9 +1240,11 @@ class Plan:
                     fa = Act(self, t + ".f", a.H, a.W, c // 8)
                     ga = Act(self, t + ".g", a.H, a.W, c // 8)
                     ha = Act(self, t + ".h", a.H, a.W, c)
-                    ConvOp(self, t + ".f", x2, None, f"{pa}.f.conv.weight", f"{pa}.f.conv.bias", fa, 1)
-                    ConvOp(self, t + ".g", x2, None, f"{pa}.g.conv.weight", f"{pa}.g.conv.bias", ga, 1)
+                    fop = ConvOp(self, t + ".f", x2, None, f"{pa}.f.conv.weight", f"{pa}.f.conv.bias", fa, 1)
+                    gop = ConvOp(self, t + ".g", x2, None, f"{pa}.g.conv.weight", f"{pa}.g.conv.bias", ga, 1)
                     hop = ConvOp(self, t + ".h", x2, None, f"{pa}.h.conv.weight", f"{pa}.h.conv.bias", ha, 1)
+                    if self.training:
+                        ProjBwd(self, fop, gop, hop)
                     y = Act(self, t + ".attn", a.H, a.W, c)
                     AttnCoreOp(self, t + ".attn", fa, ga, ha, x2, y)
                     hop.bwd_add = y
@@ -1241,10 +1312,14 @@ class Plan:
                 op.bind()
         for pr in self.pairs:
             pr.bind()                    # (before the slab arena exists: a pair that takes over a weight gradient sizes its slabs)
+        for pj in self.projs:
+            pj.bind()
         self.slab_arena = torch.zeros(max(self._slab_elems, 64), dtype=torch.float32, device=self.device)
         for op in self.ops:
             if isinstance(op, ConvOp):
                 op.late_bind()
+        for pj in self.projs:
+            pj.late_bind()
         for pr in self.pairs:
             pr.late_bind()
             pr.note()

@@ -835,3 +835,78 @@ def test_coupling_conv_weight_gradient_in_its_data_gradient_launch(monkeypatch, 
     gz = bf(bf(gy) * (bf(z_r.detach()) > 0))                  # the gradient tensor the launch reads: masked, stored in bf16
     O.conv_same(torch.cat([prev_r, cur_r], 1), wc, bc).backward(gz)
     assert err(res["1"][3]["wc"], wc.grad, False) < 2e-3 and err(res["1"][3]["bc"], bc.grad, False) < 2e-3
+
+
+@pytest.mark.parametrize("hw,B,tail", [((21, 19), 3, False), ((42, 32), 2, True), ((16, 16), 1, True)])
+def test_attention_projection_data_gradients_in_one_launch(monkeypatch, hw, B, tail):
+    """msau_attn_proj_bwd (round 5): d(x) of the attention block's f, g, h projections (model/layers/attention.py:152-154) + the
+    residual's dy + x's ReLU mask in ONE launch instead of three accumulating msau_conv2d launches (MSAU_ATTN_PROJ_FUSE=0).  The
+    fused launch rounds once where the three round three times, so the two agree to a few bf16 ulps, not bit for bit; the sharp check
+    is against float64 on the launch's own stored operands (half a bf16 ulp + fp32 accumulation).  `tail`: x has a later reader, so
+    the launch accumulates onto an earlier contribution (the net's case: the decoder's transposed conv reads the same tensor)."""
+    from msau_amd.plan import AttnCoreOp, ProjBwd
+    torch.manual_seed(43)
+    H, W = hw
+    c = 64
+    x = torch.randn(B, c, H, W)
+    p = {"w0": 0.06 * torch.randn(c, c, 3, 3), "b0": 0.1 * torch.randn(c),
+         "wf": 0.15 * torch.randn(8, c, 1, 1), "bf": 0.1 * torch.randn(8), "wg": 0.15 * torch.randn(8, c, 1, 1), "bg": 0.1 * torch.randn(8),
+         "wh": 0.12 * torch.randn(c, c, 1, 1), "bh": 0.1 * torch.randn(c),
+         "wt": 0.12 * torch.randn(c, c, 1, 1), "bt": 0.1 * torch.randn(c), "wz": 0.1 * torch.randn(8, 2 * c, 1, 1), "bz": 0.1 * torch.randn(8)}
+    if not tail:
+        p["wz"] = 0.1 * torch.randn(8, c, 1, 1)
+        del p["wt"], p["bt"]
+    gy = torch.randn(B, 8, H, W)
+    keep = {}
+
+    def build(plan):
+        x2 = Act(plan, "x2", H, W, c, relu_out=True)
+        ConvOp(plan, "c0", plan.x_in, None, "w0", "b0", x2, 3, relu_out=True)
+        fa, ga, ha = Act(plan, "f", H, W, 8), Act(plan, "g", H, W, 8), Act(plan, "h", H, W, c)
+        fop = ConvOp(plan, "f", x2, None, "wf", "bf", fa, 1)
+        gop = ConvOp(plan, "g", x2, None, "wg", "bg", ga, 1)
+        hop = ConvOp(plan, "h", x2, None, "wh", "bh", ha, 1)
+        pj = ProjBwd(plan, fop, gop, hop)
+        y = Act(plan, "y", H, W, c)
+        AttnCoreOp(plan, "attn", fa, ga, ha, x2, y)
+        hop.bwd_add = y
+        z = Act(plan, "z", H, W, 8)
+        if tail:
+            t = Act(plan, "t", H, W, c)
+            ConvOp(plan, "t", x2, None, "wt", "bt", t, 1)
+            ConvOp(plan, "z", y, t, "wz", "bz", z, 1)
+        else:
+            ConvOp(plan, "z", y, None, "wz", "bz", z, 1)
+        plan.logits = z
+        keep[os.environ["MSAU_ATTN_PROJ_FUSE"]] = (pj, x2, fa, ga, ha, y)
+    res = {}
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MSAU_ATTN_PROJ_FUSE", mode)
+            res[mode] = run_graph(build, p, x, gy, L.BF16)
+    finally:
+        monkeypatch.undo()
+    assert keep["1"][0].active and not keep["0"][0].active
+    assert bool(keep["1"][0].args.accumulate) == tail and keep["1"][0].args.add and keep["1"][0].args.mask_b
+    assert torch.equal(res["1"][0], res["0"][0])                                   # (the forward is the same launches)
+    # fused against the three launches: a few bf16 ulps on d(x2), carried through c0's data / weight gradient
+    assert err(res["1"][2], res["0"][2], True) < 6e-3
+    for n in res["1"][3]:
+        if n in ("w0", "b0"):
+            assert err(res["1"][3][n], res["0"][3][n], True) < 6e-3, n
+        else:
+            assert torch.equal(res["1"][3][n], res["0"][3][n]), n
+    if not tail:
+        # float64 on the stored operands of the launch: d(x2) = (Wf^T df + Wg^T dg + Wh^T dh + dy) * (x2 > 0)
+        pj, x2, fa, ga, ha, y = keep["1"]
+        bfw = lambda k: p[k].to(torch.bfloat16).double().view(p[k].shape[0], c)
+        d = lambda a: a.grad.double().cpu().view(-1, a.Cs)
+        terms = [d(fa) @ bfw("wf"), d(ga) @ bfw("wg"), d(ha) @ bfw("wh"), d(y)]
+        S = d(fa).abs() @ bfw("wf").abs() + d(ga).abs() @ bfw("wg").abs() + d(ha).abs() @ bfw("wh").abs() + d(y).abs()
+        mask = (x2.data.double().cpu().view(-1, c) > 0)
+        ref = sum(terms) * mask
+        got = x2.grad.double().cpu().view(-1, c)
+        ulp = torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 7)
+        excess = (got - ref).abs() - (0.5 * ulp * (1 + 1e-6) + 3e-6 * S + 1e-30)
+        assert float(excess.max()) <= 0, float(excess.max())
+        assert float((got != 0).double().mean()) > 0.2
