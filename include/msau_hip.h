@@ -44,7 +44,7 @@ const char* msau_source_hash(void);
  * makes the library read past it): which = 0 msau_conv_desc, 1 msau_wgrad_desc, 2 msau_pack_entry, 3 msau_unpack_entry,
  * 4 msau_op, 5 msau_lrn_args, 6 msau_pool_args, 7 msau_attn_args, 8 msau_csum_args, 9 msau_reduce_args,
  * 10 msau_conv_pack_geom, 11 msau_wgrad_geom, 12 msau_conv_pair_desc, 13 msau_box_args, 14 msau_allreduce_args, 15 msau_owner_ctx,
- * 16 msau_attn_proj_bwd_args;
+ * 16 msau_attn_proj_bwd_args, 17 msau_dgrad2_args;
  * -1 for anything else. */
 int msau_sizeof(int which);
 /* LDS strides (bytes) the tile kernels give a pixel of `raw_bytes` channels / a weight row of `nks` 32-deep k-steps (csrc/msau_common.h:
@@ -425,6 +425,22 @@ typedef struct {
 } msau_attn_proj_bwd_args;
 int msau_attn_proj_bwd(void* stream, int dtype, const msau_attn_proj_bwd_args* a);
 
+/* The two data gradients of a 1x1 conv over concat(x1, x2) with 64 + 64 input channels (the coupling conv of a coupled stage at the
+ * bottleneck level, model/model.py:143-148) as ONE launch -- the 64-channel counterpart of MSAU_CONV_DOUT, which the tile / row kernels
+ * implement up to 32 + 32:
+ *   dx1 = [mask1 > 0 ?] (W1^T g [+ dx1_old]),   dx2 = [mask2 > 0 ?] (W2^T g [+ dx2_old])
+ * w1_pack / w2_pack: the packed data-gradient images of the two sources exactly as msau_conv2d takes them
+ * (msau_conv_pack_geometry(dtype, 64, 0, 64, 1, 1, 1, 1, 1): one chunk, 64 rows, kchunk 64).  bf16, C = 64 only. */
+typedef struct {
+    const void* g;                                          /* [npix][C]: gradient of the conv's output (already masked by its ReLU) */
+    const void* w1_pack; const void* w2_pack;
+    void* dx1; void* dx2;                                   /* [npix][C] each */
+    const void* mask1; const void* mask2;                   /* [npix][C] or NULL */
+    int64_t npix;
+    int32_t C, accumulate1, accumulate2, reserved;
+} msau_dgrad2_args;
+int msau_dgrad2_1x1(void* stream, int dtype, const msau_dgrad2_args* a);
+
 /* ------------------------------------------------------------------------------------------
  * Masked cross entropy (model/model.py:446-459) with the batch rule of SURVEY 8(e):
  *   loss = scale * sum_b 1/max(cnt_b,1) * sum_{p: label!=0} -log softmax(logits_p)[label_p]
@@ -552,7 +568,8 @@ enum {
     MSAU_OP_BOX_FWD = 12,    /* args: msau_box_args           */
     MSAU_OP_BOX_BWD = 13,    /* args: msau_box_args           */
     MSAU_OP_ALLREDUCE = 14,  /* args: msau_allreduce_args     */
-    MSAU_OP_ATTN_PROJ_BWD = 15 /* args: msau_attn_proj_bwd_args */
+    MSAU_OP_ATTN_PROJ_BWD = 15, /* args: msau_attn_proj_bwd_args */
+    MSAU_OP_DGRAD2_1X1 = 16  /* args: msau_dgrad2_args        */
 };
 typedef struct { int32_t kind; int32_t dtype; const void* args; } msau_op;
 typedef struct { const void* a; const void* dy; void* out; int64_t npix; int32_t C, Cs, n; float alpha, beta, k; } msau_lrn_args;

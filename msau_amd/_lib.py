@@ -117,6 +117,11 @@ class AttnProjBwdArgs(C.Structure):
                [("npix", i64), ("C", i32), ("accumulate", i32)]
 
 
+class Dgrad2Args(C.Structure):
+    _fields_ = [(n, vp) for n in ("g", "w1_pack", "w2_pack", "dx1", "dx2", "mask1", "mask2")] + \
+               [("npix", i64), ("C", i32), ("accumulate1", i32), ("accumulate2", i32), ("reserved", i32)]
+
+
 OP_SIDE = 0x100
 OP_PROBE = 0x200
 OP_COMM = 0x400
@@ -126,6 +131,7 @@ OP_WGRAD_REDUCE = 10
 OP_CONV_PAIR = 11
 OP_BOX_FWD, OP_BOX_BWD = 12, 13
 OP_ATTN_PROJ_BWD = 15
+OP_DGRAD2_1X1 = 16
 OP_CONV2D, OP_WGRAD, OP_LRN_FWD, OP_LRN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_CHANNEL_SUM = range(1, 10)
 
 _SIGNATURES = {
@@ -139,6 +145,7 @@ _SIGNATURES = {
     "msau_conv2d": (C.c_int, [vp, C.c_int, C.POINTER(ConvDesc)]),
     "msau_conv2d_rider_slabs": (C.c_int, [C.c_int, C.POINTER(ConvDesc)]),
     "msau_attn_proj_bwd": (C.c_int, [vp, C.c_int, C.POINTER(AttnProjBwdArgs)]),
+    "msau_dgrad2_1x1": (C.c_int, [vp, C.c_int, C.POINTER(Dgrad2Args)]),
     "msau_conv2d_launch_info": (C.c_int, [C.c_int, C.POINTER(ConvDesc), C.POINTER(i32)]),
     "msau_conv_pair_applicable": (C.c_int, [C.c_int, C.POINTER(ConvPairDesc)]),
     "msau_conv_pair": (C.c_int, [vp, C.c_int, C.POINTER(ConvPairDesc)]),
@@ -209,7 +216,7 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 # ctypes mirrors in the order of msau_sizeof(which): load() refuses a library whose structs have another size
 ABI_STRUCTS = (ConvDesc, WgradDesc, PackEntry, UnpackEntry, Op, LrnArgs, PoolArgs, AttnArgs, CsumArgs, ReduceArgs,
-               ConvPackGeom, WgradGeom, ConvPairDesc, BoxArgs, AllreduceArgs, OwnerCtx, AttnProjBwdArgs)
+               ConvPackGeom, WgradGeom, ConvPairDesc, BoxArgs, AllreduceArgs, OwnerCtx, AttnProjBwdArgs, Dgrad2Args)
 
 
 class MsauHipError(RuntimeError):

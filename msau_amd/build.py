@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmsau_hip.so")
-SOURCES = ["pack.hip", "conv.hip", "conv_lean.hip", "conv_first.hip", "conv_pair.hip", "conv_rows.hip", "conv_wgrad.hip", "wgrad_lean.hip", "elementwise.hip", "attention.hip", "attention_mfma.hip", "raster.hip", "boxconv.hip", "sequence.hip", "comm.hip", "ownerconv.hip"]
+SOURCES = ["pack.hip", "conv.hip", "conv_lean.hip", "conv_first.hip", "conv_pair.hip", "conv_rows.hip", "conv_wgrad.hip", "wgrad_lean.hip", "elementwise.hip", "attention.hip", "attention_mfma.hip", "pointwise.hip", "raster.hip", "boxconv.hip", "sequence.hip", "comm.hip", "ownerconv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"] + os.environ.get("MSAU_EXTRA_HIPCC_FLAGS", "").split() + [
          "-ffp-contract=fast"]
 
@@ -37,6 +37,7 @@ EXTRA_FLAGS = {"elementwise.hip": ["-Xclang", "-target-feature", "-Xclang", "-pa
                # attention on the matrix cores: MFMA results in VGPRs as well (the statistics kernel read every score back with
                # v_accvgpr_read: a quarter of its vector instructions)
                "attention_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "pointwise.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
                "conv_rows.hip": ["-std=c++20"] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.environ.get("MSAU_ROWS_VGPR_FORM", "1") != "0" else [])
                                 + (["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] if os.environ.get("MSAU_ROWS_PACKED_FP32", "0") != "1" else [])
                                 + (["-DMSAU_ROWCONV_PF=" + os.environ["MSAU_ROWCONV_PF"]] if os.environ.get("MSAU_ROWCONV_PF") else [])}

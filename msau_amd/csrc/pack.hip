@@ -40,6 +40,7 @@ extern "C" int msau_sizeof(int which) {
         case 14: return (int)sizeof(msau_allreduce_args);
         case 15: return (int)sizeof(msau_owner_ctx);
         case 16: return (int)sizeof(msau_attn_proj_bwd_args);
+        case 17: return (int)sizeof(msau_dgrad2_args);
         default: return -1;
     }
 }

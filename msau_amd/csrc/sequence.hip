@@ -241,6 +241,7 @@ static int run_one_raw(void* stream, const msau_op& o, int i) {
             case MSAU_OP_BOX_FWD: rc = msau_box_fwd(stream, o.dtype, static_cast<const msau_box_args*>(o.args)); break;
             case MSAU_OP_BOX_BWD: rc = msau_box_bwd(stream, o.dtype, static_cast<const msau_box_args*>(o.args)); break;
             case MSAU_OP_ATTN_PROJ_BWD: rc = msau_attn_proj_bwd(stream, o.dtype, static_cast<const msau_attn_proj_bwd_args*>(o.args)); break;
+            case MSAU_OP_DGRAD2_1X1: rc = msau_dgrad2_1x1(stream, o.dtype, static_cast<const msau_dgrad2_args*>(o.args)); break;
             case MSAU_OP_LRN_FWD: {
                 const msau_lrn_args* a = static_cast<const msau_lrn_args*>(o.args);
                 rc = msau_lrn_fwd(stream, o.dtype, a->a, a->out, a->npix, a->C, a->Cs, a->n, a->alpha, a->beta, a->k);

@@ -111,6 +111,7 @@ class ConvOp(Op):
         self.cpl: Optional["ConvOp"] = None         # on a pair's second conv: the coupling 1x1 conv that reads its output (may ride on the launch)
         self.cpl_fused_into: Optional["PairOp"] = None   # on a coupling conv: the pair whose forward launch computes it (MSAU_PAIR_COUPLE)
         self.proj: Optional["ProjBwd"] = None       # on an attention projection: the fused data-gradient launch of f, g, h
+        self.dgrad2 = None                          # a 64 + 64-channel 1x1 conv: both data gradients in one launch (msau_dgrad2_1x1)
         if kind == "conv" and k == 1 and x2 is not None and relu_out and not relu_in and fwd_add is None and plan.ops:
             prod = plan.ops[-1]
             if isinstance(prod, ConvOp) and prod.out is x2 and prod.pair is not None and prod is prod.pair.c2 \
@@ -327,6 +328,23 @@ class ConvOp(Op):
             dd.flags = fl
             dd.x1, dd.wpack, dd.bias, dd.y = _ptr(out.grad), P.pack_ptr(self.d_off[si]), None, _ptr(x.grad)
             self.ddesc[si] = dd
+        # a 1x1 conv over concat(x1, x2) at 64 + 64 channels (the bottleneck level's coupling conv): both data gradients in one launch
+        # (msau_dgrad2_1x1, csrc/pointwise.hip) -- MSAU_CONV_DOUT has instances up to 32 + 32
+        self.dgrad2 = None
+        d1, d2 = self.ddesc
+        if conv and self.k == 1 and x2 is not None and self.dd_off is None and d1 is not None and d2 is not None \
+                and P.dtype == L.BF16 and not P.act_flag and x1.C == x1.Cs == x2.C == x2.Cs == out.Cs == 64 \
+                and not ((d1.flags | d2.flags) & ~(L.CONV_ACCUM | L.CONV_MASK_B)) and os.environ.get("MSAU_DGRAD2", "1") != "0":
+            geo = [self._geom(out.Cs, 0, x.Cs, 1, 1, 1) for x in (x1, x2)]
+            if all((gq.nchunks, gq.rows, gq.kchunk) == (1, 64, 64) for gq in geo):
+                a = L.Dgrad2Args()
+                a.g, a.w1_pack, a.w2_pack = _ptr(out.grad), P.pack_ptr(self.d_off[0]), P.pack_ptr(self.d_off[1])
+                a.dx1, a.dx2 = _ptr(x1.grad), _ptr(x2.grad)
+                a.mask1 = d1.mask_b if d1.flags & L.CONV_MASK_B else None
+                a.mask2 = d2.mask_b if d2.flags & L.CONV_MASK_B else None
+                a.npix, a.C = out.npix, 64
+                a.accumulate1, a.accumulate2 = int(bool(d1.flags & L.CONV_ACCUM)), int(bool(d2.flags & L.CONV_ACCUM))
+                self.dgrad2 = a
         # ---- weight gradient
         w = L.WgradDesc()
         w.B = P.B
@@ -441,8 +459,13 @@ class ConvOp(Op):
                 src_c = (self.x1.C + self.x2.C) if self.dd_off is not None else (self.x1, self.x2)[si].C
                 fl = 2.0 * P.B * (self.out.H * self.out.W if self.kind == "conv" else self.x1.H * self.x1.W) * taps * src_c * self.out.C
                 self.dmeta[si] = conv_meta(dd)
-                if self.proj is None or not self.proj.active:
+                if (self.proj is None or not self.proj.active) and self.dgrad2 is None:
                     P.note_launch(self.dmeta[si][0], self.dmeta[si][1], fl)
+        if self.dgrad2 is not None:
+            a = self.dgrad2
+            nops = 3 + a.accumulate1 + a.accumulate2 + (1 if a.mask1 else 0) + (1 if a.mask2 else 0)
+            self.d2meta = ("dgrad2_1x1<bf16,C64>", self.out.npix * 64 * nops * esz)
+            P.note_launch(self.d2meta[0], self.d2meta[1], 2.0 * self.out.npix * 128 * self.out.C)
         if self.wdesc is not None:
             w, wg = self.wdesc, self.wgeom
             ctn = -(-w.Cout // 16)
@@ -505,6 +528,9 @@ class ConvOp(Op):
             return recs
         if self.proj is not None and self.proj.active:  # f, g, h of an attention block: one launch, behind the last of the three
             return recs + (self.proj.recs() if self is self.proj.f else [])
+        if self.dgrad2 is not None:
+            rm[C.addressof(self.dgrad2)] = self.d2meta
+            return recs + [(L.OP_DGRAD2_1X1, self.dgrad2)]
         for si, dd in enumerate(self.ddesc):
             if dd is not None:
                 rm[C.addressof(dd)] = self.dmeta[si]
@@ -532,6 +558,9 @@ class ConvOp(Op):
         if self.proj is not None and self.proj.active:
             if self is self.proj.f:
                 self.proj.launch(s)
+            return
+        if self.dgrad2 is not None:
+            L.call("msau_dgrad2_1x1", s, P.dtype, C.byref(self.dgrad2), key=self.d2meta[0])
             return
         for si, dd in enumerate(self.ddesc):
             if dd is not None:

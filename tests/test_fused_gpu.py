@@ -910,3 +910,64 @@ def test_attention_projection_data_gradients_in_one_launch(monkeypatch, hw, B, t
         excess = (got - ref).abs() - (0.5 * ulp * (1 + 1e-6) + 3e-6 * S + 1e-30)
         assert float(excess.max()) <= 0, float(excess.max())
         assert float((got != 0).double().mean()) > 0.2
+
+
+@pytest.mark.parametrize("hw,B,later", [((21, 19), 3, False), ((42, 32), 2, True)])
+def test_both_data_gradients_of_the_64_channel_coupling_conv_in_one_launch(monkeypatch, hw, B, later):
+    """msau_dgrad2_1x1 (round 5): d(prev), d(y) of z = ReLU(Wc concat(prev, y) + bc) (model/model.py:143-148) at 64 + 64 channels in
+    one launch against the two msau_conv2d launches (MSAU_DGRAD2=0): the same rounded weights, the same k order per output, one
+    rounding each -> bit for bit, masks and accumulation included.  `later`: both sources have a later reader (their gradient
+    buffers already hold a contribution: the launch accumulates)."""
+    torch.manual_seed(47)
+    H, W = hw
+    c = 64
+    x = torch.randn(B, c, H, W)
+    p = {"w0": 0.12 * torch.randn(c, c, 1, 1), "b0": 0.1 * torch.randn(c), "w1": 0.05 * torch.randn(c, c, 3, 3), "b1": 0.1 * torch.randn(c),
+         "wc": 0.1 * torch.randn(c, 2 * c, 1, 1), "bc": 0.1 * torch.randn(c), "wz": 0.1 * torch.randn(8, (3 if later else 1) * c, 1, 1), "bz": 0.1 * torch.randn(8)}
+    gy = torch.randn(B, 8, H, W)
+    seen = []
+
+    def build(plan):
+        prev = Act(plan, "prev", H, W, c)
+        ConvOp(plan, "c0", plan.x_in, None, "w0", "b0", prev, 1)
+        cur = Act(plan, "cur", H, W, c, relu_out=True)
+        ConvOp(plan, "c1", plan.x_in, None, "w1", "b1", cur, 3, relu_out=True)
+        z = Act(plan, "z", H, W, c, relu_out=True)
+        seen.append(ConvOp(plan, "cpl", prev, cur, "wc", "bc", z, 1, relu_out=True))
+        out = Act(plan, "out", H, W, 8)
+        if later:
+            cat = Act(plan, "pc", H, W, 2 * c)                   # a later reader of prev and cur: 128 -> ... via two more convs
+            ConvOp(plan, "pc", prev, cur, "wpc", "bpc", cat, 1)
+            ConvOp(plan, "zc", z, cat, "wz", "bz", out, 1)
+        else:
+            ConvOp(plan, "zc", z, None, "wz", "bz", out, 1)
+        plan.logits = out
+    if later:
+        p["wpc"], p["bpc"] = 0.1 * torch.randn(2 * c, 2 * c, 1, 1), 0.1 * torch.randn(2 * c)
+    res = {}
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MSAU_DGRAD2", mode)
+            res[mode] = run_graph(build, p, x, gy, L.BF16)
+    finally:
+        monkeypatch.undo()
+    assert seen[0].dgrad2 is not None and seen[1].dgrad2 is None
+    assert bool(seen[0].dgrad2.accumulate1) == later and bool(seen[0].dgrad2.accumulate2) == later and seen[0].dgrad2.mask2 and not seen[0].dgrad2.mask1
+    assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][2], res["0"][2])
+    for n in res["1"][3]:
+        assert torch.equal(res["1"][3][n], res["0"][3][n]), n
+    # and against torch autograd in fp32 (bf16 storage: relative L2)
+    xs = x.clone().requires_grad_(True)
+    ps = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    prev = O.conv_same(xs, ps["w0"], ps["b0"])
+    cur = O.conv_same(xs, ps["w1"], ps["b1"], relu=True)
+    z = O.conv_same(torch.cat([prev, cur], 1), ps["wc"], ps["bc"], relu=True)
+    if later:
+        out = O.conv_same(torch.cat([z, O.conv_same(torch.cat([prev, cur], 1), ps["wpc"], ps["bpc"])], 1), ps["wz"], ps["bz"])
+    else:
+        out = O.conv_same(z, ps["wz"], ps["bz"])
+    out.backward(gy)
+    # (a sanity bound: two ReLU layers in bf16 storage against fp32 -- the sharp statement is the bit equality above)
+    assert err(res["1"][2], xs.grad, True) < 1e-1
+    for n in ("w0", "w1", "wc"):
+        assert err(res["1"][3][n], ps[n].grad, True) < 1e-1, n

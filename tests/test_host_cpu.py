@@ -308,7 +308,7 @@ def test_isa_of_the_built_kernels_has_no_cross_half_packed_fp32_adds(tmp_path):
         lines = [ln for ln in dis.splitlines() if pk.search(ln)]
         counts[name] = (len(lines), sum(1 for ln in lines if "op_sel" in ln))
     assert counts["elementwise"] == (0, 0), counts["elementwise"]
-    clean = ("conv", "conv_lean", "conv_pair", "conv_rows", "wgrad_lean", "conv_wgrad", "attention_mfma", "pack", "raster", "ownerconv", "boxconv")
+    clean = ("conv", "conv_lean", "conv_pair", "conv_rows", "wgrad_lean", "conv_wgrad", "attention_mfma", "pointwise", "pack", "raster", "ownerconv", "boxconv")
     assert all(counts[n][1] == 0 for n in clean), {n: counts[n] for n in clean}
     assert counts["conv_lean"][0] > 0                 # the check does see packed instructions where they are
     assert counts["boxconv"] == (0, 0), counts["boxconv"]       # (built without the instructions altogether, like elementwise)
