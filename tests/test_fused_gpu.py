@@ -912,7 +912,7 @@ def test_attention_projection_data_gradients_in_one_launch(monkeypatch, hw, B, t
         assert float((got != 0).double().mean()) > 0.2
 
 
-@pytest.mark.parametrize("hw,B,later", [((21, 19), 3, False), ((42, 32), 2, True)])
+@pytest.mark.parametrize("hw,B,later", [((21, 19), 3, False), ((42, 32), 2, True), ((96, 96), 8, False)])   # (the last: more tiles than the grid has waves)
 def test_both_data_gradients_of_the_64_channel_coupling_conv_in_one_launch(monkeypatch, hw, B, later):
     """msau_dgrad2_1x1 (round 5): d(prev), d(y) of z = ReLU(Wc concat(prev, y) + bc) (model/model.py:143-148) at 64 + 64 channels in
     one launch against the two msau_conv2d launches (MSAU_DGRAD2=0): the same rounded weights, the same k order per output, one
