@@ -217,9 +217,9 @@ enum { MSAU_PAIR_RELU_IN = 1, MSAU_PAIR_RELU_MID = 2, MSAU_PAIR_MASK_MID = 4,
                                    computed from the storage-rounded y exactly as the stand-alone 1x1 launch reads it; y itself is still
                                    written (the backward reads it).  cpl_w / cpl_b = the packed image / bias msau_pack_params writes
                                    for a 1x1 conv over concat(C, C) -> C.  With cpl_pool_y != NULL also the zero-padded MaxPool2d(2,2)
-                                   of z (cpl_pool_idx: the 1-byte positions, may be NULL), as MSAU_CONV_POOL does for y.  Row-streaming
-                                   8- and 16-channel instances only (msau_conv_pair_applicable says so); not together with
-                                   MSAU_CONV_POOL in flags2. */
+                                   of z (cpl_pool_idx: the 1-byte positions, may be NULL), as MSAU_CONV_POOL does for y.  The row-streaming
+                                   8- and 16-channel instances and the 32-channel bf16 tile pair have it (msau_conv_pair_applicable
+                                   says so); not together with MSAU_CONV_POOL in flags2. */
        MSAU_PAIR_TILES = 8 };   /* take the tile kernels (conv_pair.hip) even where the row-streaming kernel has an instance: the
                                    forward and the backward launch of one block must agree on the layout of the mask planes, so a
                                    caller whose forward carries a flag only the tile kernels implement (MSAU_CONV_POOL) sets this on

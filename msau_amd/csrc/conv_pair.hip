@@ -120,9 +120,15 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned of
 // BITS: the ReLU masks travel as bit planes ([B][H][W][C/8] bytes: one bit per element) -- the forward launch writes the
 // planes of its input (x > 0) and of its intermediate (mid > 0), the backward launch reads them instead of re-reading the
 // two bf16 tensors for one bit per element (110 -> 69 MB per backward launch at level 0).
-template <typename T, int C8, int TW, bool BWD, bool POOL = false, bool BITS = false, int RPW = 4>
+// CPL (MSAU_PAIR_COUPLE, 32 channels): the coupling conv z = ReLU(Wc concat(prev, y) + bc) of a coupled stage (model/model.py:143-148,
+// 246-252) in the forward launch's second epilogue; 2 = its max-pooled output as well (the encoder levels, model.py:158-160).  With two
+// channel tiles the epilogue's result layout IS the MFMA's B-fragment layout -- a lane holds channels 8 lg .. 8 lg + 7 of its pixel -- so
+// the rounded y goes from the epilogue's registers straight into the 1x1 conv: two MFMAs per channel tile and row (prev, then y: the
+// stand-alone launch's chunk order), `prev` one 16-byte load per lane and row issued ahead of the tile's phases, no LDS.
+template <typename T, int C8, int TW, bool BWD, bool POOL = false, bool BITS = false, int RPW = 4, int CPL = 0>
 __global__ __launch_bounds__((PairCfg<T, C8, TW, BWD, RPW>::NT)) void conv_pair_kernel(const PairArgs a) {
     static_assert(!(BWD && POOL), "the pooled output belongs to the forward launch");
+    static_assert(CPL == 0 || (!BWD && !POOL && C8 == 4 && sizeof(T) == 2), "the coupling rider: forward, 32 channels, bf16");
     static_assert(RPW == 4 || RPW == 2, "rows per wave");
     using Cfg = PairCfg<T, C8, TW, BWD, RPW>;
     typedef typename Vec8<T>::type V8;
@@ -274,6 +280,18 @@ __global__ __launch_bounds__((PairCfg<T, C8, TW, BWD, RPW>::NT)) void conv_pair_
             }
         }
     };
+    // the coupling conv's weights: packed forward image [chunk: prev, y][32 rows][32 k] (msau_conv_pack_geometry(32, 32, 32, 1x1)), bias
+    V8 cA[CPL ? 2 : 1][CPL ? CT : 1];
+    f32x4 cbias[CPL ? CT : 1];
+    if constexpr (CPL != 0) {
+        const T* cw = static_cast<const T*>(d.cpl_w);
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) cA[ch][ct] = load8<T>(cw + ((ch * CT + ct) * 16 + lr) * 32 + lg * 8);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) cbias[ct] = *reinterpret_cast<const f32x4*>(d.cpl_b + ch0 + ct * 4);
+    }
     int tile0 = blockIdx.x, tend = a.ntiles, tstep = gridDim.x;
     if (a.per_xcd) {
         const int xcd = blockIdx.x & 7;
@@ -294,10 +312,20 @@ __global__ __launch_bounds__((PairCfg<T, C8, TW, BWD, RPW>::NT)) void conv_pair_
     for (int tile = tile0; tile < tend; tile += tstep) {
         int b, ty0, tx0;
         decode(tile, b, ty0, tx0);
+        const long long img = (long long)b * img_bytes;
+        // the coupling conv's first source at this lane's output pixels, k-group lg (ahead of the next tile's prefetch: vmcnt retires in order)
+        V8 cprev[CPL ? RPW : 1];
+        if constexpr (CPL != 0) {
+            const __amdgpu_buffer_rsrc_t rprev = image_rsrc(static_cast<const char*>(d.cpl_prev) + img, img_bytes);
+#pragma unroll
+            for (int pt = 0; pt < RPW; ++pt) {
+                const int yy = ty0 + wave * RPW + pt, xx = tx0 + jcol;
+                cprev[pt] = buf_load8<T>(rprev, (yy < H && xx < W) ? (unsigned)(yy * a.row + xx * a.px + lg * 8 * ESZ) : kOOB);
+            }
+        }
         // the next tile's loads fly during both phases; they are waited for at the bottom, BEHIND this tile's stores
         issue_loads(tile + tstep, tile + tstep < tend);
 
-        const long long img = (long long)b * img_bytes;
         const __amdgpu_buffer_rsrc_t rmid = image_rsrc(static_cast<char*>(d.mid) + img, img_bytes);
         const __amdgpu_buffer_rsrc_t ry = image_rsrc(static_cast<char*>(d.y) + img, img_bytes);
         // ================= phase 1: intermediate on the 16 x IW lattice, image position (ty0-1+i, tx0-1+j) ===========
@@ -452,13 +480,16 @@ __global__ __launch_bounds__((PairCfg<T, C8, TW, BWD, RPW>::NT)) void conv_pair_
             // the residual (forward) / other-path gradient (backward) operand is the input tensor itself: read it back
             // from the raw LDS input tile, position (oy + 2, ox + 2); lanes without channels read slot 0
             const int xt_lane = ch_ok ? (2 * XW + jcol + 2) * PS + ch0 * ESZ : 0;
-            V4 keep[POOL ? CT : 1][RPW];                                     // MSAU_CONV_POOL: the rounded results, 0 where nothing is stored
+            constexpr bool PL = POOL || CPL == 2;                            // a pooled output: of y, or of the coupling conv's z
+            V4 keep[PL ? CT : 1][RPW];                                       // MSAU_CONV_POOL: the rounded results, 0 where nothing is stored
+            const __amdgpu_buffer_rsrc_t rz = image_rsrc(CPL ? static_cast<char*>(d.cpl_y) + img : nullptr, CPL ? img_bytes : 0u);
 #pragma unroll
             for (int pt = 0; pt < RPW; ++pt) {
                 const int oy = wave * RPW + pt;                  // wave-uniform
                 const int yy = ty0 + oy;
                 const bool ok = colok && oy < Cfg::OH && yy < H;
                 const unsigned goff = (unsigned)(yy * a.row + tx0 * a.px + lane_c);
+                V4 yv[CT];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     const V4 r = *reinterpret_cast<const V4*>(xt + xt_lane + (ch_ok ? oy * XW * PS + ct * 4 * ESZ : 0));
@@ -476,24 +507,45 @@ __global__ __launch_bounds__((PairCfg<T, C8, TW, BWD, RPW>::NT)) void conv_pair_
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) ov[jj] = (T)v[jj];
                     buf_store4(ry, ok ? goff + ct * 4 * ESZ : kOOB, ov);
+                    yv[ct] = ov;
                     if constexpr (POOL) {
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) keep[ct][pt][jj] = ok ? ov[jj] : (T)0.f;
+                    }
+                }
+                if constexpr (CPL != 0) {
+                    // z = ReLU(Wc[:, prev] prev + Wc[:, y] y + bc): the rounded y of this lane IS the B fragment (channels 8 lg .. 8 lg + 7)
+                    const V8 by = __builtin_shufflevector(yv[0], yv[CT - 1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        f32x4 zv = mma8(cA[0][ct], cprev[pt], f32x4{0.f, 0.f, 0.f, 0.f});
+                        zv = mma8(cA[1][ct], by, zv);
+                        zv += cbias[ct];
+                        V4 zo;
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) zo[jj] = (T)fmaxf(zv[jj], 0.f);
+                        buf_store4(rz, ok ? goff + ct * 4 * ESZ : kOOB, zo);
+                        if constexpr (CPL == 2) {
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) keep[ct][pt][jj] = ok ? zo[jj] : (T)0.f;
+                        }
                     }
                 }
             }
             // MaxPool2d(2,2) of the zero-padded output (MSAU_CONV_POOL, model/model.py:158-160): tile origins are even, a
             // window is rows (2pp, 2pp + 1) of this lane and of its neighbour column lr ^ 1; even lanes write.  Same order
             // of comparisons (first maximum wins) and the same rounded values as msau_maxpool2x2_fwd on y.
-            if constexpr (POOL) {
+            if constexpr (PL) {
                 {
                     const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
                     constexpr int ND = (int)sizeof(V4) / 4;
                     typedef int dwords __attribute__((ext_vector_type(ND)));
                     const unsigned pimg = (unsigned)Ho * (unsigned)Wo * (unsigned)a.px;
-                    const __amdgpu_buffer_rsrc_t rp = image_rsrc(static_cast<char*>(d.pool_y) + (long long)b * pimg, pimg);
-                    const __amdgpu_buffer_rsrc_t ri = image_rsrc(d.pool_idx ? d.pool_idx + (long long)b * (pimg / ESZ) : nullptr,
-                                                                 d.pool_idx ? pimg / ESZ : 0u);
+                    void* const pool_y = CPL == 2 ? d.cpl_pool_y : d.pool_y;
+                    uint8_t* const pool_idx = CPL == 2 ? d.cpl_pool_idx : d.pool_idx;
+                    const __amdgpu_buffer_rsrc_t rp = image_rsrc(static_cast<char*>(pool_y) + (long long)b * pimg, pimg);
+                    const __amdgpu_buffer_rsrc_t ri = image_rsrc(pool_idx ? pool_idx + (long long)b * (pimg / ESZ) : nullptr,
+                                                                 pool_idx ? pimg / ESZ : 0u);
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
@@ -542,7 +594,7 @@ __global__ __launch_bounds__((PairCfg<T, C8, TW, BWD, RPW>::NT)) void conv_pair_
 #endif
 }
 
-template <typename T, int C8, int TW, bool BWD, bool POOL = false, bool BITS = false, int RPW = 4>
+template <typename T, int C8, int TW, bool BWD, bool POOL = false, bool BITS = false, int RPW = 4, int CPL = 0>
 int launch_pair(hipStream_t s, const PairArgs& a0) {
     using Cfg = PairCfg<T, C8, TW, BWD, RPW>;
     static_assert(Cfg::LDS + Cfg::LDS_PAD + 256 <= MSAU_LDS_LIMIT, "conv_pair instance does not fit the LDS");
@@ -554,7 +606,7 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
     a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS + Cfg::LDS_PAD > 60 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD, POOL, BITS, RPW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD, POOL, BITS, RPW, CPL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_pair: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -565,7 +617,7 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
     if (!per_cu) {
         // (hipOccupancyMaxActiveBlocksPerMultiprocessor budgets 64 KB of LDS per CU, not gfx950's 160 KB: compute it here)
         hipFuncAttributes fa;
-        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD, POOL, BITS, RPW>));
+        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD, POOL, BITS, RPW, CPL>));
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_pair: hipFuncGetAttributes: %s", hipGetErrorString(e));
         const int vgprs = ((fa.numRegs > 0 ? fa.numRegs : 64) + 7) & ~7;
         int waves_per_simd = 512 / vgprs;                      // 512 VGPRs per SIMD lane, 8 waves at most
@@ -585,7 +637,7 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
         grid &= ~7;
         a.per_xcd = cdiv(a.ntiles, 8);
     }
-    hipLaunchKernelGGL((conv_pair_kernel<T, C8, TW, BWD, POOL, BITS, RPW>), dim3(grid), dim3(Cfg::NT), Cfg::LDS + Cfg::LDS_PAD, s, a);
+    hipLaunchKernelGGL((conv_pair_kernel<T, C8, TW, BWD, POOL, BITS, RPW, CPL>), dim3(grid), dim3(Cfg::NT), Cfg::LDS + Cfg::LDS_PAD, s, a);
     MSAU_CHECK_LAUNCH("conv_pair_kernel");
     return 0;
 }
@@ -622,7 +674,12 @@ extern "C" int msau_conv_pair_applicable(int dtype, const msau_conv_pair_desc* d
     if (!fwd && !bwd) return 0;
     if (d->add != d->x) return 0;                                  // the ADD operand is read back from the input tile
     if (msau_rowpair_takes(dtype, d)) return 1;                    // 8 channels, bf16: the row-streaming kernel (conv_rows.hip)
-    if (d->flags1 & (MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1 | MSAU_PAIR_COUPLE)) return 0;  // riders of the row-streaming instances only
+    if (d->flags1 & (MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1)) return 0;              // riders of the row-streaming instances only
+    if (d->flags1 & MSAU_PAIR_COUPLE) {                                            // ... the coupling conv: also the 32-channel bf16 forward tile pair
+        static const bool cpl32 = !(std::getenv("MSAU_PAIR_COUPLE32") && std::getenv("MSAU_PAIR_COUPLE32")[0] == '0');
+        if (!(cpl32 && fwd && dtype == MSAU_BF16 && d->C == 32 && !(d->flags2 & MSAU_CONV_POOL) && d->cpl_prev && d->cpl_w && d->cpl_b && d->cpl_y))
+            return 0;
+    }
     const int esz = dtype == MSAU_F32 ? 4 : 2;
     if ((int64_t)d->H * d->W * d->C * esz >= (1ll << 31)) return 0;             // 32-bit lane offsets inside an image
     const int tw = pair_tw(dtype, d);
@@ -683,6 +740,10 @@ extern "C" int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc
         if (bwd) return bits ? launch_pair<T, C8V, TWV, true, false, true, RPWV>(s, a) : launch_pair<T, C8V, TWV, true, false, false, RPWV>(s, a); \
         if (pool) return bits ? launch_pair<T, C8V, TWV, false, true, true, RPWV>(s, a) : launch_pair<T, C8V, TWV, false, true, false, RPWV>(s, a); \
         return bits ? launch_pair<T, C8V, TWV, false, false, true, RPWV>(s, a) : launch_pair<T, C8V, TWV, false, false, false, RPWV>(s, a); }
+    if (dtype == MSAU_BF16 && (d->flags1 & MSAU_PAIR_COUPLE)) {                    // (applicable: forward, 32 channels, no pooled y)
+        if (d->cpl_pool_y) return bits ? launch_pair<bf16_t, 4, 1, false, false, true, MSAU_PAIR_RPW32, 2>(s, a) : launch_pair<bf16_t, 4, 1, false, false, false, MSAU_PAIR_RPW32, 2>(s, a);
+        return bits ? launch_pair<bf16_t, 4, 1, false, false, true, MSAU_PAIR_RPW32, 1>(s, a) : launch_pair<bf16_t, 4, 1, false, false, false, MSAU_PAIR_RPW32, 1>(s, a);
+    }
     if (dtype == MSAU_BF16) {
         PAIR_CASE(bf16_t, 1, 1, 4) PAIR_CASE(bf16_t, 1, 2, 4) PAIR_CASE(bf16_t, 2, 1, 4) PAIR_CASE(bf16_t, 2, 2, 4) PAIR_CASE(bf16_t, 4, 1, MSAU_PAIR_RPW32)
     } else {

@@ -651,7 +651,8 @@ def test_first_conv_nchw_refuses_what_it_does_not_implement():
 
 
 @pytest.mark.parametrize("c,hw,B,pool", [(8, (57, 61), 3, False), (8, (64, 90), 2, True), (8, (71, 250), 2, True), (8, (33, 31), 4, False),
-                                          (16, (60, 129), 2, False), (16, (49, 70), 3, True), (16, (40, 15), 2, True), (16, (16, 28), 4, False)])
+                                          (16, (60, 129), 2, False), (16, (49, 70), 3, True), (16, (40, 15), 2, True), (16, (16, 28), 4, False),
+                                          (32, (84, 64), 2, True), (32, (29, 33), 3, False), (32, (21, 16), 2, True), (32, (14, 14), 1, False)])
 def test_coupling_conv_in_the_residual_pairs_forward_launch(monkeypatch, c, hw, B, pool):
     """MSAU_PAIR_COUPLE (round 5): z = ReLU(conv1x1(concat(prev, y))) of a coupled stage (model/model.py:143-148,246-252) computed by
     the row-streaming pair's forward launch from the finished row of y, optionally with the zero-padded 2x2 max pool of z
@@ -704,7 +705,8 @@ def test_coupling_conv_in_the_residual_pairs_forward_launch(monkeypatch, c, hw, 
         L.load().msau_reload_env()
     (plan1, cp1, _, _), (plan0, cp0, _, _) = seen
     assert plan1.pairs[0].active and cp1.cpl_fused_into is plan1.pairs[0] and cp0.cpl_fused_into is None
-    assert plan1.pairs[0].key.startswith("rowpair_kernel") and plan0.pairs[0].key.startswith("rowpair_kernel")
+    # (32 channels: the tile pair conv_pair_kernel<C32> carries the rider -- the epilogue's result layout is the 1x1 conv's B fragment)
+    assert plan1.pairs[0].key.startswith("rowpair_kernel" if c < 32 else "conv_pair_kernel") and plan0.pairs[0].key == plan1.pairs[0].key
     if pool:
         assert any(isinstance(o, PoolOp) and o.fused_into is plan1.pairs[0] for o in plan1.ops)
     assert torch.equal(mids["1"][1], mids["0"][1]), "the block's own output"
