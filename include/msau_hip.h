@@ -220,6 +220,15 @@ enum { MSAU_PAIR_RELU_IN = 1, MSAU_PAIR_RELU_MID = 2, MSAU_PAIR_MASK_MID = 4,
                                    of z (cpl_pool_idx: the 1-byte positions, may be NULL), as MSAU_CONV_POOL does for y.  The row-streaming
                                    8- and 16-channel instances and the 32-channel bf16 tile pair have it (msau_conv_pair_applicable
                                    says so); not together with MSAU_CONV_POOL in flags2. */
+       MSAU_PAIR_DCOUPLE = 128, /* backward flag set only: the block's output y feeds nothing but a coupling conv z = ReLU(Wc concat(prev, y) + bc)
+                                   whose two-output data gradient (MSAU_CONV_DOUT) becomes the PROLOGUE of this launch: the input tile is read
+                                   from dcp_dz = d(z) (masked by z > 0 already) instead of x, and
+                                       g = d(y) = (Wc[:, y]^T d(z)) . [dcp_mask > 0]   (dcp_mask = y)   feeds the two data gradients below AND is
+                                                                                      written to x -- the weight gradient of the block's second
+                                                                                      conv reads it there AFTER this launch
+                                       d(prev)  =  Wc[:, prev]^T d(z)                 written to dcp_dprev (plain write: nothing accumulated, no mask)
+                                   dcp_w = the packed two-output data-gradient image of the coupling conv (msau_conv_pack_geometry(C, 0, 2C, 1x1)).
+                                   The 32-channel bf16 tile pair has it (msau_conv_pair_applicable says so). */
        MSAU_PAIR_TILES = 8 };   /* take the tile kernels (conv_pair.hip) even where the row-streaming kernel has an instance: the
                                    forward and the backward launch of one block must agree on the layout of the mask planes, so a
                                    caller whose forward carries a flag only the tile kernels implement (MSAU_CONV_POOL) sets this on
@@ -257,6 +266,10 @@ typedef struct {
     void* cpl_y;                /* ... its output z                                                                       */
     void* cpl_pool_y;           /* ... NULL, or the pooled z [B][ceil(H/2)][ceil(W/2)][C]                                 */
     uint8_t* cpl_pool_idx;      /* ... and its 1-byte positions (may be NULL)                                             */
+    const void* dcp_dz;         /* MSAU_PAIR_DCOUPLE: gradient of the coupling conv's output, [B][H][W][C]                */
+    const void* dcp_w;          /* ... its packed two-output data-gradient image (2C rows)                                */
+    const void* dcp_mask;       /* ... the block's forward output y (ReLU mask of d(y))                                   */
+    void* dcp_dprev;            /* ... gradient w.r.t. the coupling conv's first source (written)                         */
 } msau_conv_pair_desc;
 int msau_conv_pair_applicable(int dtype, const msau_conv_pair_desc* d);
 int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc* d);

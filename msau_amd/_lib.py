@@ -33,10 +33,10 @@ class ConvPairDesc(C.Structure):
                [(n, vp) for n in ("x", "w1", "b1", "mask_mid", "mid", "w2", "b2", "add", "mask_a", "mask_b", "y", "pool_y", "pool_idx", "bits_mid", "bits_a",
                                   "lrn_a", "lrn_da")] + \
                [("lrn_alpha_over_n", f32), ("lrn_beta", f32), ("lrn_k", f32), ("reserved0", i32), ("wg1_x", vp), ("wg1_slabs", vp), ("wg1_nslabs", i32), ("reserved1", i32)] + \
-               [(n, vp) for n in ("cpl_prev", "cpl_w", "cpl_b", "cpl_y", "cpl_pool_y", "cpl_pool_idx")]
+               [(n, vp) for n in ("cpl_prev", "cpl_w", "cpl_b", "cpl_y", "cpl_pool_y", "cpl_pool_idx", "dcp_dz", "dcp_w", "dcp_mask", "dcp_dprev")]
 
 
-PAIR_RELU_IN, PAIR_RELU_MID, PAIR_MASK_MID, PAIR_TILES, PAIR_LRN_BWD, PAIR_WGRAD1, PAIR_COUPLE = 1, 2, 4, 8, 16, 32, 64
+PAIR_RELU_IN, PAIR_RELU_MID, PAIR_MASK_MID, PAIR_TILES, PAIR_LRN_BWD, PAIR_WGRAD1, PAIR_COUPLE, PAIR_DCOUPLE = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 class BoxArgs(C.Structure):

@@ -125,10 +125,17 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned of
 // channel tiles the epilogue's result layout IS the MFMA's B-fragment layout -- a lane holds channels 8 lg .. 8 lg + 7 of its pixel -- so
 // the rounded y goes from the epilogue's registers straight into the 1x1 conv: two MFMAs per channel tile and row (prev, then y: the
 // stand-alone launch's chunk order), `prev` one 16-byte load per lane and row issued ahead of the tile's phases, no LDS.
-template <typename T, int C8, int TW, bool BWD, bool POOL = false, bool BITS = false, int RPW = 4, int CPL = 0>
+// DCP (MSAU_PAIR_DCOUPLE, 32 channels, backward): the coupling conv's two-output data gradient as a PROLOGUE.  The launch's input tile
+// is d(z), the gradient of the coupling conv's output, with the tile's 2-pixel halo; phase 0 turns it IN PLACE (LDS) into the tile of
+// g = d(y) = (Wc[:, y]^T d(z)) . [y > 0] the two phases below read -- pointwise, so the halo costs 324 / 196 of the 1x1 conv's MFMAs
+// (42 per tile) and no extra bytes -- and writes g and d(prev) = Wc[:, prev]^T d(z) of the tile's own pixels (the weight gradients
+// of the block's second conv and of the previous stage read them).  A wave owns column tiles of 16 consecutive tile pixels; the
+// result layout is the B-fragment layout again (two channel tiles), so a lane writes back the 16 bytes it read.
+template <typename T, int C8, int TW, bool BWD, bool POOL = false, bool BITS = false, int RPW = 4, int CPL = 0, bool DCP = false>
 __global__ __launch_bounds__((PairCfg<T, C8, TW, BWD, RPW>::NT)) void conv_pair_kernel(const PairArgs a) {
     static_assert(!(BWD && POOL), "the pooled output belongs to the forward launch");
     static_assert(CPL == 0 || (!BWD && !POOL && C8 == 4 && sizeof(T) == 2), "the coupling rider: forward, 32 channels, bf16");
+    static_assert(!DCP || (BWD && C8 == 4 && TW == 1 && sizeof(T) == 2), "the coupling data-gradient prologue: backward, 32 channels, bf16");
     static_assert(RPW == 4 || RPW == 2, "rows per wave");
     using Cfg = PairCfg<T, C8, TW, BWD, RPW>;
     typedef typename Vec8<T>::type V8;
@@ -199,6 +206,8 @@ __global__ __launch_bounds__((PairCfg<T, C8, TW, BWD, RPW>::NT)) void conv_pair_
     const int rt_lane = ch_ok ? Cfg::X_BYTES + jcol * PS + ch0 * ESZ : Cfg::LDS + (lane & 15) * 16;
 
     V8 pre_x[Cfg::NITX];
+    constexpr int NCT0 = (Cfg::NPIX + 15) / 16, NP0 = (NCT0 + NT / 64 - 1) / (NT / 64);   // DCP: column tiles of the input tile, per wave
+    V8 pre_o[DCP ? NP0 : 1];                                                               // ... and the y values (ReLU mask) at their pixels
     V8 pre_m[BWD && !BITS ? Cfg::NITM : 1], pre_a[BWD && !BITS ? Cfg::NITM : 1];
     unsigned char bit_m[BWD && BITS ? Cfg::NITM : 1], bit_a[BWD && BITS ? Cfg::NITM : 1];
     constexpr int NITB = (16 * IW * C8) / NT;                      // bit-plane items (a byte each) per thread
@@ -213,7 +222,18 @@ __global__ __launch_bounds__((PairCfg<T, C8, TW, BWD, RPW>::NT)) void conv_pair_
         int b, ty0, tx0;
         decode(live ? tile : 0, b, ty0, tx0);
         const long long img = (long long)b * img_bytes;
-        const __amdgpu_buffer_rsrc_t rx = image_rsrc(static_cast<const char*>(d.x) + img, live ? img_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t rx = image_rsrc(static_cast<const char*>(DCP ? d.dcp_dz : d.x) + img, live ? img_bytes : 0u);
+        if constexpr (DCP) {
+            const __amdgpu_buffer_rsrc_t ro = image_rsrc(static_cast<const char*>(d.dcp_mask) + img, live ? img_bytes : 0u);
+#pragma unroll
+            for (int i = 0; i < NP0; ++i) {
+                const int p = (wave_all + i * (NT / 64)) * 16 + lr;                       // tile pixel of this lane in its i-th column tile
+                const int iy = p / XW, ix = p - iy * XW;
+                const int vy = ty0 - 2 + iy, vx = tx0 - 2 + ix;
+                const bool ok = p < Cfg::NPIX && (unsigned)vy < (unsigned)H && (unsigned)vx < (unsigned)W;
+                pre_o[i] = buf_load8<T>(ro, ok ? (unsigned)(vy * a.row + vx * a.px + lg * 8 * ESZ) : kOOB);
+            }
+        }
         constexpr int NITEMS = Cfg::NPIX * C8;
 #pragma unroll
         for (int it = 0; it < Cfg::NITX; ++it) {
@@ -292,6 +312,21 @@ __global__ __launch_bounds__((PairCfg<T, C8, TW, BWD, RPW>::NT)) void conv_pair_
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) cbias[ct] = *reinterpret_cast<const f32x4*>(d.cpl_b + ch0 + ct * 4);
     }
+    // DCP: rows of the two-output data-gradient image ([2C rows][kchunk 32], msau_conv2d's row order for 4 channel tiles: slot
+    // ct4*16 + 4 q4 + j <-> output channel 16 q4 + 4 ct4 + j, first C = prev, last C = y) picked per lane so that MFMA row lr of channel
+    // tile ct is channel 8 (lr >> 2) + 4 ct + (lr & 3) of its half: the two-tile result layout
+    V8 dA[DCP ? 2 : 1][DCP ? CT : 1];
+    if constexpr (DCP) {
+        const T* dw = static_cast<const T*>(d.dcp_w);
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int call = half * Cfg::C + (lr >> 2) * 8 + ct * 4 + (lr & 3);
+                const int slot = ((call >> 2) & 3) * 16 + 4 * (call >> 4) + (call & 3);
+                dA[half][ct] = load8<T>(dw + slot * 32 + lg * 8);
+            }
+    }
     int tile0 = blockIdx.x, tend = a.ntiles, tstep = gridDim.x;
     if (a.per_xcd) {
         const int xcd = blockIdx.x & 7;
@@ -313,6 +348,42 @@ __global__ __launch_bounds__((PairCfg<T, C8, TW, BWD, RPW>::NT)) void conv_pair_
         int b, ty0, tx0;
         decode(tile, b, ty0, tx0);
         const long long img = (long long)b * img_bytes;
+        if constexpr (DCP) {
+            // ================= phase 0: the input tile d(z) -> g = (Wy^T d(z)) . [y > 0] in place; g and d(prev) of the own pixels out ====
+            const __amdgpu_buffer_rsrc_t rg = image_rsrc(const_cast<char*>(static_cast<const char*>(d.x)) + img, img_bytes);
+            const __amdgpu_buffer_rsrc_t rdp = image_rsrc(static_cast<char*>(d.dcp_dprev) + img, img_bytes);
+#pragma unroll
+            for (int i = 0; i < NP0; ++i) {
+                const int t = wave_all + i * (NT / 64);                                    // wave-uniform
+                if (t < NCT0) {
+                    const int p = t * 16 + lr;
+                    const bool valid = p < Cfg::NPIX;
+                    unsigned char* slot = xt + (valid ? p : 0) * PS + lg * 8 * ESZ;
+                    const V8 bz = *reinterpret_cast<const V8*>(slot);
+                    const int iy = p / XW, ix = p - iy * XW;
+                    const int vy = ty0 - 2 + iy, vx = tx0 - 2 + ix;
+                    const bool own = valid && iy >= 2 && iy < 2 + Cfg::OH && ix >= 2 && ix < 2 + Cfg::OW && vy < H && vx < W;
+                    const unsigned goff = own ? (unsigned)(vy * a.row + vx * a.px + lg * 8 * ESZ) : kOOB;
+                    V4 gq[CT], pq[CT];
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const f32x4 gp = mma8(dA[0][ct], bz, f32x4{0.f, 0.f, 0.f, 0.f});
+                        const f32x4 gy = mma8(dA[1][ct], bz, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            pq[ct][jj] = (T)gp[jj];
+                            gq[ct][jj] = (T)(((float)pre_o[i][ct * 4 + jj] > 0.f) ? gy[jj] : 0.f);       // MSAU_CONV_MASK_B of the y half
+                        }
+                    }
+                    const V8 gv = __builtin_shufflevector(gq[0], gq[CT - 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const V8 pv = __builtin_shufflevector(pq[0], pq[CT - 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    if (valid) *reinterpret_cast<V8*>(slot) = gv;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gv), rg, goff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pv), rdp, goff, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
         // the coupling conv's first source at this lane's output pixels, k-group lg (ahead of the next tile's prefetch: vmcnt retires in order)
         V8 cprev[CPL ? RPW : 1];
         if constexpr (CPL != 0) {
@@ -594,7 +665,7 @@ __global__ __launch_bounds__((PairCfg<T, C8, TW, BWD, RPW>::NT)) void conv_pair_
 #endif
 }
 
-template <typename T, int C8, int TW, bool BWD, bool POOL = false, bool BITS = false, int RPW = 4, int CPL = 0>
+template <typename T, int C8, int TW, bool BWD, bool POOL = false, bool BITS = false, int RPW = 4, int CPL = 0, bool DCP = false>
 int launch_pair(hipStream_t s, const PairArgs& a0) {
     using Cfg = PairCfg<T, C8, TW, BWD, RPW>;
     static_assert(Cfg::LDS + Cfg::LDS_PAD + 256 <= MSAU_LDS_LIMIT, "conv_pair instance does not fit the LDS");
@@ -606,7 +677,7 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
     a.mag_ty = (unsigned)((0x100000000ull + a.tiles_y - 1) / a.tiles_y);
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS + Cfg::LDS_PAD > 60 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD, POOL, BITS, RPW, CPL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD, POOL, BITS, RPW, CPL, DCP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, MSAU_LDS_LIMIT);
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_pair: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -617,7 +688,7 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
     if (!per_cu) {
         // (hipOccupancyMaxActiveBlocksPerMultiprocessor budgets 64 KB of LDS per CU, not gfx950's 160 KB: compute it here)
         hipFuncAttributes fa;
-        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD, POOL, BITS, RPW, CPL>));
+        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_pair_kernel<T, C8, TW, BWD, POOL, BITS, RPW, CPL, DCP>));
         if (e != hipSuccess) return msau_set_error(MSAU_ERR_HIP, "conv_pair: hipFuncGetAttributes: %s", hipGetErrorString(e));
         const int vgprs = ((fa.numRegs > 0 ? fa.numRegs : 64) + 7) & ~7;
         int waves_per_simd = 512 / vgprs;                      // 512 VGPRs per SIMD lane, 8 waves at most
@@ -637,7 +708,7 @@ int launch_pair(hipStream_t s, const PairArgs& a0) {
         grid &= ~7;
         a.per_xcd = cdiv(a.ntiles, 8);
     }
-    hipLaunchKernelGGL((conv_pair_kernel<T, C8, TW, BWD, POOL, BITS, RPW, CPL>), dim3(grid), dim3(Cfg::NT), Cfg::LDS + Cfg::LDS_PAD, s, a);
+    hipLaunchKernelGGL((conv_pair_kernel<T, C8, TW, BWD, POOL, BITS, RPW, CPL, DCP>), dim3(grid), dim3(Cfg::NT), Cfg::LDS + Cfg::LDS_PAD, s, a);
     MSAU_CHECK_LAUNCH("conv_pair_kernel");
     return 0;
 }
@@ -668,13 +739,21 @@ extern "C" int msau_conv_pair_applicable(int dtype, const msau_conv_pair_desc* d
     if ((d->C != 8 && d->C != 16 && d->C != 32) || (d->C > maxc && !(tiny && d->C == 32))) return 0;
     if (dtype == MSAU_F32 && d->C == 32) return 0;                 // two fp32 tiles + two weight sets exceed the LDS
     if (d->B <= 0 || d->H <= 0 || d->W <= 0) return 0;
-    const int f1 = d->flags1 & ~(MSAU_PAIR_TILES | MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1 | MSAU_PAIR_COUPLE);
+    const int f1 = d->flags1 & ~(MSAU_PAIR_TILES | MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1 | MSAU_PAIR_COUPLE | MSAU_PAIR_DCOUPLE);
     const bool fwd = f1 == kFwd1 && (d->flags2 & ~MSAU_CONV_POOL) == kFwd2, bwd = f1 == kBwd1 && d->flags2 == kBwd2;
     if (fwd && (d->flags2 & MSAU_CONV_POOL) && !d->pool_y) return 0;
     if (!fwd && !bwd) return 0;
     if (d->add != d->x) return 0;                                  // the ADD operand is read back from the input tile
+    if ((d->flags1 & MSAU_PAIR_DCOUPLE) && !bwd) return 0;
+    if ((d->flags1 & MSAU_PAIR_COUPLE) && !fwd) return 0;
     if (msau_rowpair_takes(dtype, d)) return 1;                    // 8 channels, bf16: the row-streaming kernel (conv_rows.hip)
     if (d->flags1 & (MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1)) return 0;              // riders of the row-streaming instances only
+    if (d->flags1 & MSAU_PAIR_DCOUPLE) {                                           // the coupling conv's data gradients as the backward's prologue
+        static const bool dcp32 = !(std::getenv("MSAU_PAIR_DCOUPLE32") && std::getenv("MSAU_PAIR_DCOUPLE32")[0] == '0');
+        if (!(dcp32 && dtype == MSAU_BF16 && d->C == 32 && d->dcp_dz && d->dcp_w && d->dcp_mask && d->dcp_dprev)) return 0;
+        msau_conv_pack_geom g;                                                     // the image the prologue indexes: [64 rows][kchunk 32]
+        if (msau_conv_pack_geometry(dtype, 32, 0, 64, 1, 1, 1, 1, 1, &g) != 0 || g.nchunks != 1 || g.kchunk != 32 || g.rows != 64) return 0;
+    }
     if (d->flags1 & MSAU_PAIR_COUPLE) {                                            // ... the coupling conv: also the 32-channel bf16 forward tile pair
         static const bool cpl32 = !(std::getenv("MSAU_PAIR_COUPLE32") && std::getenv("MSAU_PAIR_COUPLE32")[0] == '0');
         if (!(cpl32 && fwd && dtype == MSAU_BF16 && d->C == 32 && !(d->flags2 & MSAU_CONV_POOL) && d->cpl_prev && d->cpl_w && d->cpl_b && d->cpl_y))
@@ -719,7 +798,7 @@ extern "C" int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc
     MSAU_CHECK_ARG(d && d->x && d->w1 && d->w2 && d->mid && (d->y || (d->flags1 & MSAU_PAIR_LRN_BWD)), "conv_pair: null pointer");
     MSAU_CHECK_ARG(msau_conv_pair_applicable(dtype, d), "conv_pair: unsupported shape or flags (C %d, %dx%d, B %d, flags 0x%x / 0x%x; "
                    "MSAU_CONV_ADD must name the input tensor)", d->C, d->H, d->W, d->B, d->flags1, d->flags2);
-    const bool bwd = (d->flags1 & ~(MSAU_PAIR_TILES | MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1)) == kBwd1;
+    const bool bwd = (d->flags1 & ~(MSAU_PAIR_TILES | MSAU_PAIR_LRN_BWD | MSAU_PAIR_WGRAD1 | MSAU_PAIR_DCOUPLE)) == kBwd1;
     MSAU_CHECK_ARG(!bwd || (d->mask_mid && d->mask_a) || (d->bits_mid && d->bits_a), "conv_pair: backward without mask_mid / mask_a (tensors or bit planes)");
     MSAU_CHECK_ARG(!d->bits_mid == !d->bits_a, "conv_pair: bits_mid and bits_a come together");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -740,6 +819,8 @@ extern "C" int msau_conv_pair(void* stream, int dtype, const msau_conv_pair_desc
         if (bwd) return bits ? launch_pair<T, C8V, TWV, true, false, true, RPWV>(s, a) : launch_pair<T, C8V, TWV, true, false, false, RPWV>(s, a); \
         if (pool) return bits ? launch_pair<T, C8V, TWV, false, true, true, RPWV>(s, a) : launch_pair<T, C8V, TWV, false, true, false, RPWV>(s, a); \
         return bits ? launch_pair<T, C8V, TWV, false, false, true, RPWV>(s, a) : launch_pair<T, C8V, TWV, false, false, false, RPWV>(s, a); }
+    if (dtype == MSAU_BF16 && (d->flags1 & MSAU_PAIR_DCOUPLE))                     // (applicable: backward, 32 channels)
+        return bits ? launch_pair<bf16_t, 4, 1, true, false, true, MSAU_PAIR_RPW32, 0, true>(s, a) : launch_pair<bf16_t, 4, 1, true, false, false, MSAU_PAIR_RPW32, 0, true>(s, a);
     if (dtype == MSAU_BF16 && (d->flags1 & MSAU_PAIR_COUPLE)) {                    // (applicable: forward, 32 channels, no pooled y)
         if (d->cpl_pool_y) return bits ? launch_pair<bf16_t, 4, 1, false, false, true, MSAU_PAIR_RPW32, 2>(s, a) : launch_pair<bf16_t, 4, 1, false, false, false, MSAU_PAIR_RPW32, 2>(s, a);
         return bits ? launch_pair<bf16_t, 4, 1, false, false, true, MSAU_PAIR_RPW32, 1>(s, a) : launch_pair<bf16_t, 4, 1, false, false, false, MSAU_PAIR_RPW32, 1>(s, a);

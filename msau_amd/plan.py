@@ -112,6 +112,7 @@ class ConvOp(Op):
         self.cpl_fused_into: Optional["PairOp"] = None   # on a coupling conv: the pair whose forward launch computes it (MSAU_PAIR_COUPLE)
         self.proj: Optional["ProjBwd"] = None       # on an attention projection: the fused data-gradient launch of f, g, h
         self.dgrad2 = None                          # a 64 + 64-channel 1x1 conv: both data gradients in one launch (msau_dgrad2_1x1)
+        self.dgrad_in_pair: Optional["PairOp"] = None   # on a coupling conv: the pair whose BACKWARD launch computes its two data gradients (MSAU_PAIR_DCOUPLE)
         if kind == "conv" and k == 1 and x2 is not None and relu_out and not relu_in and fwd_add is None and plan.ops:
             prod = plan.ops[-1]
             if isinstance(prod, ConvOp) and prod.out is x2 and prod.pair is not None and prod is prod.pair.c2 \
@@ -210,6 +211,17 @@ class ConvOp(Op):
                 e, n = self._pack_entry(gd, self.dd_off, row_is_dim0=False, flip=True, row_off=0,
                                         rows_real=x1.C + x2.C, k1=(out.C, out.Cs), k2=(0, 0))
                 P.add_pack_entry(e, n)
+        # the same image for MSAU_PAIR_DCOUPLE where no two-output instance takes the launch (small images): the prologue of the
+        # residual pair's backward launch only needs the packed weights
+        self.dcp_off = self.dd_off
+        if P.training and conv and self.k == 1 and x2 is not None and self.dd_off is None and None not in self.slots \
+                and x1.C == x1.Cs == x2.C == x2.Cs == out.Cs == 32 and P.dtype == L.BF16 and not P.act_flag \
+                and any(pr.c2.cpl is self for pr in P.pairs):
+            gd = self._geom(out.Cs, 0, x1.Cs + x2.Cs, self.dil, 1, 1)
+            self.dcp_off = P.alloc_pack(gd.bytes)
+            e, n = self._pack_entry(gd, self.dcp_off, row_is_dim0=False, flip=True, row_off=0,
+                                    rows_real=x1.C + x2.C, k1=(out.C, out.Cs), k2=(0, 0))
+            P.add_pack_entry(e, n)
         if P.training and self.dd_off is None:
             for si, x in enumerate((x1, x2)):
                 if x is None or self.slots[si] is None:
@@ -459,7 +471,7 @@ class ConvOp(Op):
                 src_c = (self.x1.C + self.x2.C) if self.dd_off is not None else (self.x1, self.x2)[si].C
                 fl = 2.0 * P.B * (self.out.H * self.out.W if self.kind == "conv" else self.x1.H * self.x1.W) * taps * src_c * self.out.C
                 self.dmeta[si] = conv_meta(dd)
-                if (self.proj is None or not self.proj.active) and self.dgrad2 is None:
+                if (self.proj is None or not self.proj.active) and self.dgrad2 is None and self.dgrad_in_pair is None:
                     P.note_launch(self.dmeta[si][0], self.dmeta[si][1], fl)
         if self.dgrad2 is not None:
             a = self.dgrad2
@@ -524,7 +536,11 @@ class ConvOp(Op):
         if self.pair is not None and self.pair.active and self.pair.bdesc is not None:
             if self is self.pair.c2:                    # both data gradients in one launch, behind the second conv's wgrad
                 rm[C.addressof(self.pair.bdesc)] = (self.pair.key, self.pair.bbytes)
+                if self.pair.dcp is not None:           # (MSAU_PAIR_DCOUPLE: that launch WRITES the gradient this conv's wgrad reads)
+                    return [(L.OP_CONV_PAIR, self.pair.bdesc)] + recs
                 recs.append((L.OP_CONV_PAIR, self.pair.bdesc))
+            return recs
+        if self.dgrad_in_pair is not None:              # a coupling conv whose data gradients are the prologue of the pair's backward launch
             return recs
         if self.proj is not None and self.proj.active:  # f, g, h of an attention block: one launch, behind the last of the three
             return recs + (self.proj.recs() if self is self.proj.f else [])
@@ -562,11 +578,17 @@ class ConvOp(Op):
         if self.dgrad2 is not None:
             L.call("msau_dgrad2_1x1", s, P.dtype, C.byref(self.dgrad2), key=self.d2meta[0])
             return
+        if self.dgrad_in_pair is not None:
+            return
         for si, dd in enumerate(self.ddesc):
             if dd is not None:
                 L.call("msau_conv2d", s, P.dtype, C.byref(dd), key=self.dmeta[si][0])
 
     def bwd(self, s):
+        if self.pair is not None and self.pair.active and self.pair.dcp is not None and self is self.pair.c2:
+            self.bwd_dgrad(s)                           # (MSAU_PAIR_DCOUPLE: the pair launch writes the gradient the wgrad reads)
+            self.bwd_wgrad(s)
+            return
         self.bwd_wgrad(s)
         self.bwd_dgrad(s)
 
@@ -581,6 +603,7 @@ class PairOp:
         self.plan, self.c1, self.c2 = plan, c1, c2
         self.active = False
         self.fdesc = self.bdesc = None
+        self.dcp: Optional[ConvOp] = None            # the coupling conv whose two data gradients this pair's backward launch computes
         c1.pair = c2.pair = self
         plan.pairs.append(self)
 
@@ -714,6 +737,26 @@ class PairOp:
             else:
                 f.flags1 &= ~L.PAIR_COUPLE
                 f.cpl_prev = f.cpl_w = f.cpl_b = f.cpl_y = f.cpl_pool_y = f.cpl_pool_idx = None
+        # ... and its two-output data gradient becomes the PROLOGUE of the backward launch where an instance has that (the 32-channel
+        # tile pair): the launch reads d(z) instead of d(y), computes d(y) for its tile and writes d(y) and d(prev) of its own pixels
+        b = self.bdesc
+        plain = False                                  # d(prev) a plain write, d(y) masked by y and nothing else: what the prologue implements
+        if b is not None and cp is not None and cp.x2 is out and getattr(cp, "dcp_off", None) is not None and out.n_contrib == 1:
+            d1, d2 = cp.ddesc
+            if cp.dd_off is not None:
+                plain = d1 is not None and d1.flags == L.CONV_DOUT and d1.flags2 == L.CONV_MASK_B and d1.mask_b2 == _ptr(out.data)
+            else:
+                plain = d1 is not None and d2 is not None and d1.flags == 0 and d2.flags == L.CONV_MASK_B and d2.mask_b == _ptr(out.data)
+        if plain and os.environ.get("MSAU_PAIR_DCOUPLE", "1") != "0" and P.cfg.get("fuse_couple", True):
+            b.flags1 |= L.PAIR_DCOUPLE
+            b.dcp_dz, b.dcp_w, b.dcp_mask, b.dcp_dprev = _ptr(cp.out.grad), P.pack_ptr(cp.dcp_off), _ptr(out.data), _ptr(cp.x1.grad)
+            if L.load().msau_conv_pair_applicable(P.dtype, C.byref(b)) and L.load().msau_conv_pair_instance(P.dtype, C.byref(b)) == 1:
+                self.dcp = cp
+                cp.dgrad_in_pair = self
+                self.bbytes += 3 * n * esz                             # y (the mask) read, d(y) and d(prev) written; d(z) read in place of d(y)
+            else:
+                b.flags1 &= ~L.PAIR_DCOUPLE
+                b.dcp_dz = b.dcp_w = b.dcp_mask = b.dcp_dprev = None
         # label by the instance that takes the launches (the backward descriptor, once it has its planes, decides for both)
         probe = self.bdesc if self.bdesc is not None else f
         if L.load().msau_conv_pair_instance(P.dtype, C.byref(probe)) == 2:
@@ -739,7 +782,7 @@ class PairOp:
         if self.bdesc is not None:
             for c in (c1, c2):
                 P.unnote_launch(c.dmeta[0][0], c.dmeta[0][1], c.flops)
-            P.note_launch(self.key, self.bbytes, c1.flops + c2.flops)
+            P.note_launch(self.key, self.bbytes, c1.flops + c2.flops + (2.0 * self.dcp.flops if self.dcp is not None else 0.0))
 
 
 class BoxOp(Op):

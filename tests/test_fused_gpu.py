@@ -973,3 +973,64 @@ def test_both_data_gradients_of_the_64_channel_coupling_conv_in_one_launch(monke
     assert err(res["1"][2], xs.grad, True) < 1e-1
     for n in ("w0", "w1", "wc"):
         assert err(res["1"][3][n], ps[n].grad, True) < 1e-1, n
+
+
+@pytest.mark.parametrize("hw,B,pool", [((84, 64), 2, True), ((29, 33), 3, False), ((21, 16), 2, True), ((14, 14), 1, False), ((45, 100), 2, False),
+                                        ((45, 100), 6, False), ((84, 64), 8, True)])       # (the last two: sizes at which the stand-alone form is ONE two-output launch)
+def test_coupling_conv_data_gradients_as_the_prologue_of_the_pairs_backward_launch(monkeypatch, hw, B, pool):
+    """MSAU_PAIR_DCOUPLE (round 5): the two-output data gradient of the coupling conv z = ReLU(Wc concat(prev, y) + bc)
+    (model/model.py:143-148,246-252) at 32 channels as the prologue of the residual pair's backward launch -- the launch reads d(z),
+    computes g = d(y) = (Wc[:, y]^T d(z)) . [y > 0] for its tile incl. the halo in LDS, writes g and d(prev) of its own pixels --
+    against the stand-alone MSAU_CONV_DOUT launch (MSAU_PAIR_DCOUPLE=0): one k-step with the same rounded weights either way, so
+    every gradient is bit-identical."""
+    from msau_amd.plan import PairOp
+    torch.manual_seed(23)
+    H, W = hw
+    c = 32
+    x = torch.randn(B, c, H, W)
+    p = {"w": 0.1 * torch.randn(c, c, 3, 3), "b": 0.1 * torch.randn(c), "w2": 0.1 * torch.randn(c, c, 3, 3), "b2": 0.1 * torch.randn(c),
+         "w0": 0.2 * torch.randn(c, c, 1, 1), "b0": 0.1 * torch.randn(c), "wc": 0.15 * torch.randn(c, 2 * c, 1, 1), "bc": 0.1 * torch.randn(c)}
+    Ho, Wo = ((H + 1) // 2, (W + 1) // 2) if pool else (H, W)
+    gy = torch.randn(B, c, Ho, Wo)
+    seen = []
+
+    def build(plan):
+        x0 = plan.x_in
+        prev = Act(plan, "prev", H, W, c)                   # (no ReLU of its own: this launch then writes its gradient un-masked, as in the net)
+        ConvOp(plan, "c0", x0, None, "w0", "b0", prev, 1)
+        r1 = Act(plan, "r1", H, W, c, relu_out=True)
+        c1 = ConvOp(plan, "c1", x0, None, "w", "b", r1, 3, relu_in=True, relu_out=True)
+        out = Act(plan, "out", H, W, c, relu_out=True)
+        c2 = ConvOp(plan, "c2", r1, None, "w2", "b2", out, 3, relu_out=True, fwd_add=x0)
+        c1.bwd_add = out
+        PairOp(plan, c1, c2)
+        z = Act(plan, "z", H, W, c, relu_out=True)
+        cp = ConvOp(plan, "cpl", prev, out, "wc", "bc", z, 1, relu_out=True)
+        if pool:
+            q = Act(plan, "q", Ho, Wo, c)
+            PoolOp(plan, "p", z, q)
+            plan.logits = q
+        else:
+            plan.logits = z
+        seen.append((plan, cp, out, prev))
+    res, grads = {}, {}
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MSAU_PAIR_DCOUPLE", mode)
+            res[mode] = run_graph(build, p, x, gy, L.BF16)
+            plan, cp, out, prev = seen[-1]
+            grads[mode] = (out.grad.clone(), prev.grad.clone())
+    finally:
+        monkeypatch.undo()
+    (plan1, cp1, _, _), (plan0, cp0, _, _) = seen
+    assert plan1.pairs[0].dcp is cp1 and cp1.dgrad_in_pair is plan1.pairs[0] and plan0.pairs[0].dcp is None and cp0.dgrad_in_pair is None
+    assert plan1.pairs[0].key.startswith("conv_pair_kernel")
+    assert torch.equal(grads["1"][0], grads["0"][0]), "d(y)"
+    assert torch.equal(grads["1"][1], grads["0"][1]), "d(prev)"
+    for a, b in zip(res["1"], res["0"]):
+        if isinstance(a, dict):
+            for n in a:
+                assert torch.equal(a[n], b[n]), n
+        elif a is not None:
+            assert torch.equal(a, b)
+    assert float((grads["1"][0] != 0).float().mean()) > 0.1 and float((grads["1"][1] != 0).float().mean()) > 0.5
